@@ -1,0 +1,139 @@
+"""Circuits the reference's own tests evaluate, restated as data for
+tests/sieve_writer.py (inputs and expected outputs only -- no reference code).
+
+Sources (all under /root/reference/rust/src):
+  arithmetic example  producers/examples.rs:39-70 (inputs), :72-212 (relation)
+  boolean example     producers/boolean_examples.rs:28-68, :70-239
+Expected verdicts: consumers/evaluator.rs:987-1004,1083-1104, cli.rs:574-627.
+"""
+from sieve_writer import int_to_le, write_instance, write_relation, write_witness
+
+BN254_R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+def lit32(v):
+    return v.to_bytes(4, 'little')
+
+
+def arith_example(modulus=101, incorrect=False):
+    """Pythagorean + Fibonacci example; returns (instance, witness, relation) buffers."""
+    mod_le = lit32(modulus) if modulus < 2 ** 32 else int_to_le(modulus)
+    neg_one = bytes([mod_le[0] - 1]) + mod_le[1:]  # examples.rs:236-241 encode_negative_one
+    inst = write_instance(mod_le, [lit32(25), lit32(0), lit32(1)])
+    if incorrect:
+        wit = write_witness(mod_le, [lit32(3), lit32(5), lit32(1), lit32(40)])
+    else:
+        wit = write_witness(mod_le, [lit32(3), lit32(4), lit32(0), int_to_le(17711 % modulus)])
+    mul = 'com.example::mul'
+    functions = [(mul, 1, 2, 0, 0, [('mul', 0, 1, 2)])]
+    gates = [
+        ('witness', 1),
+        ('switch', 1, [0, 2, 4, 5, 6, 9, 10, 11], [bytes([3]), bytes([5])], [
+            ('anon', [1], 3, 3, [
+                ('instance', 0),
+                ('witness', 1),
+                ('call', mul, [2], [8, 8]),
+                ('call', mul, [3], [1, 1]),
+                ('add', 4, 2, 3),
+                ('witness', 9),
+                ('assert_zero', 9),
+                ('instance', 6),
+                ('assert_zero', 6),
+                ('instance', 7),
+                ('witness', 5),
+            ]),
+            ('anon', [1], 3, 2, [
+                ('instance', 0),
+                ('call', mul, [1], [8, 0]),
+                ('witness', 2),
+                ('mul', 3, 1, 2),
+                ('add', 4, 2, 3),
+                ('instance', 5),
+                ('instance', 6),
+                ('witness', 7),
+                ('assert_zero', 5),
+                ('assert_zero', 0),
+            ]),
+        ]),
+        ('constant', 3, neg_one),
+        ('call', mul, [7], [3, 0]),
+        ('add', 8, 6, 7),
+        ('free', 0, 7),
+        ('assert_zero', 8),
+        ('for', 'i', 0, 20, [(12, 32)],
+         ('anon', [('add', ('name', 'i'), ('const', 12))],
+          [('add', ('name', 'i'), ('const', 10)), ('add', ('name', 'i'), ('const', 11))], 0, 0,
+          [('add', 0, 1, 2)])),
+        ('mulc', 33, 32, neg_one),
+        ('add', 34, 9, 33),
+        ('assert_zero', 34),
+        ('for', 'i', 35, 50, [(35, 50)],
+         ('call', mul, [('name', 'i')],
+          [('sub', ('name', 'i'), ('const', 1)), ('sub', ('name', 'i'), ('const', 2))])),
+        ('free', 8, 50),
+    ]
+    rel = write_relation(mod_le, '@add,@mul,@mulc,', '@for,@switch,@function,', functions, gates)
+    return inst, wit, rel
+
+
+def bool_example(incorrect=False):
+    mod_le = bytes([2])
+    inst = write_instance(mod_le, [bytes([v]) for v in (0, 0, 0, 0, 0, 1, 0, 1)])
+    wvals = (1, 1, 1, 0, 0) if incorrect else (1, 0, 1, 0, 0)
+    wit = write_witness(mod_le, [bytes([v]) for v in wvals])
+    adder = 'two_bit_adder'
+    functions = [(adder, 3, 4, 0, 0, [
+        ('xor', 2, 4, 6), ('and', 7, 4, 6), ('xor', 8, 3, 5), ('xor', 1, 7, 8), ('and', 9, 3, 5),
+        ('not', 10, 9), ('and', 11, 8, 7), ('not', 12, 11), ('and', 13, 10, 12), ('not', 0, 13),
+        ('free', 7, 13),
+    ])]
+
+    def lin(c):  # 3*i + c
+        return ('add', ('mul', ('name', 'i'), ('const', 3)), ('const', c))
+    gates = [
+        ('for', 'i', 0, 2, [(0, 2)], ('anon', [('name', 'i')], [], 0, 1, [('witness', 0)])),
+        ('for', 'i', 3, 8, [(3, 8)], ('anon', [('name', 'i')], [], 1, 0, [('instance', 0)])),
+        ('for', 'i', 0, 3, [(9, 20)],
+         ('call', adder, [('range', lin(9), lin(11))], [lin(4), lin(5), lin(7), lin(8)])),
+        ('free', 3, 17),
+        ('xor', 21, 18, 0), ('xor', 22, 19, 1), ('xor', 23, 20, 2),
+        ('assert_zero', 21), ('assert_zero', 22), ('assert_zero', 23),
+        ('free', 0, 2), ('free', 18, 23),
+        ('witness', 24), ('witness', 25),
+        ('switch', 24, [26], [bytes([1]), bytes([0])], [
+            ('anon', [], 2, 0, [('instance', 1), ('instance', 2), ('xor', 0, 1, 2)]),
+            ('anon', [], 2, 0, [('instance', 1), ('instance', 2), ('and', 0, 1, 2)]),
+        ]),
+        ('xor', 27, 26, 25),
+        ('assert_zero', 27),
+        ('free', 24, 27),
+    ]
+    rel = write_relation(mod_le, '@xor,@and,@not,', '@for,@switch,@function,', functions, gates)
+    return inst, wit, rel
+
+
+# (n_ops, sha256 of the backend-op trace, violations)
+GOLDEN_TRACES = {
+    'ref_examples': (208, '2fe5f78a8db88d59c9776731ea5fc5ee51a11f249af1c6b99a337a2add55faf1', []),
+    'arith_101_correct': (277, 'e5c9f4f9cc851e7aef518c609d47e6c416e69709dfd60b2a7eaff6233fe4758e', []),
+    'arith_101_incorrect': (30, '57ab337afefaf46c0be92ca41cde425c15cc476a7ece4c0b7a3a765368cabb59',
+                            ['Wire_9 (may be weighted) should be 0, while it is not']),
+    'bool_correct': (121, 'a735e90dd59f399f54d79081489aac6b10b148e185a850227de610742c955a22', []),
+    'bool_incorrect': (91, '639e0ee24009cbf02b68d59d442e025cfe4b3e227c38bbf2b650181aa176577e',
+                       ['Wire_22 (may be weighted) should be 0, while it is not']),
+    'arith_bn254_correct': (965, 'fc83347734539aa52037cf1dcec3db7485570f51a2af606fa691c10f341dd3b2', []),
+}
+
+
+def golden_case(name):
+    if name == 'arith_101_correct':
+        return arith_example(101)
+    if name == 'arith_101_incorrect':
+        return arith_example(101, incorrect=True)
+    if name == 'bool_correct':
+        return bool_example()
+    if name == 'bool_incorrect':
+        return bool_example(incorrect=True)
+    if name == 'arith_bn254_correct':
+        return arith_example(BN254_R)
+    raise KeyError(name)

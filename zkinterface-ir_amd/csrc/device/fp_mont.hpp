@@ -1,0 +1,156 @@
+// GF(p) arithmetic for the SIEVE IR tape replay kernels (gfx950).
+//
+// Replaces, on device, the arithmetic of the reference's PlaintextBackend
+// (rust/src/consumers/evaluator.rs:908-922: `(a + b) % m`, `(a * b) % m` on
+// num-bigint BigUint).  Wire values live in Montgomery form x*R mod p with
+// R = 2^(64*NL); the stored limbs are NL 64-bit little-endian limbs, handled
+// here as N = 2*NL 32-bit words because the CDNA4 integer multiplier is
+// 32x32 (v_mad_u64_u32).  All results are canonical (< p), which is what makes
+// from_mont(x) bit-identical to the reference's reduced BigUint.
+//
+// Requirements: p odd, p < 2^(32*N).  p = 2 is handled by the Boolean path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zkgpu {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int kMaxWords = 8;  // 256-bit fields
+
+// Per-field constants, passed by value in the kernarg segment (wave-uniform:
+// the compiler keeps them in SGPRs).
+struct FieldParams {
+  u32 p[kMaxWords];    // modulus, little-endian 32-bit words
+  u32 r2[kMaxWords];   // R^2 mod p   (to_mont multiplier)
+  u32 one[kMaxWords];  // R mod p     (Montgomery form of 1)
+  u32 n0inv;           // -p^{-1} mod 2^32
+  u32 nwords;          // N actually used (2, 4, 6 or 8)
+};
+
+template <int N>
+struct Fp {
+  u32 w[N];
+};
+
+template <int N>
+__device__ __forceinline__ bool fp_is_zero(const Fp<N>& a) {
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc |= a.w[i];
+  return acc == 0;
+}
+
+// a >= p ?
+template <int N>
+__device__ __forceinline__ bool fp_geq_p(const Fp<N>& a, const FieldParams& fp) {
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    u64 d = (u64)a.w[i] - fp.p[i] - borrow;
+    borrow = (d >> 63) & 1;  // high bits set on underflow
+  }
+  return borrow == 0;
+}
+
+// r = (a + b) mod p for canonical a, b.
+template <int N>
+__device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
+  Fp<N> s, d;
+  u64 c = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    c += (u64)a.w[i] + b.w[i];
+    s.w[i] = (u32)c;
+    c >>= 32;
+  }
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    u64 t = (u64)s.w[i] - fp.p[i] - borrow;
+    d.w[i] = (u32)t;
+    borrow = (t >> 63) & 1;
+  }
+  // s >= p  <=>  carry-out of the add, or no borrow in the subtract
+  const bool use_d = (c != 0) | (borrow == 0);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = use_d ? d.w[i] : s.w[i];
+  return r;
+}
+
+// Montgomery product a*b*R^{-1} mod p (CIOS over 32-bit words), canonical out.
+template <int N>
+__device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
+  u32 t[N + 2];
+#pragma unroll
+  for (int i = 0; i < N + 2; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    u64 c = 0;
+    const u32 bi = b.w[i];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      c += (u64)a.w[j] * bi + t[j];
+      t[j] = (u32)c;
+      c >>= 32;
+    }
+    c += t[N];
+    t[N] = (u32)c;
+    t[N + 1] = (u32)(c >> 32);
+    const u32 m = t[0] * fp.n0inv;
+    c = (u64)m * fp.p[0] + t[0];
+    c >>= 32;
+#pragma unroll
+    for (int j = 1; j < N; ++j) {
+      c += (u64)m * fp.p[j] + t[j];
+      t[j - 1] = (u32)c;
+      c >>= 32;
+    }
+    c += t[N];
+    t[N - 1] = (u32)c;
+    t[N] = t[N + 1] + (u32)(c >> 32);
+  }
+  // t < 2p here; one conditional subtraction.
+  Fp<N> d;
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    u64 x = (u64)t[i] - fp.p[i] - borrow;
+    d.w[i] = (u32)x;
+    borrow = (x >> 63) & 1;
+  }
+  const bool use_d = (t[N] != 0) | (borrow == 0);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = use_d ? d.w[i] : t[i];
+  return r;
+}
+
+template <int N>
+__device__ __forceinline__ Fp<N> fp_load_const(const u32* __restrict__ w) {
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = w[i];
+  return r;
+}
+
+template <int N>
+__device__ __forceinline__ Fp<N> fp_to_mont(const Fp<N>& a, const FieldParams& fp) {
+  Fp<N> r2;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r2.w[i] = fp.r2[i];
+  return fp_mul<N>(a, r2, fp);
+}
+
+template <int N>
+__device__ __forceinline__ Fp<N> fp_from_mont(const Fp<N>& a, const FieldParams& fp) {
+  Fp<N> one;
+#pragma unroll
+  for (int i = 0; i < N; ++i) one.w[i] = (i == 0) ? 1u : 0u;
+  return fp_mul<N>(a, one, fp);
+}
+
+}  // namespace zkgpu

@@ -1,0 +1,234 @@
+// Tape replay kernels: one lane per witness, wave-uniform tape entries.
+//
+// Device-side equivalent of the reference's hot loop
+// (rust/src/consumers/evaluator.rs:288-301 driving PlaintextBackend
+// :892-946): every value-producing ZKBackend call recorded by the host is one
+// TapeOp; a wavefront executes an op for 64 witnesses at once.
+//
+// Wire table layout in HBM (witness-major inside a 64-lane block):
+//   table[lane_block][slot][chunk][lane 0..63] of 16-byte chunks
+//   chunk c of a value holds 64-bit limbs {2c, 2c+1}; a wave-wide access to
+//   one chunk is one contiguous 1 KiB global_load/store_dwordx4.
+#pragma once
+#include "fp_mont.hpp"
+
+namespace zkgpu {
+
+enum OpKind : u32 {
+  OP_NOP = 0,
+  OP_ADD = 1,       // dst = a + b
+  OP_MUL = 2,       // dst = a * b
+  OP_ADDC = 3,      // dst = a + const[b]
+  OP_MULC = 4,      // dst = a * const[b]
+  OP_COPY = 5,      // dst = a
+  OP_CONST = 6,     // dst = const[a]
+  OP_INSTANCE = 7,  // dst = to_mont(instance[lane][a])
+  OP_WITNESS = 8,   // dst = to_mont(witness[lane][a])
+  OP_ASSERT = 9,    // a must be zero; b = assert sequence number
+  OP_AND = 10,      // boolean-mode ops on {0,1} (arith tables only see them for p=2)
+  OP_XOR = 11,
+  OP_NOT = 12,
+};
+
+struct TapeOp {
+  u32 dst;
+  u32 a;
+  u32 b;
+  u32 kind;
+};
+
+constexpr u32 kNoFail = 0xFFFFFFFFu;
+constexpr u32 kLaneFlagNonCanonical = 1u;
+
+struct ReplayArgs {
+  const TapeOp* ops;      // ops of this launch (device)
+  u32 n_ops;
+  u32 ops_per_wave;       // contiguous ops walked by one wave
+  uint4* table;           // wire table
+  u32 n_slots;            // slots per lane block
+  u32 batch;              // real lanes (<= 64 * gridDim.y)
+  const u32* consts;      // constant pool, Montgomery form, N words each
+  const uint8_t* inst;    // [lane][n_inst][4N bytes] little-endian, canonical
+  const uint8_t* wit;     // [lane][n_wit][4N bytes]
+  u32 n_inst;
+  u32 n_wit;
+  u32* first_fail;        // [lane] min assert sequence number that failed
+  u32* lane_flags;        // [lane] sticky flags (non-canonical input ...)
+};
+
+template <int N>
+struct Layout {
+  static constexpr int kChunks = (N + 3) / 4;          // 16-byte chunks (last may be half used)
+  static constexpr int kRecord = kChunks * 64;         // uint4 per (lane block, slot)
+};
+
+template <int N>
+__device__ __forceinline__ Fp<N> wire_load(const uint4* __restrict__ rec) {
+  Fp<N> r;
+#pragma unroll
+  for (int c = 0; c < Layout<N>::kChunks; ++c) {
+    if constexpr (N % 4 == 2) {
+      if (c == Layout<N>::kChunks - 1) {
+        const uint2 v = *reinterpret_cast<const uint2*>(&rec[c * 64]);
+        r.w[4 * c] = v.x;
+        r.w[4 * c + 1] = v.y;
+        continue;
+      }
+    }
+    const uint4 v = rec[c * 64];
+    r.w[4 * c] = v.x;
+    r.w[4 * c + 1] = v.y;
+    r.w[4 * c + 2] = v.z;
+    r.w[4 * c + 3] = v.w;
+  }
+  return r;
+}
+
+template <int N>
+__device__ __forceinline__ void wire_store(uint4* __restrict__ rec, const Fp<N>& r) {
+#pragma unroll
+  for (int c = 0; c < Layout<N>::kChunks; ++c) {
+    if constexpr (N % 4 == 2) {
+      if (c == Layout<N>::kChunks - 1) {
+        *reinterpret_cast<uint2*>(&rec[c * 64]) = make_uint2(r.w[4 * c], r.w[4 * c + 1]);
+        continue;
+      }
+    }
+    rec[c * 64] = make_uint4(r.w[4 * c], r.w[4 * c + 1], r.w[4 * c + 2], r.w[4 * c + 3]);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ Fp<N> input_load(const uint8_t* __restrict__ base, u32 lane_g, u32 n_vals,
+                                            u32 idx, bool valid) {
+  Fp<N> r;
+  if (valid) {
+    const u32* p = reinterpret_cast<const u32*>(base + ((size_t)lane_g * n_vals + idx) * (4 * N));
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.w[i] = p[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.w[i] = 0;
+  }
+  return r;
+}
+
+// One wave = 64 witnesses x `ops_per_wave` consecutive tape ops.
+// PIPE: operands of op i+1 are requested before op i is computed; legal only
+// when the ops of one wave are mutually independent (a level of the schedule).
+template <int N, bool PIPE>
+__global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, const FieldParams fp) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 lb = blockIdx.y;
+  const u32 gw = blockIdx.x * (blockDim.x >> 6) + wave;
+  const u32 begin = gw * args.ops_per_wave;
+  if (begin >= args.n_ops) return;
+  const u32 end = min(args.n_ops, begin + args.ops_per_wave);
+  const u32 lane_g = lb * 64 + lane;
+  const bool lane_valid = lane_g < args.batch;
+  uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
+  constexpr int REC = Layout<N>::kRecord;
+
+  auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_NOP; };
+  auto needs_b = [](u32 k) { return k == OP_ADD || k == OP_MUL || k == OP_AND || k == OP_XOR; };
+
+  TapeOp op = args.ops[begin];
+  Fp<N> a, b;
+  if (needs_a(op.kind)) a = wire_load<N>(T + (size_t)op.a * REC);
+  if (needs_b(op.kind)) b = wire_load<N>(T + (size_t)op.b * REC);
+
+  for (u32 i = begin; i < end; ++i) {
+    TapeOp nop;
+    Fp<N> na, nb;
+    nop.kind = OP_NOP;
+    if (PIPE && i + 1 < end) {
+      nop = args.ops[i + 1];
+      if (needs_a(nop.kind)) na = wire_load<N>(T + (size_t)nop.a * REC);
+      if (needs_b(nop.kind)) nb = wire_load<N>(T + (size_t)nop.b * REC);
+    }
+    Fp<N> r;
+    bool has_out = true;
+    switch (op.kind) {
+      case OP_ADD: r = fp_add<N>(a, b, fp); break;
+      case OP_MUL: r = fp_mul<N>(a, b, fp); break;
+      case OP_ADDC: r = fp_add<N>(a, fp_load_const<N>(args.consts + (size_t)op.b * N), fp); break;
+      case OP_MULC: r = fp_mul<N>(a, fp_load_const<N>(args.consts + (size_t)op.b * N), fp); break;
+      case OP_COPY: r = a; break;
+      case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a * N); break;
+      case OP_INSTANCE:
+      case OP_WITNESS: {
+        const bool is_inst = op.kind == OP_INSTANCE;
+        Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit,
+                                  op.a, lane_valid);
+        if (fp_geq_p<N>(raw, fp)) {
+          // The reference keeps unreduced inputs (evaluator.rs:862-864,940-946);
+          // this path only claims parity for canonical ones: flag the lane.
+          atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+        }
+        r = fp_to_mont<N>(raw, fp);
+        break;
+      }
+      case OP_ASSERT: {
+        has_out = false;
+        const bool nz = !fp_is_zero<N>(a);
+        if (__ballot(nz && lane_valid) != 0ull) {
+          if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b);
+        }
+        break;
+      }
+      default: has_out = false; break;
+    }
+    if (has_out) wire_store<N>(T + (size_t)op.dst * REC, r);
+    if (PIPE) {
+      op = nop;
+      a = na;
+      b = nb;
+    } else if (i + 1 < end) {
+      op = args.ops[i + 1];
+      if (needs_a(op.kind)) a = wire_load<N>(T + (size_t)op.a * REC);
+      if (needs_b(op.kind)) b = wire_load<N>(T + (size_t)op.b * REC);
+    }
+  }
+}
+
+// Final verdict reduction: satisfied = lanes with no failing assert and no flag.
+// counts[0] += satisfied, counts[1] += failed (u64 each), one atomic per wave.
+__global__ __launch_bounds__(256) void verdict_kernel(const u32* __restrict__ first_fail,
+                                                       const u32* __restrict__ lane_flags, u32 batch,
+                                                       unsigned long long* __restrict__ counts) {
+  const u32 lane_g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = lane_g < batch;
+  const bool ok = valid && first_fail[lane_g] == kNoFail && lane_flags[lane_g] == 0;
+  const unsigned long long okm = __ballot(ok);
+  const unsigned long long vm = __ballot(valid);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long n_ok = __popcll(okm);
+    const unsigned long long n_v = __popcll(vm);
+    if (n_v) {
+      atomicAdd(&counts[0], n_ok);
+      atomicAdd(&counts[1], n_v - n_ok);
+    }
+  }
+}
+
+// Dump one slot of every lane back to canonical little-endian words:
+// out[lane][N] (parity tests; evaluator.rs:750-752 `Evaluator::get`).
+template <int N>
+__global__ __launch_bounds__(64) void dump_slots_kernel(const uint4* __restrict__ table, u32 n_slots,
+                                                        const u32* __restrict__ slots, u32 n_dump, u32 batch,
+                                                        u32* __restrict__ out, const FieldParams fp) {
+  const u32 lane = threadIdx.x & 63;
+  const u32 lb = blockIdx.y;
+  const u32 k = blockIdx.x;
+  const u32 lane_g = lb * 64 + lane;
+  if (k >= n_dump || lane_g >= batch) return;
+  const uint4* T = table + (size_t)lb * n_slots * Layout<N>::kRecord + lane;
+  Fp<N> v = wire_load<N>(T + (size_t)slots[k] * Layout<N>::kRecord);
+  v = fp_from_mont<N>(v, fp);
+  u32* o = out + ((size_t)lane_g * n_dump + k) * N;
+#pragma unroll
+  for (int i = 0; i < N; ++i) o[i] = v.w[i];
+}
+
+}  // namespace zkgpu
