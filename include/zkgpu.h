@@ -1,0 +1,140 @@
+/* zkgpu.h -- C ABI of the MI355X-native SIEVE IR batch evaluator.
+ *
+ * Drop-in boundary for the `evaluate` / `valid-eval-metrics` hot path of
+ * dryajov/zkinterface-ir (zki_sieve 3.0.0).  Three groups of entry points:
+ *
+ *  1. zkgpu_backend_*  -- one function per method of the reference's plugin
+ *     trait `ZKBackend` (rust/src/consumers/evaluator.rs:17-76).  A Rust
+ *     `impl ZKBackend for GpuBackend` binds them 1:1; the
+ *     reference's own `Evaluator` then records the circuit into the GPU tape,
+ *     exactly as it drives `IRFlattener` (rust/src/consumers/flattening.rs:42-191).
+ *  2. zkgpu_ingest_* / zkgpu_declare_inputs -- the `Evaluator` entry points
+ *     (`from_messages`, `ingest_message`; evaluator.rs:187-303) and `Source`
+ *     (rust/src/consumers/source.rs:59-118) for callers without a Rust
+ *     toolchain: size-prefixed `.sieve` FlatBuffers in, tape out.
+ *  3. zkgpu_finalize / zkgpu_set_inputs* / zkgpu_replay / result getters --
+ *     the batch extension: the recorded tape is replayed by HIP kernels for
+ *     `batch` independent (instance, witness) pairs, one lane per witness.
+ *     Lane i behaves like the i-th run of `zki_sieve evaluate` on the same
+ *     relation (cli.rs:315-320): same verdict, same violation strings.
+ *
+ * Conventions: plain pointers and sizes, no ownership transfer; every byte
+ * buffer is borrowed for the duration of the call.  Functions returning int
+ * return 0 on success and non-zero on failure, with text in zkgpu_last_error().
+ * A session is single-owner and not thread-safe (the reference `Evaluator`
+ * is `&mut self` everywhere).  There is no CPU fallback: replay entry points
+ * fail if no GPU is present.
+ */
+#ifndef ZKGPU_H
+#define ZKGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkgpu_session zkgpu_session;
+
+#define ZKGPU_NO_FAIL 0xFFFFFFFFu        /* first_fail value of a satisfied lane */
+#define ZKGPU_LANE_NONCANONICAL 0x1u     /* lane flag: an input value was >= p   */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+zkgpu_session* zkgpu_session_new(void);                 /* Evaluator::default() + backend */
+void zkgpu_session_free(zkgpu_session* s);
+const char* zkgpu_last_error(const zkgpu_session* s);
+const char* zkgpu_version(void);
+
+/* ---- 1. ZKBackend trait (evaluator.rs:17-76) ----------------------------- */
+/* Wires are uint32 handles owned by the session (like IRFlattener::Wire = WireId). */
+int zkgpu_backend_set_field(zkgpu_session* s, const uint8_t* modulus_le, size_t len, uint32_t degree,
+                            int is_boolean);                                   /* :28 */
+int zkgpu_backend_copy(zkgpu_session* s, uint32_t wire, uint32_t* out);        /* :38 */
+int zkgpu_backend_constant(zkgpu_session* s, const uint8_t* value_le, size_t len, uint32_t* out); /* :41 */
+/* local_wire_id = the id printed in "Wire_{} (may be weighted) should be 0, while it is not" (:357-363) */
+int zkgpu_backend_assert_zero(zkgpu_session* s, uint32_t wire, uint64_t local_wire_id);          /* :46 */
+int zkgpu_backend_add(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out);                  /* :49 */
+int zkgpu_backend_multiply(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out);             /* :51 */
+int zkgpu_backend_add_constant(zkgpu_session* s, uint32_t a, const uint8_t* c_le, size_t len, uint32_t* out); /* :53 */
+int zkgpu_backend_mul_constant(zkgpu_session* s, uint32_t a, const uint8_t* c_le, size_t len, uint32_t* out); /* :55 */
+int zkgpu_backend_and(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out);                  /* :58 */
+int zkgpu_backend_xor(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out);                  /* :60 */
+int zkgpu_backend_not(zkgpu_session* s, uint32_t a, uint32_t* out);                              /* :62 */
+/* instance()/witness() (:66,:75): the FieldElement is the position of the value in the lane's
+ * instance / witness stream; the values themselves arrive per lane through zkgpu_set_inputs. */
+int zkgpu_backend_instance(zkgpu_session* s, uint32_t position, uint32_t* out);
+int zkgpu_backend_witness(zkgpu_session* s, uint32_t position, uint32_t* out);
+
+/* ---- 2. Evaluator / Source entry points ---------------------------------- */
+/* A byte stream of one or more size-prefixed messages (consumers/utils.rs:6-41).
+ * Instance / Witness messages define lane 0's input streams (single-statement use). */
+int zkgpu_ingest_messages(zkgpu_session* s, const uint8_t* data, size_t len);
+/* Files and directories, read in the order of Source::from_dirs_and_files (source.rs:64-89). */
+int zkgpu_ingest_paths(zkgpu_session* s, const char* const* paths, size_t n_paths);
+/* Batch use: announce n_instance / n_witness queued values per lane before the Relation
+ * messages are ingested (what ingest_instance / ingest_witness do for one statement). */
+int zkgpu_declare_inputs(zkgpu_session* s, uint32_t n_instance, uint32_t n_witness);
+/* Evaluator::get_violations() of the recording itself (lane independent part). */
+size_t zkgpu_host_violations(zkgpu_session* s, char* buf, size_t cap);
+
+/* tape inspection (host logic tests, statistics) */
+uint64_t zkgpu_tape_len(const zkgpu_session* s);        /* backend calls, asserts included   */
+uint64_t zkgpu_tape_value_ops(const zkgpu_session* s);  /* value-returning calls             */
+uint64_t zkgpu_tape_asserts(const zkgpu_session* s);
+/* kinds[i] in {1 add,2 mul,3 addc,4 mulc,5 copy,6 constant,7 instance,8 witness,9 assert_zero,
+ *              10 and,11 xor,12 not}; a[i], b[i] = operand handles / constant index / position */
+int zkgpu_tape_dump(const zkgpu_session* s, uint8_t* kinds, uint32_t* a, uint32_t* b, uint64_t cap);
+uint32_t zkgpu_n_constants(const zkgpu_session* s);
+size_t zkgpu_constant_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap);
+
+/* ---- 3. batch replay on the GPU ------------------------------------------ */
+/* Build the device program: levelise, assign wire-table slots (host work; the GPU is first touched
+ * by zkgpu_set_inputs*).
+ * retain_all != 0 keeps every wire value readable afterwards (parity dumps). */
+int zkgpu_finalize(zkgpu_session* s, int retain_all);
+uint32_t zkgpu_elem_bytes(const zkgpu_session* s);   /* bytes per input value: 8*limbs, or 1 for GF(2) */
+uint32_t zkgpu_n_instance(const zkgpu_session* s);   /* values per lane the tape consumes */
+uint32_t zkgpu_n_witness(const zkgpu_session* s);
+/* schedule facts: out[0]=levels out[1]=launches out[2]=slots out[3]=widest level out[4]=sequential launches */
+/* ... out[5]=device ops out[6]=constant words out[7]=words per constant */
+int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]);
+/* the device program itself (host-logic tests interpret it without a GPU): ops4 = {dst,a,b,kind} per op,
+ * launches4 = {first,count,ops_per_wave,sequential} per launch, const_words = constant pool in device form,
+ * slot_of[i] = wire-table slot of tape op i (0xFFFFFFFF for asserts).  Any pointer may be NULL. */
+int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
+                        uint32_t* slot_of);
+
+/* inputs: [batch][n_instance][elem_bytes] and [batch][n_witness][elem_bytes], little-endian */
+int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* witnesses, uint32_t batch);
+int zkgpu_set_inputs_device(zkgpu_session* s, const void* d_instances, const void* d_witnesses, uint32_t batch);
+/* use the values of the ingested Instance / Witness messages as a batch of one */
+int zkgpu_set_inputs_from_messages(zkgpu_session* s);
+/* replay lane groups of this many witnesses one after the other (0 = whole batch at once) */
+int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
+
+int zkgpu_replay(zkgpu_session* s);                  /* asynchronous */
+int zkgpu_replay_timed(zkgpu_session* s);            /* per-launch HIP events, synchronous */
+int zkgpu_synchronize(zkgpu_session* s);
+float zkgpu_last_replay_ms(const zkgpu_session* s);  /* HIP-event time of the last replay */
+/* per-launch timings of the last zkgpu_replay_timed: ms[i], ops[i] for launch i; returns count */
+size_t zkgpu_launch_timings(const zkgpu_session* s, float* ms, uint32_t* ops, size_t cap);
+
+/* results (synchronise first) */
+int zkgpu_counts(zkgpu_session* s, uint64_t out[2]);          /* {satisfied, failed} */
+void* zkgpu_counts_device(zkgpu_session* s);                  /* device uint64[2], for an RCCL all-reduce */
+void* zkgpu_stream(zkgpu_session* s);                         /* hipStream_t the replay runs on */
+int zkgpu_lane_results(zkgpu_session* s, uint32_t* first_fail, uint32_t* flags); /* [batch] each */
+/* Evaluator::get_violations() of lane `lane`, '\n'-separated; returns the length needed */
+size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t cap);
+/* retain_all only: out[lane][k][elem_bytes] = value of the k-th value-returning backend call
+ * (k in [first, first+count)), i.e. flattened wire k of IRFlattener's numbering. */
+int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, uint8_t* out);
+/* Evaluator::get(id) (evaluator.rs:750-752) for every lane: out[lane][elem_bytes]; 3 = not found */
+int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out);
+uint64_t zkgpu_table_bytes(const zkgpu_session* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKGPU_H */

@@ -6,7 +6,7 @@ Sources (all under /root/reference/rust/src):
   boolean example     producers/boolean_examples.rs:28-68, :70-239
 Expected verdicts: consumers/evaluator.rs:987-1004,1083-1104, cli.rs:574-627.
 """
-from sieve_writer import int_to_le, write_instance, write_relation, write_witness
+from zkinterface_ir_amd.sieve_writer import int_to_le, write_instance, write_relation, write_witness
 
 BN254_R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 

@@ -1,0 +1,95 @@
+"""Test infrastructure: interprets the *scheduled device program* exported by
+zkgpu_schedule_dump() with Python integers, launch by launch and slot by slot,
+exactly as the HIP kernels would (Montgomery domain for odd p, bits for p=2).
+It lets the CPU-only test tier check the host logic -- tape recording,
+levelisation, slot reuse, constant pool -- against the oracle without a GPU.
+It is not a product path and is never imported outside tests/."""
+
+OP = {'nop': 0, 'add': 1, 'mul': 2, 'addc': 3, 'mulc': 4, 'copy': 5, 'const': 6, 'instance': 7, 'witness': 8,
+      'assert': 9, 'and': 10, 'xor': 11, 'not': 12}
+
+
+def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None):
+    """Run one lane.  instances / witnesses: python ints.  Returns (slots, first_fail_seq, noncanonical).
+    Within a non-sequential launch the ops are executed in a shuffled order when shuffle_seed is given
+    (they must be independent), mimicking the arbitrary order of waves on the GPU."""
+    import random
+    boolean = p == 2
+    if not boolean:
+        nbits = 32 * words_per_const
+        R = 1 << nbits
+        rinv = pow(R, -1, p)
+    consts = []
+    for i in range(len(const_words) // max(words_per_const, 1)):
+        v = 0
+        for k in range(words_per_const):
+            v |= int(const_words[i * words_per_const + k]) << (32 * k)
+        consts.append(v)
+    slots = [None] * n_slots
+    first_fail = None
+    noncanon = False
+    rng = random.Random(shuffle_seed)
+    for (first, count, opw, sequential) in launches:
+        idx = list(range(int(first), int(first) + int(count)))
+        if shuffle_seed is not None and not sequential:
+            rng.shuffle(idx)
+        pending = []
+        reads = set()
+        for i in idx:
+            dst, a, b, kind = (int(x) for x in ops[i])
+            if kind in (OP['add'], OP['mul'], OP['and'], OP['xor']):
+                x, y = slots[a], slots[b]
+                reads.update((a, b))
+                assert x is not None and y is not None, 'read of an unwritten slot'
+                if kind == OP['add']:
+                    r = (x + y) % p
+                elif kind == OP['mul']:
+                    r = x * y * rinv % p
+                elif kind == OP['and']:
+                    r = x & y
+                else:
+                    r = x ^ y
+            elif kind in (OP['addc'], OP['mulc']):
+                x = slots[a]
+                reads.add(a)
+                assert x is not None
+                r = (x + consts[b]) % p if kind == OP['addc'] else x * consts[b] * rinv % p
+            elif kind == OP['copy']:
+                r = slots[a]
+                reads.add(a)
+                assert r is not None
+            elif kind == OP['not']:
+                assert slots[a] is not None
+                reads.add(a)
+                r = 1 - slots[a]
+            elif kind == OP['const']:
+                r = consts[a]
+            elif kind in (OP['instance'], OP['witness']):
+                v = instances[a] if kind == OP['instance'] else witnesses[a]
+                if v >= p:
+                    noncanon = True
+                r = (v & 1) if boolean else (v * R % p)
+            elif kind == OP['assert']:
+                assert slots[a] is not None
+                reads.add(a)
+                if slots[a] != 0 and (first_fail is None or b < first_fail):
+                    first_fail = b
+                continue
+            else:
+                continue
+            if sequential:
+                slots[dst] = r
+            else:
+                pending.append((dst, r))  # a level's writes never feed its own reads
+        written = [d for d, _ in pending]
+        assert len(set(written)) == len(written), 'two ops of one level write the same slot'
+        assert not (reads & set(written)), 'a level overwrites a slot it also reads (race on the GPU)'
+        for dst, r in pending:
+            slots[dst] = r
+    return slots, first_fail, noncanon
+
+
+def from_device_form(v, p, words_per_const):
+    if p == 2 or v is None:
+        return v
+    return v * pow(1 << (32 * words_per_const), -1, p) % p

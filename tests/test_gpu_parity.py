@@ -1,0 +1,193 @@
+"""GPU tier: the HIP path, called through the C ABI, against the oracle.
+
+Bar: bit-exact wire values (integer work) and identical violation strings.  Sizes
+the oracle finishes in seconds are compared wire by wire; the BASELINE.json size
+is checked through size-independent properties (known satisfied count, sampled
+lanes against the oracle, replay idempotence, lane-group invariance)."""
+import numpy as np
+import pytest
+
+import circuits
+from helpers import batch_arrays, golden_buffers, oracle_lane
+from oracle_lib import OracleRun
+import zkinterface_ir_amd as zk
+from zkinterface_ir_amd import sieve_writer as sw
+from zkinterface_ir_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+SINGLE = ['ref_examples', 'arith_101_correct', 'arith_101_incorrect', 'bool_correct', 'bool_incorrect',
+          'arith_bn254_correct']
+
+
+@pytest.mark.parametrize('retain', [True, False])
+@pytest.mark.parametrize('name', SINGLE)
+def test_single_statement_matches_oracle(name, retain):
+    """`zki_sieve evaluate <workspace>` for the reference's own statements: verdict, violation
+    string and (retain) every backend-op value up to the oracle's stopping point."""
+    bufs = golden_buffers(name)
+    ev = zk.Evaluator.from_messages(bufs)
+    ev.finalize(retain_all=retain)
+    ev.set_inputs_from_messages()
+    ev.replay()
+    ev.synchronize()
+    ref = OracleRun(buffers=bufs)
+    assert ev.get_violations(0) == ref.violations
+    assert ev.get_violations(0) == circuits.GOLDEN_TRACES[name][2]
+    sat, failed = ev.counts()
+    assert (sat, failed) == ((1, 0) if not ref.violations else (0, 1))
+    if retain:
+        rv = ref.trace_values()
+        assert ev.dump_trace_values(1)[0][:len(rv)] == rv
+
+
+def test_evaluate_helper_prints_reference_verdicts():
+    assert zk.evaluate(golden_buffers('arith_101_correct')) == []
+    assert zk.evaluate(golden_buffers('arith_101_incorrect')) == [
+        'Wire_9 (may be weighted) should be 0, while it is not']
+    inst, wit, rel = golden_buffers('arith_101_correct')
+    assert zk.evaluate([inst, wit]) == ['Did not receive any gate to verify.']
+
+
+def _batched_example(modulus, lanes):
+    """Lane inputs for the arithmetic example relation (examples.rs:72-212): the switch condition
+    (witness 0) stays 3 so the pythagorean branch is live; it checks instance0 == 3^2 + witness1^2
+    and witness3 == fib(22).  Every third lane gets a wrong instance0."""
+    rows_i, rows_w = [], []
+    rng = np.random.default_rng(11)
+    for lane in range(lanes):
+        b = int(rng.integers(0, 2 ** 62)) % modulus
+        good = lane % 3 != 1
+        rows_i.append([(9 + b * b + (0 if good else 1)) % modulus, 0, 1])
+        rows_w.append([3, b, 0, 17711 % modulus])
+    return rows_i, rows_w
+
+
+@pytest.mark.parametrize('modulus', [101, circuits.BN254_R, 2 ** 61 - 1, 2 ** 127 - 1])
+def test_batched_example_matches_oracle_per_lane(modulus):
+    """One relation, many (instance, witness) pairs: lane i == i-th reference run."""
+    lanes = 70  # spans two 64-lane blocks, ragged tail
+    _, _, rel = circuits.arith_example(modulus)
+    rows_i, rows_w = _batched_example(modulus, lanes)
+    ev = zk.Evaluator()
+    ev.declare_inputs(3, 4)
+    ev.ingest_message(rel)
+    assert ev.host_violations() == []
+    ev.finalize(retain_all=True)
+    w = ev.elem_bytes
+    inst, wit = batch_arrays(rows_i, rows_w, w)
+    ev.set_inputs(inst, wit, lanes)
+    ev.replay()
+    ev.synchronize()
+    vals = ev.dump_trace_values(lanes)
+    mod_le = sw.int_to_le(modulus) if modulus >= 2 ** 32 else modulus.to_bytes(4, 'little')
+    n_ok = 0
+    for lane in range(lanes):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], w)
+        assert ev.get_violations(lane) == ref.violations, lane
+        rv = ref.trace_values()
+        assert vals[lane][:len(rv)] == rv, lane
+        n_ok += not ref.violations
+    assert ev.counts() == (n_ok, lanes - n_ok)
+    assert 0 < n_ok < lanes
+
+
+def test_noncanonical_inputs_are_flagged_not_guessed():
+    """The reference keeps inputs unreduced (evaluator.rs:862-864,940-946); this path refuses
+    them per lane instead of silently reducing."""
+    _, _, rel = circuits.arith_example(101)
+    ev = zk.Evaluator()
+    ev.declare_inputs(3, 4)
+    ev.ingest_message(rel)
+    ev.finalize()
+    w = ev.elem_bytes
+    inst, wit = batch_arrays([[25, 0, 1], [25 + 101, 0, 1]], [[3, 4, 0, 36], [3, 4, 0, 36]], w)
+    ev.set_inputs(inst, wit, 2)
+    ev.replay()
+    ev.synchronize()
+    assert ev.get_violations(0) == []
+    v = ev.get_violations(1)
+    assert len(v) == 1 and 'not canonical' in v[0]
+    assert ev.counts() == (1, 1)
+
+
+def _layered_session(wl, batch, lane_group=0):
+    """probe pass (outputs) + full relation; returns (evaluator, inst, wit, n_bad)."""
+    probe = zk.Evaluator()
+    probe.declare_inputs(wl.n_instance0, wl.n_witness)
+    for m in wl.relation_messages(with_epilogue=False, free_last=False):
+        probe.ingest_message(m)
+    assert probe.host_violations() == []
+    probe.finalize()
+    inst, wit = wl.inputs(batch)
+    probe.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), batch)
+    probe.replay()
+    probe.synchronize()
+    outs = np.zeros((batch, wl.n_out, wl.width), dtype=np.uint8)
+    for t, wid in enumerate(wl.output_wire_ids()):
+        vals = probe.get(wid, batch)
+        for lane in range(batch):
+            outs[lane, t] = np.frombuffer(vals[lane].to_bytes(wl.width, 'little'), dtype=np.uint8)
+    probe.close()
+    n_bad = wl.set_expected_outputs(inst, outs)
+    ev = zk.Evaluator()
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in wl.relation_messages():
+        ev.ingest_message(m)
+    assert ev.host_violations() == []
+    ev.finalize()
+    if lane_group:
+        ev.set_lane_group(lane_group)
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    return ev, inst, wit, n_bad
+
+
+def test_layered_relation_small_all_lanes_against_oracle():
+    wl = workloads.ArithLayered(W=256, D=12, n_instance0=16, n_out=8)
+    batch = 130
+    ev, inst, wit, n_bad = _layered_session(wl, batch)
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (batch - n_bad, n_bad)
+    msgs = wl.relation_messages()
+    for lane in list(range(0, batch, 13)) + [97, batch - 1]:
+        iv = [int.from_bytes(inst[lane, k].tobytes(), 'little') for k in range(wl.n_instance)]
+        wv = [int.from_bytes(wit[lane, k].tobytes(), 'little') for k in range(wl.n_witness)]
+        ref = oracle_lane(wl.mod_le, iv, wv, msgs, wl.width, trace=False)
+        assert ev.get_violations(lane) == ref.violations, lane
+        assert (ref.violations == []) == (lane % 97 != 0)
+
+
+def test_full_size_c2_properties():
+    """BASELINE.json configs[1]: BN254, 2^20 Add/Mul gates, batch 1024."""
+    wl = workloads.ArithLayered()  # W=4096, D=256
+    batch = 1024
+    ev, inst, wit, n_bad = _layered_session(wl, batch)
+    assert ev.n_value_ops == 4096 * 257 + 64 * 3 + 64 and ev.n_asserts == 64
+    ev.replay()
+    ev.synchronize()
+    first = ev.lane_results(batch)
+    assert ev.counts() == (workloads.expected_satisfied(batch), n_bad)
+    # corrupted lanes fail at their first output comparison: assert #0 -> local wire id of that Add
+    bad_lanes = [i for i in range(batch) if i % 97 == 0]
+    assert all(first[0][i] == 0 for i in bad_lanes)
+    assert all(first[0][i] == zk.NO_FAIL for i in range(batch) if i % 97)
+    assert ev.get_violations(97) == ['Wire_%d (may be weighted) should be 0, while it is not' % ((wl.D + 1) * wl.W + 2)]
+    # idempotence: a second replay of the same inputs gives the same per-lane words
+    ev.replay()
+    ev.synchronize()
+    again = ev.lane_results(batch)
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+    # lane groups (Infinity-Cache sized passes) do not change results
+    ev.set_lane_group(256)
+    ev.replay()
+    ev.synchronize()
+    grouped = ev.lane_results(batch)
+    assert np.array_equal(first[0], grouped[0])
+    # two sampled lanes of the full relation against the oracle (a good and a corrupted one)
+    msgs = wl.relation_messages()
+    for lane in (5, 97):
+        iv = [int.from_bytes(inst[lane, k].tobytes(), 'little') for k in range(wl.n_instance)]
+        wv = [int.from_bytes(wit[lane, k].tobytes(), 'little') for k in range(wl.n_witness)]
+        ref = oracle_lane(wl.mod_le, iv, wv, msgs, wl.width, trace=False)
+        assert ev.get_violations(lane) == ref.violations

@@ -1,0 +1,174 @@
+"""CPU tier: product host logic (reader, Evaluator, recording backend, scheduler, C ABI
+surface) checked against the oracle.  No GPU call is made here: the scheduled device
+program is interpreted by tests/program_sim.py."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import circuits
+import program_sim
+from helpers import REF_EXAMPLES, ROOT, golden_buffers, oracle_lane
+from oracle_lib import OracleRun
+import zkinterface_ir_amd as zk
+from zkinterface_ir_amd import workloads
+
+INPUTS = {
+    'ref_examples': (101, [25, 0, 1], [3, 4, 36]),
+    'arith_101_correct': (101, [25, 0, 1], [3, 4, 0, 36]),
+    'arith_101_incorrect': (101, [25, 0, 1], [3, 5, 1, 40]),
+    'bool_correct': (2, [0, 0, 0, 0, 0, 1, 0, 1], [1, 0, 1, 0, 0]),
+    'bool_incorrect': (2, [0, 0, 0, 0, 0, 1, 0, 1], [1, 1, 1, 0, 0]),
+    'arith_bn254_correct': (circuits.BN254_R, [25, 0, 1], [3, 4, 0, 17711]),
+}
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'zkgpu.h')).read()
+    declared = set(re.findall(r'\b(zkgpu_[a-z_0-9]+)\s*\(', header))
+    declared.discard('zkgpu_session')
+    L = ctypes.CDLL(zk.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert declared == set(zk.exported_symbols()), declared ^ set(zk.exported_symbols())
+    assert b'gfx950' in zk.lib().zkgpu_version()
+
+
+@pytest.mark.parametrize('name', sorted(INPUTS))
+def test_tape_matches_oracle_trace(name):
+    bufs = golden_buffers(name)
+    ev = zk.Evaluator.from_messages(bufs)
+    kinds, a, b = ev.tape()
+    mine = [zk.KIND_NAMES[k] for k in kinds if k != 9]
+    ref = OracleRun(buffers=bufs)
+    ref_kinds = ref.trace_kinds()
+    # the reference stops at the first failing assert; the tape always records the whole relation
+    assert mine[:len(ref_kinds)] == ref_kinds
+    if not ref.violations:
+        assert len(mine) == len(ref_kinds) and ev.n_asserts == ref.n_asserts
+    assert ev.host_violations() == []
+
+
+@pytest.mark.parametrize('retain', [True, False])
+@pytest.mark.parametrize('name', sorted(INPUTS))
+def test_scheduled_program_matches_oracle(name, retain):
+    p, inst, wit = INPUTS[name]
+    bufs = golden_buffers(name)
+    ev = zk.Evaluator.from_messages(bufs)
+    ev.finalize(retain_all=retain)
+    ops, launches, consts, slot_of = ev.schedule_dump()
+    info = ev.schedule_info()
+    ref = OracleRun(buffers=bufs)
+    for shuffle in (None, 7):
+        slots, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p,
+                                                   inst, wit, shuffle_seed=shuffle)
+        assert not noncanon
+        assert (ff is None) == (ref.violations == [])
+        if retain:
+            kinds, _, _ = ev.tape()
+            vals = [program_sim.from_device_form(slots[slot_of[i]], p, info['words_per_const'])
+                    for i in range(len(kinds)) if kinds[i] != 9]
+            rv = ref.trace_values()
+            assert vals[:len(rv)] == rv
+    if not retain:
+        assert info['slots'] < ev.n_value_ops  # liveness actually reuses slots
+
+
+def test_reader_file_ordering_and_framing(tmp_path):
+    # Source::from_filenames ordering (source.rs:69-89): name sort, then instance < witness < relation
+    ev = zk.Evaluator()
+    ev.ingest_paths(list(reversed(REF_EXAMPLES)))
+    assert ev.host_violations() == []
+    assert ev.n_value_ops == 208 and ev.n_asserts == 2
+    # a directory works too, and several messages may share one buffer / file
+    d = tmp_path / 'ws'
+    d.mkdir()
+    inst, wit, rel = golden_buffers('arith_101_correct')
+    (d / '000_instance.sieve').write_bytes(inst)
+    (d / '001_witness.sieve').write_bytes(wit)
+    (d / '002_relation.sieve').write_bytes(rel)
+    (d / 'notes.txt').write_bytes(b'ignored')
+    ev2 = zk.Evaluator()
+    ev2.ingest_paths([str(d)])
+    assert ev2.n_value_ops == 277
+    ev3 = zk.Evaluator.from_messages([inst + wit + rel + b'\x00\x00\x00\x00' + rel])  # size 0 = end marker
+    assert ev3.n_value_ops == 277
+
+
+def test_recording_errors_use_reference_strings():
+    inst, wit, rel = golden_buffers('arith_101_correct')
+    assert zk.Evaluator.from_messages([inst, wit]).host_violations() == ['Did not receive any gate to verify.']
+    assert zk.Evaluator.from_messages([wit, rel]).host_violations() == ['Not enough instance to consume']
+    v = zk.Evaluator.from_messages([inst, rel]).host_violations()
+    assert len(v) == 1 and 'Missing witness value' in v[0]
+    # same strings as the oracle for structurally broken relations
+    from zkinterface_ir_amd import sieve_writer as sw
+    mod = bytes([101])
+    cases = {
+        'ssa': [('constant', 0, b'\x01'), ('constant', 0, b'\x02')],
+        'missing': [('add', 2, 0, 1)],
+        'unknown_fn': [('call', 'nope', [0], [])],
+        'bad_range': [('constant', 5, b'\x01'), ('anoncall', [(3, 3)], [], 0, 0, [('constant', 0, b'\x01')])],
+        'free_twice': [('constant', 0, b'\x01'), ('free', 0, None), ('free', 0, None)],
+    }
+    for name, gates in cases.items():
+        rel = sw.write_relation(mod, 'arithmetic', '@function,@for,@switch', [], gates)
+        ref = OracleRun(buffers=[rel]).violations
+        got = zk.Evaluator.from_messages([rel]).host_violations()
+        assert got == ref and len(ref) == 1, (name, got, ref)
+    fn = [('f', 1, 2, 0, 0, [('add', 0, 1, 2)])]
+    rel = sw.write_relation(mod, 'arithmetic', '@function', fn,
+                            [('constant', 1, b'\x01'), ('call', 'f', [0], [1])])
+    ref = OracleRun(buffers=[rel]).violations
+    assert zk.Evaluator.from_messages([rel]).host_violations() == ref
+    assert 'Wrong number of input variables' in ref[0]
+
+
+def test_synthetic_workload_small_against_oracle():
+    wl = workloads.ArithLayered(W=32, D=6, n_instance0=4, n_out=3)
+    probe = wl.relation_messages(with_epilogue=False, free_last=False)
+    inst, wit = wl.inputs(3)
+    width = wl.width
+    outs = np.zeros((3, wl.n_out, width), dtype=np.uint8)
+    for lane in range(3):
+        iv = [int.from_bytes(inst[lane, k].tobytes(), 'little') for k in range(wl.n_instance0)]
+        wv = [int.from_bytes(wit[lane, k].tobytes(), 'little') for k in range(wl.n_witness)]
+        assert all(v < wl.p for v in iv + wv)
+        run = oracle_lane(wl.mod_le, iv, wv, probe, width, trace=False)
+        assert run.violations == []
+        for t, wid in enumerate(wl.output_wire_ids()):
+            outs[lane, t] = np.frombuffer(run.get(wid).to_bytes(width, 'little'), dtype=np.uint8)
+    bad = wl.set_expected_outputs(inst, outs, corrupt_every=2)
+    assert bad == 2
+    msgs = wl.relation_messages()
+    for lane in range(3):
+        iv = [int.from_bytes(inst[lane, k].tobytes(), 'little') for k in range(wl.n_instance)]
+        wv = [int.from_bytes(wit[lane, k].tobytes(), 'little') for k in range(wl.n_witness)]
+        run = oracle_lane(wl.mod_le, iv, wv, msgs, width, trace=False)
+        assert (run.violations == []) == (lane % 2 != 0), (lane, run.violations)
+        if not run.violations:
+            assert run.n_live_wires() == 0  # the relation frees everything it creates
+    # the product records exactly the relation's gates (no structured gates here)
+    ev = zk.Evaluator()
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in msgs:
+        ev.ingest_message(m)
+    assert ev.host_violations() == []
+    assert ev.n_value_ops == 32 + 32 * 6 + 3 * 4 and ev.n_asserts == 3
+    ev.finalize()
+    info = ev.schedule_info()
+    assert info['slots'] <= 2 * 32 + 16
+
+
+def test_relation_is_split_into_100k_gate_messages():
+    wl = workloads.ArithLayered(W=4096, D=50)
+    msgs = wl.relation_messages()
+    assert len(msgs) == 3
+    ev = zk.Evaluator()
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in msgs:
+        ev.ingest_message(m)
+    assert ev.host_violations() == []
+    assert ev.n_value_ops == 4096 * 51 + 64 * 4 and ev.n_asserts == 64

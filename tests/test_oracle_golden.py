@@ -1,0 +1,70 @@
+"""CPU tier: the oracle against every golden vector the reference's own tests hold
+for the evaluate path, and the trace digests of SURVEY.md Appendix A."""
+from collections import Counter
+
+import pytest
+
+import circuits
+from helpers import REF_EXAMPLES, golden_buffers
+from oracle_lib import OracleRun, oracle_exp
+
+
+@pytest.mark.parametrize('name', sorted(circuits.GOLDEN_TRACES))
+def test_trace_digest_and_verdict(name):
+    n_ops, sha, violations = circuits.GOLDEN_TRACES[name]
+    run = OracleRun(buffers=golden_buffers(name))
+    assert run.violations == violations
+    assert len(run.trace_kinds()) == n_ops
+    assert run.trace_sha256() == sha
+
+
+def test_committed_fixture_via_file_source():
+    # rust/examples/*.sieve read through the Source ordering rule (source.rs:69-89):
+    # the paths are handed over in the wrong order on purpose.
+    run = OracleRun(files=list(reversed(REF_EXAMPLES)))
+    assert run.violations == []
+    assert Counter(run.trace_kinds()) == {'copy': 99, 'add': 43, 'mul': 37, 'constant': 11, 'instance': 6,
+                                          'witness': 5, 'mulc': 5, 'addc': 2}
+    assert run.n_asserts == 2
+    assert run.n_live_wires() == 0 and run.queue_len(0) == 0 and run.queue_len(1) == 0
+
+
+def test_example_op_histograms():
+    # acceptance numbers for the current examples.rs / boolean_examples.rs relations
+    run = OracleRun(buffers=golden_buffers('arith_101_correct'))
+    assert Counter(run.trace_kinds()) == {'copy': 147, 'mul': 57, 'add': 43, 'constant': 11, 'instance': 6,
+                                          'witness': 6, 'mulc': 5, 'addc': 2}
+    assert run.n_asserts == 6
+    run = OracleRun(buffers=golden_buffers('bool_correct'))
+    assert Counter(run.trace_kinds()) == {'copy': 49, 'xor': 21, 'and': 19, 'not': 14, 'instance': 10,
+                                          'witness': 5, 'constant': 3}
+    assert run.n_asserts == 4
+    run = OracleRun(buffers=golden_buffers('arith_bn254_correct'))
+    assert Counter(run.trace_kinds())['mul'] == 745
+
+
+def test_exponentiation_known_answers():
+    # rust/src/consumers/evaluator.rs:950-984 test_exponentiation
+    assert oracle_exp(2, 2206000150907221872269901214599500635,
+                      16249742125730185677094195492597105093) == 5834907326474057072663503101785122138
+    assert oracle_exp(42, 100, 101) == 1
+    # and against Python's pow on a few more
+    for b, e, m in [(3, 65537, 2 ** 61 - 1), (123456789, circuits.BN254_R - 1, circuits.BN254_R), (7, 1, 101)]:
+        assert oracle_exp(b, e, m) == pow(b, e, m)
+
+
+def test_no_gate_and_latch():
+    inst, wit, rel = golden_buffers('arith_101_incorrect')
+    # no relation at all -> "Did not receive any gate to verify." (evaluator.rs:199-203)
+    assert OracleRun(buffers=[inst, wit]).violations == ['Did not receive any gate to verify.']
+    # after the first error later messages are ignored (evaluator.rs:213-222)
+    run = OracleRun(buffers=[inst, wit, rel, rel])
+    assert run.violations == ['Wire_9 (may be weighted) should be 0, while it is not']
+    assert len(run.trace_kinds()) == 30
+
+
+def test_missing_inputs():
+    inst, wit, rel = golden_buffers('arith_101_correct')
+    assert OracleRun(buffers=[wit, rel]).violations == ['Not enough instance to consume']
+    run = OracleRun(buffers=[inst, rel])  # PlaintextBackend panics on a missing witness (evaluator.rs:944-946)
+    assert run.panicked and 'Missing witness value' in run.violations[0]

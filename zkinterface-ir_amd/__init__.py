@@ -1,0 +1,331 @@
+"""Python binding of libzkgpu.so (include/zkgpu.h) -- plumbing for tests and bench.py.
+
+The product is the C-ABI library: C++ host (`.sieve` ingest, `Evaluator`,
+recording `ZKBackend`, scheduler) + hand-written HIP kernels for gfx950.  This
+module only wraps it with ctypes; it contains no evaluation logic and no CPU
+fallback -- if the library or a GPU is missing the calls raise.
+
+The directory name contains a hyphen, so import it through `load_package()` in
+`__graft_entry__.py` (it registers the module as `zkinterface_ir_amd`).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libzkgpu.so')
+
+NO_FAIL = 0xFFFFFFFF
+LANE_NONCANONICAL = 0x1
+KIND_NAMES = {1: 'add', 2: 'mul', 3: 'addc', 4: 'mulc', 5: 'copy', 6: 'constant', 7: 'instance', 8: 'witness',
+              9: 'assert_zero', 10: 'and', 11: 'xor', 12: 'not'}
+
+_lib = None
+
+
+class ZkGpuError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libzkgpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(['make', '-s', '-C', _HERE, 'clean'])
+    subprocess.check_call(['make', '-s', '-C', _HERE])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZkGpuError('libzkgpu.so is not built (run __graft_entry__.build()); there is no fallback path')
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u8p, u32p, u64p = ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)
+    sz, u32, u64, ci = ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    sig = {
+        'zkgpu_session_new': (vp, []),
+        'zkgpu_session_free': (None, [vp]),
+        'zkgpu_last_error': (ctypes.c_char_p, [vp]),
+        'zkgpu_version': (ctypes.c_char_p, []),
+        'zkgpu_backend_set_field': (ci, [vp, u8p, sz, u32, ci]),
+        'zkgpu_backend_copy': (ci, [vp, u32, u32p]),
+        'zkgpu_backend_constant': (ci, [vp, u8p, sz, u32p]),
+        'zkgpu_backend_assert_zero': (ci, [vp, u32, u64]),
+        'zkgpu_backend_add': (ci, [vp, u32, u32, u32p]),
+        'zkgpu_backend_multiply': (ci, [vp, u32, u32, u32p]),
+        'zkgpu_backend_add_constant': (ci, [vp, u32, u8p, sz, u32p]),
+        'zkgpu_backend_mul_constant': (ci, [vp, u32, u8p, sz, u32p]),
+        'zkgpu_backend_and': (ci, [vp, u32, u32, u32p]),
+        'zkgpu_backend_xor': (ci, [vp, u32, u32, u32p]),
+        'zkgpu_backend_not': (ci, [vp, u32, u32p]),
+        'zkgpu_backend_instance': (ci, [vp, u32, u32p]),
+        'zkgpu_backend_witness': (ci, [vp, u32, u32p]),
+        'zkgpu_ingest_messages': (ci, [vp, u8p, sz]),
+        'zkgpu_ingest_paths': (ci, [vp, ctypes.POINTER(ctypes.c_char_p), sz]),
+        'zkgpu_declare_inputs': (ci, [vp, u32, u32]),
+        'zkgpu_host_violations': (sz, [vp, ctypes.c_char_p, sz]),
+        'zkgpu_tape_len': (u64, [vp]),
+        'zkgpu_tape_value_ops': (u64, [vp]),
+        'zkgpu_tape_asserts': (u64, [vp]),
+        'zkgpu_tape_dump': (ci, [vp, vp, vp, vp, u64]),
+        'zkgpu_n_constants': (u32, [vp]),
+        'zkgpu_constant_bytes': (sz, [vp, u32, ctypes.c_char_p, sz]),
+        'zkgpu_finalize': (ci, [vp, ci]),
+        'zkgpu_elem_bytes': (u32, [vp]),
+        'zkgpu_n_instance': (u32, [vp]),
+        'zkgpu_n_witness': (u32, [vp]),
+        'zkgpu_schedule_info': (ci, [vp, u64p]),
+        'zkgpu_schedule_dump': (ci, [vp, vp, vp, vp, vp]),
+        'zkgpu_set_inputs': (ci, [vp, vp, vp, u32]),
+        'zkgpu_set_inputs_device': (ci, [vp, vp, vp, u32]),
+        'zkgpu_set_inputs_from_messages': (ci, [vp]),
+        'zkgpu_set_lane_group': (ci, [vp, u32]),
+        'zkgpu_replay': (ci, [vp]),
+        'zkgpu_replay_timed': (ci, [vp]),
+        'zkgpu_synchronize': (ci, [vp]),
+        'zkgpu_last_replay_ms': (ctypes.c_float, [vp]),
+        'zkgpu_launch_timings': (sz, [vp, vp, vp, sz]),
+        'zkgpu_counts': (ci, [vp, u64p]),
+        'zkgpu_counts_device': (vp, [vp]),
+        'zkgpu_stream': (vp, [vp]),
+        'zkgpu_lane_results': (ci, [vp, vp, vp]),
+        'zkgpu_lane_violations': (sz, [vp, u32, ctypes.c_char_p, sz]),
+        'zkgpu_dump_trace_values': (ci, [vp, u64, u64, vp]),
+        'zkgpu_get_wire': (ci, [vp, u64, vp]),
+        'zkgpu_table_bytes': (u64, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    L._signatures = sig
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = None  # filled lazily by exported_symbols()
+
+
+def exported_symbols():
+    return sorted(lib()._signatures.keys())
+
+
+class Evaluator:
+    """Host-side mirror of `consumers::evaluator::Evaluator` bound to the GPU
+    tape backend (evaluator.rs:158-303): ingest messages, then evaluate a batch."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = self.L.zkgpu_session_new()
+        if not self.h:
+            raise ZkGpuError('zkgpu_session_new failed')
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.zkgpu_session_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise ZkGpuError(self.L.zkgpu_last_error(self.h).decode())
+
+    # -- Evaluator::from_messages / ingest_message ------------------------------
+    def ingest_message(self, data):
+        data = bytes(data)
+        self._ck(self.L.zkgpu_ingest_messages(self.h, data, len(data)))
+
+    def ingest_paths(self, paths):
+        arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+        self._ck(self.L.zkgpu_ingest_paths(self.h, arr, len(paths)))
+
+    @classmethod
+    def from_messages(cls, buffers):
+        ev = cls()
+        for b in buffers:
+            ev.ingest_message(b)
+        return ev
+
+    def declare_inputs(self, n_instance, n_witness):
+        self._ck(self.L.zkgpu_declare_inputs(self.h, n_instance, n_witness))
+
+    def host_violations(self):
+        n = self.L.zkgpu_host_violations(self.h, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        self.L.zkgpu_host_violations(self.h, buf, n + 1)
+        s = buf.value.decode()
+        return s.split('\n') if s else []
+
+    # -- tape --------------------------------------------------------------------
+    def tape(self):
+        import numpy as np
+        n = self.L.zkgpu_tape_len(self.h)
+        kinds = np.zeros(n, dtype=np.uint8)
+        a = np.zeros(n, dtype=np.uint32)
+        b = np.zeros(n, dtype=np.uint32)
+        if n:
+            self._ck(self.L.zkgpu_tape_dump(self.h, kinds.ctypes.data, a.ctypes.data, b.ctypes.data, n))
+        return kinds, a, b
+
+    def constants(self):
+        out = []
+        for i in range(self.L.zkgpu_n_constants(self.h)):
+            n = self.L.zkgpu_constant_bytes(self.h, i, None, 0)
+            buf = ctypes.create_string_buffer(max(n, 1))
+            self.L.zkgpu_constant_bytes(self.h, i, buf, n)
+            out.append(buf.raw[:n])
+        return out
+
+    @property
+    def n_value_ops(self):
+        return self.L.zkgpu_tape_value_ops(self.h)
+
+    @property
+    def n_asserts(self):
+        return self.L.zkgpu_tape_asserts(self.h)
+
+    # -- batch replay -------------------------------------------------------------
+    def finalize(self, retain_all=False):
+        self._ck(self.L.zkgpu_finalize(self.h, 1 if retain_all else 0))
+
+    @property
+    def elem_bytes(self):
+        return self.L.zkgpu_elem_bytes(self.h)
+
+    @property
+    def n_instance(self):
+        return self.L.zkgpu_n_instance(self.h)
+
+    @property
+    def n_witness(self):
+        return self.L.zkgpu_n_witness(self.h)
+
+    def schedule_info(self):
+        out = (ctypes.c_uint64 * 8)()
+        self._ck(self.L.zkgpu_schedule_info(self.h, out))
+        keys = ['levels', 'launches', 'slots', 'max_width', 'sequential_launches', 'device_ops', 'const_words',
+                'words_per_const']
+        return dict(zip(keys, list(out)))
+
+    def schedule_dump(self):
+        import numpy as np
+        info = self.schedule_info()
+        ops = np.zeros((info['device_ops'], 4), dtype=np.uint32)
+        launches = np.zeros((info['launches'], 4), dtype=np.uint32)
+        consts = np.zeros(max(info['const_words'], 1), dtype=np.uint32)
+        slot_of = np.zeros(max(self.L.zkgpu_tape_len(self.h), 1), dtype=np.uint32)
+        self._ck(self.L.zkgpu_schedule_dump(self.h, ops.ctypes.data, launches.ctypes.data, consts.ctypes.data,
+                                            slot_of.ctypes.data))
+        return ops, launches, consts[:info['const_words']], slot_of[:self.L.zkgpu_tape_len(self.h)]
+
+    def set_inputs(self, instances, witnesses, batch):
+        """instances / witnesses: bytes-like of [batch][n][elem_bytes] (or None when n == 0)."""
+        self._keep = (bytes(instances) if instances is not None else None,
+                      bytes(witnesses) if witnesses is not None else None)
+        self._ck(self.L.zkgpu_set_inputs(self.h, self._keep[0], self._keep[1], batch))
+
+    def set_inputs_device(self, d_instances, d_witnesses, batch):
+        self._ck(self.L.zkgpu_set_inputs_device(self.h, d_instances, d_witnesses, batch))
+
+    def set_inputs_from_messages(self):
+        self._ck(self.L.zkgpu_set_inputs_from_messages(self.h))
+
+    def set_lane_group(self, lanes):
+        self._ck(self.L.zkgpu_set_lane_group(self.h, lanes))
+
+    def replay(self):
+        self._ck(self.L.zkgpu_replay(self.h))
+
+    def replay_timed(self):
+        import numpy as np
+        self._ck(self.L.zkgpu_replay_timed(self.h))
+        n = self.L.zkgpu_launch_timings(self.h, None, None, 0)
+        ms = np.zeros(n, dtype=np.float32)
+        ops = np.zeros(n, dtype=np.uint32)
+        self.L.zkgpu_launch_timings(self.h, ms.ctypes.data, ops.ctypes.data, n)
+        return ms, ops
+
+    def synchronize(self):
+        self._ck(self.L.zkgpu_synchronize(self.h))
+
+    @property
+    def last_replay_ms(self):
+        return float(self.L.zkgpu_last_replay_ms(self.h))
+
+    def counts(self):
+        out = (ctypes.c_uint64 * 2)()
+        self._ck(self.L.zkgpu_counts(self.h, out))
+        return int(out[0]), int(out[1])
+
+    def counts_device_ptr(self):
+        return self.L.zkgpu_counts_device(self.h)
+
+    def stream_ptr(self):
+        return self.L.zkgpu_stream(self.h)
+
+    def lane_results(self, batch):
+        import numpy as np
+        ff = np.zeros(batch, dtype=np.uint32)
+        fl = np.zeros(batch, dtype=np.uint32)
+        self._ck(self.L.zkgpu_lane_results(self.h, ff.ctypes.data, fl.ctypes.data))
+        return ff, fl
+
+    def get_violations(self, lane=0):
+        """`Evaluator::get_violations()` (evaluator.rs:199-208) for one lane."""
+        n = self.L.zkgpu_lane_violations(self.h, lane, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        self.L.zkgpu_lane_violations(self.h, lane, buf, n + 1)
+        s = buf.value.decode()
+        return s.split('\n') if s else []
+
+    def dump_trace_values(self, batch, first=0, count=None):
+        """[batch][count] python ints: value of every value-returning backend call (retain_all only)."""
+        if count is None:
+            count = self.n_value_ops - first
+        w = self.elem_bytes
+        buf = ctypes.create_string_buffer(max(batch * count * w, 1))
+        self._ck(self.L.zkgpu_dump_trace_values(self.h, first, count, buf))
+        raw = buf.raw
+        return [[int.from_bytes(raw[(l * count + k) * w:(l * count + k + 1) * w], 'little') for k in range(count)]
+                for l in range(batch)]
+
+    def get(self, wire_id, batch):
+        """`Evaluator::get` (evaluator.rs:750-752): value of a live top-level wire, per lane."""
+        w = self.elem_bytes
+        buf = ctypes.create_string_buffer(max(batch * w, 1))
+        rc = self.L.zkgpu_get_wire(self.h, wire_id, buf)
+        if rc == 3:
+            return None
+        self._ck(rc)
+        return [int.from_bytes(buf.raw[l * w:(l + 1) * w], 'little') for l in range(batch)]
+
+    @property
+    def table_bytes(self):
+        return self.L.zkgpu_table_bytes(self.h)
+
+
+def evaluate(paths_or_buffers):
+    """`zki_sieve evaluate` (cli.rs:315-320) for one statement: returns the violation list
+    (empty list = "The statement is TRUE!")."""
+    ev = Evaluator()
+    if paths_or_buffers and isinstance(paths_or_buffers[0], str):
+        ev.ingest_paths(list(paths_or_buffers))
+    else:
+        for b in paths_or_buffers:
+            ev.ingest_message(b)
+    try:
+        ev.finalize()
+    except ZkGpuError:
+        # no Relation reached the backend: only the recording-time violations exist
+        return ev.host_violations()
+    ev.set_inputs_from_messages()
+    ev.replay()
+    ev.synchronize()
+    return ev.get_violations(0)

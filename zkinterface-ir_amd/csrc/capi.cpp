@@ -1,0 +1,444 @@
+// extern "C" surface declared in include/zkgpu.h.
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/zkgpu.h"
+#include "engine.hpp"
+#include "evaluator.hpp"
+#include "schedule.hpp"
+#include "tape.hpp"
+
+using namespace zki;
+
+struct zkgpu_session {
+  TapeBackend backend;
+  Evaluator<TapeBackend> ev;
+  std::unique_ptr<Engine> engine;
+  Schedule sched;
+  bool finalized = false;
+  bool retain_all = false;
+  uint32_t declared_inst = 0, declared_wit = 0;
+  uint32_t lane_group = 0;
+  std::string last_error;
+  std::vector<uint32_t> first_fail, flags;
+  std::vector<uint32_t> value_op_index;  // k-th value-returning call -> tape index
+  bool results_fresh = false;
+};
+
+namespace {
+
+template <class F>
+int guarded(zkgpu_session* s, F&& f) {
+  if (!s) return -1;
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    s->last_error = e.what();
+    return 1;
+  } catch (...) {
+    s->last_error = "unknown error";
+    return 2;
+  }
+}
+
+uint32_t lane_inputs(const zkgpu_session* s, bool instance) {
+  const Tape& t = s->backend.tape();
+  return instance ? std::max<uint32_t>(t.n_instance, std::max<uint32_t>(s->declared_inst, (uint32_t)s->backend.lane0_instances().size()))
+                  : std::max<uint32_t>(t.n_witness, std::max<uint32_t>(s->declared_wit, (uint32_t)s->backend.lane0_witnesses().size()));
+}
+
+// The engine (and with it the HIP runtime / a GPU) is only touched by the
+// replay entry points; recording and scheduling are host work.
+void need_engine(zkgpu_session* s) {
+  if (!s->finalized) throw std::runtime_error("zkgpu_finalize() has not been called");
+  if (!s->engine) {
+    std::unique_ptr<Engine> e(new Engine());
+    e->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
+    e->set_lane_group(s->lane_group);
+    s->engine = std::move(e);
+  }
+}
+
+void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
+  for (const auto& m : split_messages(data, len)) {
+    if (s->ev.has_error()) return;
+    // peek the message type: Instance / Witness messages become lane 0's streams
+    Message msg;
+    try {
+      msg = read_message(data + m.first, m.second);
+    } catch (const std::exception& e) {
+      // Evaluator::from_messages unwraps (evaluator.rs:193): route through the latch
+      s->ev.ingest_buffer(data + m.first, m.second, s->backend);
+      continue;
+    }
+    if (msg.kind == Message::IsInstance) {
+      s->ev.set_modulus(msg.instance.header.field_characteristic);
+      for (const Value& v : msg.instance.common_inputs) s->ev.push_instance(s->backend.import_instance(v));
+    } else if (msg.kind == Message::IsWitness) {
+      s->ev.set_modulus(msg.witness.header.field_characteristic);
+      for (const Value& v : msg.witness.short_witness) s->ev.push_witness(s->backend.import_witness(v));
+    } else {
+      s->ev.ingest_message(msg, s->backend);
+    }
+  }
+}
+
+std::string join_lines(const std::vector<std::string>& v) {
+  std::string out;
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (i) out.push_back('\n');
+    out += v[i];
+  }
+  return out;
+}
+
+size_t copy_out(const std::string& s, char* buf, size_t cap) {
+  if (buf && cap) {
+    const size_t n = std::min(cap - 1, s.size());
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return s.size();
+}
+
+void fetch_results(zkgpu_session* s) {
+  need_engine(s);
+  if (s->results_fresh) return;
+  uint64_t counts[2];
+  s->engine->download(&s->first_fail, &s->flags, counts);
+  s->results_fresh = true;
+}
+
+// pad / check one little-endian Value into a fixed-width slot; values that do
+// not fit are necessarily >= p: written as all-ones so the device flags them.
+void put_value(const Value& v, uint8_t* dst, uint32_t width) {
+  size_t n = v.size();
+  while (n > 0 && v[n - 1] == 0) --n;
+  if (n > width) {
+    memset(dst, 0xff, width);
+    return;
+  }
+  memset(dst, 0, width);
+  memcpy(dst, v.data(), n);
+}
+
+}  // namespace
+
+extern "C" {
+
+zkgpu_session* zkgpu_session_new(void) { return new (std::nothrow) zkgpu_session(); }
+void zkgpu_session_free(zkgpu_session* s) { delete s; }
+const char* zkgpu_last_error(const zkgpu_session* s) { return s ? s->last_error.c_str() : "null session"; }
+const char* zkgpu_version(void) { return "zkgpu 0.1 (gfx950)"; }
+
+// ---- ZKBackend trait -------------------------------------------------------
+int zkgpu_backend_set_field(zkgpu_session* s, const uint8_t* modulus_le, size_t len, uint32_t degree, int is_boolean) {
+  return guarded(s, [&] { s->backend.set_field(Value(modulus_le, modulus_le + len), degree, is_boolean != 0); });
+}
+int zkgpu_backend_copy(zkgpu_session* s, uint32_t wire, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.copy(wire); });
+}
+int zkgpu_backend_constant(zkgpu_session* s, const uint8_t* v, size_t len, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.constant(TapeBackend::from_bytes_le(Value(v, v + len))); });
+}
+int zkgpu_backend_assert_zero(zkgpu_session* s, uint32_t wire, uint64_t local_wire_id) {
+  return guarded(s, [&] {
+    s->backend.note_assert_wire(local_wire_id);
+    s->backend.assert_zero(wire);
+  });
+}
+int zkgpu_backend_add(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.add(a, b); });
+}
+int zkgpu_backend_multiply(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.multiply(a, b); });
+}
+int zkgpu_backend_add_constant(zkgpu_session* s, uint32_t a, const uint8_t* c, size_t len, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.add_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
+}
+int zkgpu_backend_mul_constant(zkgpu_session* s, uint32_t a, const uint8_t* c, size_t len, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.mul_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
+}
+int zkgpu_backend_and(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.and_(a, b); });
+}
+int zkgpu_backend_xor(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.xor_(a, b); });
+}
+int zkgpu_backend_not(zkgpu_session* s, uint32_t a, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.not_(a); });
+}
+int zkgpu_backend_instance(zkgpu_session* s, uint32_t position, uint32_t* out) {
+  return guarded(s, [&] { *out = s->backend.instance(TapeBackend::instance_ref(position)); });
+}
+int zkgpu_backend_witness(zkgpu_session* s, uint32_t position, uint32_t* out) {
+  return guarded(s, [&] {
+    TapeElement e = TapeBackend::witness_ref(position);
+    *out = s->backend.witness(&e);
+  });
+}
+
+// ---- Evaluator / Source -----------------------------------------------------
+int zkgpu_ingest_messages(zkgpu_session* s, const uint8_t* data, size_t len) {
+  return guarded(s, [&] {
+    if (s->finalized) throw std::runtime_error("session already finalized");
+    ingest_stream(s, data, len);
+  });
+}
+
+int zkgpu_ingest_paths(zkgpu_session* s, const char* const* paths, size_t n_paths) {
+  return guarded(s, [&] {
+    if (s->finalized) throw std::runtime_error("session already finalized");
+    std::vector<std::string> v(paths, paths + n_paths);
+    Source src = Source::from_dirs_and_files(v);
+    src.print_filenames = false;
+    src.for_each_buffer([&](const uint8_t* p, size_t n) { ingest_stream(s, p, n); });
+  });
+}
+
+int zkgpu_declare_inputs(zkgpu_session* s, uint32_t n_instance, uint32_t n_witness) {
+  return guarded(s, [&] {
+    if (s->finalized) throw std::runtime_error("session already finalized");
+    for (uint32_t k = 0; k < n_instance; ++k) s->ev.push_instance(TapeBackend::instance_ref(s->declared_inst + k));
+    for (uint32_t k = 0; k < n_witness; ++k) s->ev.push_witness(TapeBackend::witness_ref(s->declared_wit + k));
+    s->declared_inst += n_instance;
+    s->declared_wit += n_witness;
+  });
+}
+
+size_t zkgpu_host_violations(zkgpu_session* s, char* buf, size_t cap) {
+  if (!s) return 0;
+  return copy_out(join_lines(s->ev.get_violations()), buf, cap);
+}
+
+uint64_t zkgpu_tape_len(const zkgpu_session* s) { return s ? s->backend.tape().size() : 0; }
+uint64_t zkgpu_tape_value_ops(const zkgpu_session* s) { return s ? s->backend.tape().n_value_ops : 0; }
+uint64_t zkgpu_tape_asserts(const zkgpu_session* s) { return s ? s->backend.tape().assert_op.size() : 0; }
+int zkgpu_tape_dump(const zkgpu_session* s, uint8_t* kinds, uint32_t* a, uint32_t* b, uint64_t cap) {
+  if (!s) return -1;
+  const Tape& t = s->backend.tape();
+  if (cap < t.size()) return 1;
+  if (t.size()) {
+    memcpy(kinds, t.kind.data(), t.size());
+    memcpy(a, t.a.data(), t.size() * 4);
+    memcpy(b, t.b.data(), t.size() * 4);
+  }
+  return 0;
+}
+uint32_t zkgpu_n_constants(const zkgpu_session* s) { return s ? (uint32_t)s->backend.tape().consts.size() : 0; }
+size_t zkgpu_constant_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap) {
+  if (!s || index >= s->backend.tape().consts.size()) return 0;
+  const Value& v = s->backend.tape().consts[index];
+  if (out && cap >= v.size() && !v.empty()) memcpy(out, v.data(), v.size());
+  return v.size();
+}
+
+// ---- batch replay -------------------------------------------------------------
+int zkgpu_finalize(zkgpu_session* s, int retain_all) {
+  return guarded(s, [&] {
+    if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
+    ScheduleOptions opt;
+    opt.retain_all = retain_all != 0;
+    s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
+    s->sched = build_schedule(s->backend.tape(), s->backend.field(), opt);
+    s->retain_all = opt.retain_all;
+    const Tape& t = s->backend.tape();
+    s->value_op_index.clear();
+    for (size_t i = 0; i < t.size(); ++i)
+      if (t.kind[i] != TK_ASSERT) s->value_op_index.push_back((uint32_t)i);
+    s->engine.reset();
+    s->finalized = true;
+    s->results_fresh = false;
+  });
+}
+
+uint32_t zkgpu_elem_bytes(const zkgpu_session* s) {
+  if (!s || !s->backend.field_set()) return 0;
+  return s->backend.field().is_two ? 1 : 4 * s->backend.field().nwords;
+}
+uint32_t zkgpu_n_instance(const zkgpu_session* s) { return s ? lane_inputs(s, true) : 0; }
+uint32_t zkgpu_n_witness(const zkgpu_session* s) { return s ? lane_inputs(s, false) : 0; }
+
+int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]) {
+  if (!s || !s->finalized) return 1;
+  memset(out, 0, 8 * sizeof(uint64_t));
+  out[0] = s->sched.n_levels;
+  out[1] = s->sched.launches.size();
+  out[2] = s->sched.n_slots;
+  out[3] = s->sched.max_level_width;
+  for (const Launch& l : s->sched.launches) out[4] += l.sequential ? 1 : 0;
+  out[5] = s->sched.ops.size();
+  out[6] = s->sched.const_words.size();
+  out[7] = s->sched.words_per_const;
+  return 0;
+}
+
+int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
+                        uint32_t* slot_of) {
+  if (!s || !s->finalized) return 1;
+  const Schedule& sc = s->sched;
+  if (ops4 && !sc.ops.empty()) memcpy(ops4, sc.ops.data(), sc.ops.size() * sizeof(DevOp));
+  if (launches4)
+    for (size_t i = 0; i < sc.launches.size(); ++i) {
+      launches4[4 * i + 0] = sc.launches[i].first;
+      launches4[4 * i + 1] = sc.launches[i].count;
+      launches4[4 * i + 2] = sc.launches[i].ops_per_wave;
+      launches4[4 * i + 3] = sc.launches[i].sequential ? 1 : 0;
+    }
+  if (const_words && !sc.const_words.empty()) memcpy(const_words, sc.const_words.data(), sc.const_words.size() * 4);
+  if (slot_of && !sc.slot_of.empty()) memcpy(slot_of, sc.slot_of.data(), sc.slot_of.size() * 4);
+  return 0;
+}
+
+int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* witnesses, uint32_t batch) {
+  return guarded(s, [&] {
+    need_engine(s);
+    s->engine->set_batch(batch);
+    s->engine->upload_inputs(instances, witnesses);
+    s->results_fresh = false;
+  });
+}
+
+int zkgpu_set_inputs_device(zkgpu_session* s, const void* d_instances, const void* d_witnesses, uint32_t batch) {
+  return guarded(s, [&] {
+    need_engine(s);
+    s->engine->set_batch(batch);
+    s->engine->use_device_inputs(d_instances, d_witnesses);
+    s->results_fresh = false;
+  });
+}
+
+int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
+  return guarded(s, [&] {
+    need_engine(s);
+    const uint32_t w = s->engine->elem_bytes();
+    const uint32_t ni = zkgpu_n_instance(s), nw = zkgpu_n_witness(s);
+    std::vector<uint8_t> inst((size_t)ni * w, 0), wit((size_t)nw * w, 0);
+    const auto& li = s->backend.lane0_instances();
+    const auto& lw = s->backend.lane0_witnesses();
+    if (s->backend.tape().n_instance > li.size() || s->backend.tape().n_witness > lw.size())
+      throw std::runtime_error("the tape consumes more instance/witness values than the ingested messages hold");
+    for (size_t k = 0; k < li.size(); ++k) put_value(li[k], &inst[k * w], w);
+    for (size_t k = 0; k < lw.size(); ++k) put_value(lw[k], &wit[k * w], w);
+    s->engine->set_batch(1);
+    s->engine->upload_inputs(inst.data(), wit.data());
+    s->results_fresh = false;
+  });
+}
+
+int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes) {
+  return guarded(s, [&] {
+    s->lane_group = lanes;
+    if (s->engine) s->engine->set_lane_group(lanes);
+  });
+}
+
+int zkgpu_replay(zkgpu_session* s) {
+  return guarded(s, [&] {
+    need_engine(s);
+    s->results_fresh = false;
+    s->engine->replay(false);
+  });
+}
+int zkgpu_replay_timed(zkgpu_session* s) {
+  return guarded(s, [&] {
+    need_engine(s);
+    s->results_fresh = false;
+    s->engine->replay(true);
+    s->engine->synchronize();
+  });
+}
+int zkgpu_synchronize(zkgpu_session* s) {
+  return guarded(s, [&] {
+    need_engine(s);
+    s->engine->synchronize();
+  });
+}
+float zkgpu_last_replay_ms(const zkgpu_session* s) { return (s && s->engine) ? s->engine->last_replay_ms() : 0.f; }
+
+size_t zkgpu_launch_timings(const zkgpu_session* s, float* ms, uint32_t* ops, size_t cap) {
+  if (!s || !s->engine) return 0;
+  const auto& t = s->engine->launch_timings();
+  for (size_t i = 0; i < t.size() && i < cap; ++i) {
+    if (ms) ms[i] = t[i].ms;
+    if (ops) ops[i] = t[i].count;
+  }
+  return t.size();
+}
+
+int zkgpu_counts(zkgpu_session* s, uint64_t out[2]) {
+  return guarded(s, [&] {
+    need_engine(s);
+    s->engine->download(nullptr, nullptr, out);
+  });
+}
+void* zkgpu_counts_device(zkgpu_session* s) { return (s && s->engine) ? s->engine->counts_device() : nullptr; }
+void* zkgpu_stream(zkgpu_session* s) { return (s && s->engine) ? s->engine->stream() : nullptr; }
+
+int zkgpu_lane_results(zkgpu_session* s, uint32_t* first_fail, uint32_t* flags) {
+  return guarded(s, [&] {
+    fetch_results(s);
+    if (first_fail) memcpy(first_fail, s->first_fail.data(), s->first_fail.size() * 4);
+    if (flags) memcpy(flags, s->flags.data(), s->flags.size() * 4);
+  });
+}
+
+size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t cap) {
+  if (!s) return 0;
+  std::vector<std::string> v;
+  try {
+    fetch_results(s);
+    if (lane >= s->first_fail.size()) throw std::runtime_error("lane out of range");
+    // evaluator.rs:199-208 for this lane: the first error in execution order wins
+    for (const std::string& m : s->ev.get_violations())
+      if (!s->ev.has_error() || m != s->ev.error()) v.push_back(m);  // "Did not receive any gate to verify."
+    const uint32_t ff = s->first_fail[lane];
+    if (s->flags[lane] & ZKGPU_LANE_NONCANONICAL) {
+      v.push_back("GPU backend: an instance or witness value is not canonical (>= field characteristic); "
+                  "the reference keeps such values unreduced and this path does not support them");
+    } else if (ff != ZKGPU_NO_FAIL) {
+      v.push_back("Wire_" + std::to_string(s->backend.tape().assert_wire[ff]) +
+                  " (may be weighted) should be 0, while it is not");
+    } else if (s->ev.has_error()) {
+      v.push_back(s->ev.error());
+    }
+  } catch (const std::exception& e) {
+    s->last_error = e.what();
+    return 0;
+  }
+  return copy_out(join_lines(v), buf, cap);
+}
+
+int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, uint8_t* out) {
+  return guarded(s, [&] {
+    need_engine(s);
+    if (!s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) is required for trace dumps");
+    if (first + count > s->value_op_index.size()) throw std::runtime_error("trace range out of bounds");
+    std::vector<uint32_t> slots(count);
+    for (uint64_t k = 0; k < count; ++k) slots[k] = s->sched.slot_of[s->value_op_index[first + k]];
+    std::vector<uint8_t> tmp;
+    s->engine->dump_slots(slots, &tmp);
+    if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+  });
+}
+
+int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out) {
+  if (!s) return -1;
+  const uint32_t* h = s->ev.get(wire_id);
+  if (!h) return 3;  // "No value given for wire_{id}"
+  return guarded(s, [&] {
+    need_engine(s);
+    std::vector<uint32_t> slots(1, s->sched.slot_of[*h]);
+    std::vector<uint8_t> tmp;
+    s->engine->dump_slots(slots, &tmp);
+    if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+  });
+}
+
+uint64_t zkgpu_table_bytes(const zkgpu_session* s) { return (s && s->engine) ? s->engine->table_bytes() : 0; }
+
+}  // extern "C"

@@ -46,7 +46,8 @@ struct ReplayArgs {
   u32 ops_per_wave;       // contiguous ops walked by one wave
   uint4* table;           // wire table
   u32 n_slots;            // slots per lane block
-  u32 batch;              // real lanes (<= 64 * gridDim.y)
+  u32 batch;              // real lanes
+  u32 lb_base;            // first lane block of this launch (lane groups)
   const u32* consts;      // constant pool, Montgomery form, N words each
   const uint8_t* inst;    // [lane][n_inst][4N bytes] little-endian, canonical
   const uint8_t* wit;     // [lane][n_wit][4N bytes]
@@ -120,7 +121,7 @@ template <int N, bool PIPE>
 __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, const FieldParams fp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
-  const u32 lb = blockIdx.y;
+  const u32 lb = args.lb_base + blockIdx.y;
   const u32 gw = blockIdx.x * (blockDim.x >> 6) + wave;
   const u32 begin = gw * args.ops_per_wave;
   if (begin >= args.n_ops) return;

@@ -1,0 +1,319 @@
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <algorithm>
+#include <stdexcept>
+#include <string>
+
+#include "device/bool_kernels.hpp"
+#include "device/replay_kernels.hpp"
+#include "engine.hpp"
+
+namespace zki {
+namespace {
+
+void check(hipError_t e, const char* what) {
+  if (e != hipSuccess)
+    throw std::runtime_error(std::string("HIP: ") + what + ": " + hipGetErrorString(e) +
+                             " (no CPU fallback exists for the replay path)");
+}
+#define HIP_OK(x) check((x), #x)
+
+static_assert(sizeof(DevOp) == sizeof(zkgpu::TapeOp), "DevOp must match the device TapeOp");
+static_assert(sizeof(zkgpu::FieldParams) <= 128, "FieldParams must fit Engine::field_params_");
+
+template <typename T>
+void dfree(T*& p) {
+  if (p) {
+    (void)hipFree((void*)p);
+    p = nullptr;
+  }
+}
+
+template <int N>
+void launch_arith(const zkgpu::ReplayArgs& a, const zkgpu::FieldParams& fp, bool sequential, dim3 grid,
+                  hipStream_t st) {
+  if (sequential || a.ops_per_wave == 1)
+    zkgpu::replay_kernel<N, false><<<grid, 256, 0, st>>>(a, fp);
+  else
+    zkgpu::replay_kernel<N, true><<<grid, 256, 0, st>>>(a, fp);
+}
+
+}  // namespace
+
+Engine::Engine() {
+  int n = 0;
+  HIP_OK(hipGetDeviceCount(&n));
+  if (n <= 0) throw std::runtime_error("HIP: no GPU visible (no CPU fallback exists for the replay path)");
+  hipStream_t st;
+  HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  stream_ = st;
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  ev_begin_ = e0;
+  ev_end_ = e1;
+  HIP_OK(hipMalloc(&d_counts_, 16));
+  HIP_OK(hipMemset(d_counts_, 0, 16));
+}
+
+Engine::~Engine() {
+  free_batch();
+  dfree(d_ops_);
+  dfree(d_consts_);
+  dfree(d_counts_);
+  for (void* e : launch_events_) (void)hipEventDestroy((hipEvent_t)e);
+  if (ev_begin_) (void)hipEventDestroy((hipEvent_t)ev_begin_);
+  if (ev_end_) (void)hipEventDestroy((hipEvent_t)ev_end_);
+  if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
+}
+
+void Engine::free_batch() {
+  dfree(d_table_);
+  dfree(d_first_fail_);
+  dfree(d_flags_);
+  dfree(d_inst_own_);
+  dfree(d_wit_own_);
+  dfree(d_packed_inst_);
+  dfree(d_packed_wit_);
+  d_inst_ = d_wit_ = nullptr;
+  batch_ = 0;
+}
+
+void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness) {
+  free_batch();
+  dfree(d_ops_);
+  dfree(d_consts_);
+  sched_ = s;
+  boolean_ = s.boolean_path;
+  nwords_ = f.nwords;
+  elem_bytes_ = boolean_ ? 1 : 4 * f.nwords;
+  lanes_per_block_ = boolean_ ? 4096 : 64;
+  n_inst_ = n_instance;
+  n_wit_ = n_witness;
+  zkgpu::FieldParams fp;
+  memset(&fp, 0, sizeof fp);
+  memcpy(fp.p, f.p, sizeof fp.p);
+  memcpy(fp.r2, f.r2, sizeof fp.r2);
+  memcpy(fp.one, f.one, sizeof fp.one);
+  fp.n0inv = f.n0inv;
+  fp.nwords = f.nwords;
+  memset(field_params_, 0, sizeof field_params_);
+  memcpy(field_params_, &fp, sizeof fp);
+  if (!s.ops.empty()) {
+    HIP_OK(hipMalloc(&d_ops_, s.ops.size() * sizeof(DevOp)));
+    HIP_OK(hipMemcpy(d_ops_, s.ops.data(), s.ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
+  }
+  const size_t cbytes = std::max<size_t>(s.const_words.size() * 4, 64);
+  HIP_OK(hipMalloc(&d_consts_, cbytes));
+  HIP_OK(hipMemset(d_consts_, 0, cbytes));
+  if (!s.const_words.empty())
+    HIP_OK(hipMemcpy(d_consts_, s.const_words.data(), s.const_words.size() * 4, hipMemcpyHostToDevice));
+  loaded_ = true;
+}
+
+void Engine::set_batch(uint32_t batch) {
+  if (!loaded_) throw std::runtime_error("Engine: load_program() first");
+  if (batch == 0) throw std::runtime_error("Engine: empty batch");
+  if (batch == batch_) return;
+  free_batch();
+  batch_ = batch;
+  lane_blocks_ = (batch + lanes_per_block_ - 1) / lanes_per_block_;
+  const uint64_t rec_bytes = boolean_ ? 64 * 8 : (uint64_t)((nwords_ + 3) / 4) * 64 * 16;
+  table_bytes_ = (uint64_t)lane_blocks_ * sched_.n_slots * rec_bytes;
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  if (table_bytes_ > (uint64_t)(0.92 * (double)free_b))
+    throw std::runtime_error("Engine: wire table of " + std::to_string(table_bytes_ >> 20) +
+                             " MiB does not fit in free HBM (" + std::to_string(free_b >> 20) + " MiB)");
+  HIP_OK(hipMalloc(&d_table_, std::max<uint64_t>(table_bytes_, 64)));
+  const size_t padded_lanes = (size_t)lane_blocks_ * lanes_per_block_;
+  HIP_OK(hipMalloc(&d_first_fail_, padded_lanes * 4));
+  HIP_OK(hipMalloc(&d_flags_, padded_lanes * 4));
+  if (boolean_) {
+    const size_t words = (size_t)lane_blocks_ * 64;
+    HIP_OK(hipMalloc(&d_packed_inst_, std::max<size_t>((size_t)n_inst_ * words * 8, 64)));
+    HIP_OK(hipMalloc(&d_packed_wit_, std::max<size_t>((size_t)n_wit_ * words * 8, 64)));
+  }
+}
+
+void Engine::upload_inputs(const uint8_t* inst, const uint8_t* wit) {
+  if (!batch_) throw std::runtime_error("Engine: set_batch() first");
+  const size_t ib = (size_t)batch_ * n_inst_ * elem_bytes_, wb = (size_t)batch_ * n_wit_ * elem_bytes_;
+  if (ib && !inst) throw std::runtime_error("Engine: instance values missing");
+  if (wb && !wit) throw std::runtime_error("Engine: witness values missing");
+  if (!d_inst_own_) HIP_OK(hipMalloc(&d_inst_own_, std::max<size_t>(ib, 64)));
+  if (!d_wit_own_) HIP_OK(hipMalloc(&d_wit_own_, std::max<size_t>(wb, 64)));
+  if (ib) HIP_OK(hipMemcpy(d_inst_own_, inst, ib, hipMemcpyHostToDevice));
+  if (wb) HIP_OK(hipMemcpy(d_wit_own_, wit, wb, hipMemcpyHostToDevice));
+  d_inst_ = d_inst_own_;
+  d_wit_ = d_wit_own_;
+}
+
+void Engine::use_device_inputs(const void* d_inst, const void* d_wit) {
+  if (!batch_) throw std::runtime_error("Engine: set_batch() first");
+  d_inst_ = d_inst;
+  d_wit_ = d_wit;
+}
+
+void Engine::launch_range(uint32_t lb0, uint32_t lbs, bool time_each) {
+  hipStream_t st = (hipStream_t)stream_;
+  const DevOp* ops = (const DevOp*)d_ops_;
+  zkgpu::FieldParams fp;
+  memcpy(&fp, field_params_, sizeof fp);
+  size_t ev = 0;
+  for (size_t li = 0; li < sched_.launches.size(); ++li) {
+    const Launch& L = sched_.launches[li];
+    const uint32_t waves = (L.count + L.ops_per_wave - 1) / L.ops_per_wave;
+    const dim3 grid((waves + 3) / 4, lbs);
+    if (time_each) HIP_OK(hipEventRecord((hipEvent_t)launch_events_[2 * li], st));
+    if (boolean_) {
+      zkgpu::BoolReplayArgs a;
+      memset(&a, 0, sizeof a);
+      a.ops = (const zkgpu::TapeOp*)(ops + L.first);
+      a.n_ops = L.count;
+      a.ops_per_wave = L.ops_per_wave;
+      a.table = (zkgpu::u64*)d_table_;
+      a.n_slots = sched_.n_slots;
+      a.batch = batch_;
+      a.lb_base = lb0;
+      a.total_words = lane_blocks_ * 64;
+      a.consts = (const zkgpu::u32*)d_consts_;
+      a.packed_inst = (const zkgpu::u64*)d_packed_inst_;
+      a.packed_wit = (const zkgpu::u64*)d_packed_wit_;
+      a.first_fail = (zkgpu::u32*)d_first_fail_;
+      zkgpu::bool_replay_kernel<<<grid, 256, 0, st>>>(a);
+    } else {
+      zkgpu::ReplayArgs a;
+      memset(&a, 0, sizeof a);
+      a.ops = (const zkgpu::TapeOp*)(ops + L.first);
+      a.n_ops = L.count;
+      a.ops_per_wave = L.ops_per_wave;
+      a.table = (uint4*)d_table_;
+      a.n_slots = sched_.n_slots;
+      a.batch = batch_;
+      a.lb_base = lb0;
+      a.consts = (const zkgpu::u32*)d_consts_;
+      a.inst = (const uint8_t*)d_inst_;
+      a.wit = (const uint8_t*)d_wit_;
+      a.n_inst = n_inst_;
+      a.n_wit = n_wit_;
+      a.first_fail = (zkgpu::u32*)d_first_fail_;
+      a.lane_flags = (zkgpu::u32*)d_flags_;
+      switch (nwords_) {
+        case 2: launch_arith<2>(a, fp, L.sequential, grid, st); break;
+        case 4: launch_arith<4>(a, fp, L.sequential, grid, st); break;
+        case 6: launch_arith<6>(a, fp, L.sequential, grid, st); break;
+        case 8: launch_arith<8>(a, fp, L.sequential, grid, st); break;
+        default: throw std::runtime_error("Engine: unsupported limb count");
+      }
+    }
+    if (time_each) HIP_OK(hipEventRecord((hipEvent_t)launch_events_[2 * li + 1], st));
+    (void)ev;
+  }
+  HIP_OK(hipGetLastError());
+}
+
+void Engine::replay(bool time_each_launch) {
+  if (!batch_) throw std::runtime_error("Engine: set_batch() first");
+  if ((n_inst_ && !d_inst_) || (n_wit_ && !d_wit_)) throw std::runtime_error("Engine: inputs not set");
+  hipStream_t st = (hipStream_t)stream_;
+  const size_t padded_lanes = (size_t)lane_blocks_ * lanes_per_block_;
+  if (time_each_launch) {
+    while (launch_events_.size() < 2 * sched_.launches.size()) {
+      hipEvent_t e;
+      HIP_OK(hipEventCreate(&e));
+      launch_events_.push_back(e);
+    }
+  }
+  HIP_OK(hipEventRecord((hipEvent_t)ev_begin_, st));
+  HIP_OK(hipMemsetAsync(d_first_fail_, 0xFF, padded_lanes * 4, st));
+  HIP_OK(hipMemsetAsync(d_flags_, 0, padded_lanes * 4, st));
+  HIP_OK(hipMemsetAsync(d_counts_, 0, 16, st));
+  if (boolean_) {
+    const uint32_t words = lane_blocks_ * 64;
+    if (n_inst_)
+      zkgpu::pack_inputs_kernel<<<dim3((words + 3) / 4, (n_inst_ + 255) / 256), 256, 0, st>>>(
+          (const uint8_t*)d_inst_, n_inst_, batch_, words, (zkgpu::u64*)d_packed_inst_, (zkgpu::u32*)d_flags_);
+    if (n_wit_)
+      zkgpu::pack_inputs_kernel<<<dim3((words + 3) / 4, (n_wit_ + 255) / 256), 256, 0, st>>>(
+          (const uint8_t*)d_wit_, n_wit_, batch_, words, (zkgpu::u64*)d_packed_wit_, (zkgpu::u32*)d_flags_);
+  }
+  uint32_t group_blocks = lane_blocks_;
+  if (lane_group_) group_blocks = std::max<uint32_t>(1, std::min(lane_blocks_, lane_group_ / lanes_per_block_));
+  if (time_each_launch) group_blocks = lane_blocks_;  // per-launch events describe whole-batch launches
+  for (uint32_t lb0 = 0; lb0 < lane_blocks_; lb0 += group_blocks)
+    launch_range(lb0, std::min(group_blocks, lane_blocks_ - lb0), time_each_launch);
+  zkgpu::verdict_kernel<<<(batch_ + 255) / 256, 256, 0, st>>>((const zkgpu::u32*)d_first_fail_,
+                                                              (const zkgpu::u32*)d_flags_, batch_,
+                                                              (unsigned long long*)d_counts_);
+  HIP_OK(hipEventRecord((hipEvent_t)ev_end_, st));
+  HIP_OK(hipGetLastError());
+  timings_.clear();
+  if (time_each_launch) {
+    HIP_OK(hipStreamSynchronize(st));
+    for (size_t li = 0; li < sched_.launches.size(); ++li) {
+      LaunchTiming t;
+      t.launch = (uint32_t)li;
+      t.count = sched_.launches[li].count;
+      HIP_OK(hipEventElapsedTime(&t.ms, (hipEvent_t)launch_events_[2 * li], (hipEvent_t)launch_events_[2 * li + 1]));
+      timings_.push_back(t);
+    }
+  }
+}
+
+void Engine::synchronize() {
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream_));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)ev_begin_, (hipEvent_t)ev_end_) == hipSuccess) last_ms_ = ms;
+}
+
+void Engine::download(std::vector<uint32_t>* first_fail, std::vector<uint32_t>* flags, uint64_t counts[2]) {
+  synchronize();
+  if (first_fail) {
+    first_fail->resize(batch_);
+    HIP_OK(hipMemcpy(first_fail->data(), d_first_fail_, (size_t)batch_ * 4, hipMemcpyDeviceToHost));
+  }
+  if (flags) {
+    flags->resize(batch_);
+    HIP_OK(hipMemcpy(flags->data(), d_flags_, (size_t)batch_ * 4, hipMemcpyDeviceToHost));
+  }
+  if (counts) HIP_OK(hipMemcpy(counts, d_counts_, 16, hipMemcpyDeviceToHost));
+}
+
+void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out) {
+  synchronize();
+  const uint32_t k = (uint32_t)slots.size();
+  out->assign((size_t)batch_ * k * elem_bytes_, 0);
+  if (!k) return;
+  hipStream_t st = (hipStream_t)stream_;
+  uint32_t* d_slots = nullptr;
+  void* d_out = nullptr;
+  HIP_OK(hipMalloc(&d_slots, (size_t)k * 4));
+  HIP_OK(hipMalloc(&d_out, out->size()));
+  HIP_OK(hipMemcpy(d_slots, slots.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+  zkgpu::FieldParams fp;
+  memcpy(&fp, field_params_, sizeof fp);
+  const uint32_t lb64 = (batch_ + 63) / 64;
+  // grid.x is limited to 2^31-1, grid.y to 65535: chunk the slot list
+  if (boolean_) {
+    zkgpu::bool_dump_slots_kernel<<<dim3(k, lb64), 64, 0, st>>>((const zkgpu::u64*)d_table_, sched_.n_slots, d_slots,
+                                                                k, batch_, (uint8_t*)d_out);
+  } else {
+    const uint4* T = (const uint4*)d_table_;
+    switch (nwords_) {
+      case 2: zkgpu::dump_slots_kernel<2><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 4: zkgpu::dump_slots_kernel<4><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 6: zkgpu::dump_slots_kernel<6><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 8: zkgpu::dump_slots_kernel<8><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      default: break;
+    }
+  }
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(hipMemcpy(out->data(), d_out, out->size(), hipMemcpyDeviceToHost));
+  (void)hipFree(d_slots);
+  (void)hipFree(d_out);
+}
+
+}  // namespace zki

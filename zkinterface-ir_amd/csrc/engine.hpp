@@ -1,0 +1,87 @@
+// Device engine: owns the HBM-resident program (scheduled tape + constant
+// pool), the witness-major wire table and the per-witness verdict words, and
+// replays the program for a batch on one MI355X.  No host fallback: every
+// entry point throws if the HIP runtime or a GPU is missing.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "schedule.hpp"
+
+namespace zki {
+
+struct LaunchTiming {
+  uint32_t launch = 0;  // index into Schedule::launches
+  uint32_t count = 0;   // ops in the launch
+  float ms = 0.f;
+};
+
+class Engine {
+ public:
+  Engine();
+  ~Engine();
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+
+  // Upload the program.  n_instance / n_witness = values per witness stream.
+  void load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness);
+  // Bytes per input value the batch buffers must use: 4*nwords (arithmetic) or 1 (GF(2)).
+  uint32_t elem_bytes() const { return elem_bytes_; }
+
+  // (Re)size the per-batch state.  Inputs are [batch][n][elem_bytes] little-endian.
+  void set_batch(uint32_t batch);
+  void upload_inputs(const uint8_t* inst, const uint8_t* wit);        // host -> HBM
+  void use_device_inputs(const void* d_inst, const void* d_wit);      // already resident
+  // Limit how many lanes are replayed together (0 = all): lane groups run one
+  // after the other so that a group's live wires stay in the 256 MiB Infinity Cache.
+  void set_lane_group(uint32_t lanes) { lane_group_ = lanes; }
+
+  void replay(bool time_each_launch = false);  // asynchronous on the engine's stream
+  void synchronize();
+  float last_replay_ms() const { return last_ms_; }
+  const std::vector<LaunchTiming>& launch_timings() const { return timings_; }
+
+  void download(std::vector<uint32_t>* first_fail, std::vector<uint32_t>* flags, uint64_t counts[2]);
+  void* counts_device() const { return d_counts_; }  // u64[2] {satisfied, failed}
+  void* stream() const { return stream_; }
+  // out[lane][k][elem_bytes]: canonical value of slot slots[k] for every lane
+  void dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out);
+
+  uint64_t table_bytes() const { return table_bytes_; }
+  uint32_t batch() const { return batch_; }
+
+ private:
+  void free_batch();
+  void launch_range(uint32_t lb0, uint32_t lbs, bool time_each);
+
+  Schedule sched_;  // host copy (launch list)
+  bool loaded_ = false;
+  bool boolean_ = false;
+  uint32_t nwords_ = 0, elem_bytes_ = 0;
+  uint32_t n_inst_ = 0, n_wit_ = 0;
+  uint32_t batch_ = 0, lane_blocks_ = 0, lanes_per_block_ = 64, lane_group_ = 0;
+  uint64_t table_bytes_ = 0;
+  float last_ms_ = 0.f;
+  std::vector<LaunchTiming> timings_;
+
+  void* stream_ = nullptr;
+  void* ev_begin_ = nullptr;
+  void* ev_end_ = nullptr;
+  std::vector<void*> launch_events_;
+  void* d_ops_ = nullptr;
+  void* d_consts_ = nullptr;
+  void* d_table_ = nullptr;
+  void* d_first_fail_ = nullptr;
+  void* d_flags_ = nullptr;
+  void* d_counts_ = nullptr;
+  void* d_inst_own_ = nullptr;
+  void* d_wit_own_ = nullptr;
+  const void* d_inst_ = nullptr;
+  const void* d_wit_ = nullptr;
+  void* d_packed_inst_ = nullptr;  // GF(2) path
+  void* d_packed_wit_ = nullptr;
+  unsigned char field_params_[128];  // zkgpu::FieldParams, opaque here
+};
+
+}  // namespace zki

@@ -1,0 +1,193 @@
+#include "schedule.hpp"
+
+#include <string.h>
+
+#include <algorithm>
+
+namespace zki {
+namespace {
+
+inline int n_inputs(uint8_t k) {
+  switch (k) {
+    case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR: return 2;
+    case TK_ADDC: case TK_MULC: case TK_COPY: case TK_NOT: case TK_ASSERT: return 1;
+    default: return 0;  // CONST, INSTANCE, WITNESS, NOP
+  }
+}
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+
+}  // namespace
+
+Schedule build_schedule(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt) {
+  Schedule s;
+  const size_t n = tape.size();
+  s.retain_all = opt.retain_all;
+  s.boolean_path = field.is_two;
+  s.slot_of.assign(n, kNoWire);
+  s.level_of.assign(n, 0);
+  if (n == 0) return s;
+
+  // ---- constant pool in device form -------------------------------------
+  const uint32_t n_consts = (uint32_t)tape.consts.size();
+  std::vector<uint8_t> const_odd(n_consts, 0);
+  uint32_t bool_zero_const = 0;
+  if (s.boolean_path) {
+    s.words_per_const = 1;
+    s.const_words.resize(n_consts + 1);
+    for (uint32_t i = 0; i < n_consts; ++i) {
+      const Value& v = tape.consts[i];
+      const_odd[i] = !v.empty() && (v[0] & 1);  // value mod 2
+      s.const_words[i] = const_odd[i];
+    }
+    bool_zero_const = n_consts;  // synthetic 0 for mul_constant by an even constant
+    s.const_words[n_consts] = 0;
+  } else {
+    s.words_per_const = field.nwords;
+    s.const_words.assign((size_t)n_consts * field.nwords, 0);
+    for (uint32_t i = 0; i < n_consts; ++i) {
+      uint32_t r[8], m[8];
+      field.reduce(tape.consts[i], r);
+      field.to_mont(r, m);
+      memcpy(&s.const_words[(size_t)i * field.nwords], m, 4 * field.nwords);
+    }
+  }
+
+  // ---- dependency levels (ASAP for ops with inputs) ----------------------
+  std::vector<uint32_t>& level = s.level_of;
+  std::vector<uint32_t> first_use(n, kInf), last_use(n, 0);
+  std::vector<uint8_t> used(n, 0);
+  for (size_t i = 0; i < n; ++i) {
+    const int ni = n_inputs(tape.kind[i]);
+    uint32_t lv = 0;
+    if (ni >= 1) lv = level[tape.a[i]] + 1;
+    if (ni == 2) lv = std::max(lv, level[tape.b[i]] + 1);
+    level[i] = lv;
+  }
+  // sources (constant / instance / witness) are produced as late as possible:
+  // one level before their first reader, so they do not occupy a slot early.
+  for (size_t i = 0; i < n; ++i) {
+    const int ni = n_inputs(tape.kind[i]);
+    if (ni >= 1) first_use[tape.a[i]] = std::min(first_use[tape.a[i]], level[i]);
+    if (ni == 2) first_use[tape.b[i]] = std::min(first_use[tape.b[i]], level[i]);
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (n_inputs(tape.kind[i]) == 0 && tape.kind[i] != TK_NOP)
+      level[i] = first_use[i] == kInf ? 0 : first_use[i] - 1;
+  uint32_t n_levels = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int ni = n_inputs(tape.kind[i]);
+    if (ni >= 1) { last_use[tape.a[i]] = std::max(last_use[tape.a[i]], level[i]); used[tape.a[i]] = 1; }
+    if (ni == 2) { last_use[tape.b[i]] = std::max(last_use[tape.b[i]], level[i]); used[tape.b[i]] = 1; }
+    n_levels = std::max(n_levels, level[i] + 1);
+  }
+  for (size_t i = 0; i < n; ++i)
+    if (!used[i]) last_use[i] = level[i];
+  for (uint32_t h : opt.pinned)
+    if (h < n) last_use[h] = kInf;
+  s.n_levels = n_levels;
+
+  // ---- order ops by (level, kind): counting sort ------------------------
+  constexpr uint32_t kKinds = TK_NOT + 1;
+  std::vector<uint64_t> bucket((size_t)n_levels * kKinds + 1, 0);
+  for (size_t i = 0; i < n; ++i) ++bucket[(size_t)level[i] * kKinds + tape.kind[i] + 1];
+  for (size_t k = 1; k < bucket.size(); ++k) bucket[k] += bucket[k - 1];
+  std::vector<uint32_t> order(n);
+  {
+    std::vector<uint64_t> cursor(bucket.begin(), bucket.end() - 1);
+    for (size_t i = 0; i < n; ++i) order[cursor[(size_t)level[i] * kKinds + tape.kind[i]]++] = (uint32_t)i;
+  }
+  std::vector<uint64_t> level_start(n_levels + 1);
+  for (uint32_t l = 0; l <= n_levels; ++l) level_start[l] = bucket[(size_t)l * kKinds];
+
+  // ---- slots: liveness-based reuse, level by level ----------------------
+  std::vector<uint32_t> free_slots;
+  std::vector<uint32_t> expire_head(n_levels + 1, kInf), expire_next(n, kInf);  // intrusive lists per last_use level
+  uint32_t n_slots = 0;
+  for (uint32_t l = 0; l < n_levels; ++l) {
+    if (!opt.retain_all && l > 0) {
+      for (uint32_t h = expire_head[l - 1]; h != kInf; h = expire_next[h]) free_slots.push_back(s.slot_of[h]);
+    }
+    for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
+      const uint32_t i = order[k];
+      if (tape.kind[i] == TK_ASSERT || tape.kind[i] == TK_NOP) continue;
+      uint32_t slot;
+      if (!free_slots.empty()) {
+        slot = free_slots.back();
+        free_slots.pop_back();
+      } else {
+        slot = n_slots++;
+      }
+      s.slot_of[i] = slot;
+      if (last_use[i] != kInf) {
+        expire_next[i] = expire_head[last_use[i]];
+        expire_head[last_use[i]] = i;
+      }
+    }
+  }
+  s.n_slots = std::max<uint32_t>(n_slots, 1);
+
+  // ---- device ops ----------------------------------------------------------
+  s.ops.resize(n);
+  for (size_t k = 0; k < n; ++k) {
+    const uint32_t i = order[k];
+    DevOp d{0, 0, 0, tape.kind[i]};
+    const uint8_t kind = tape.kind[i];
+    d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
+    switch (kind) {
+      case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR:
+        d.a = s.slot_of[tape.a[i]];
+        d.b = s.slot_of[tape.b[i]];
+        break;
+      case TK_ADDC: case TK_MULC:
+        d.a = s.slot_of[tape.a[i]];
+        d.b = tape.b[i];
+        break;
+      case TK_COPY: case TK_NOT: d.a = s.slot_of[tape.a[i]]; break;
+      case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a = tape.a[i]; break;
+      case TK_ASSERT:
+        d.a = s.slot_of[tape.a[i]];
+        d.b = tape.b[i];
+        break;
+      default: break;
+    }
+    if (s.boolean_path) {  // arithmetic mod 2 on {0,1}: (a+b)%2 = xor, (a*b)%2 = and
+      if (kind == TK_ADD) d.kind = TK_XOR;
+      else if (kind == TK_MUL) d.kind = TK_AND;
+      else if (kind == TK_ADDC) d.kind = const_odd[tape.b[i]] ? TK_NOT : TK_COPY;
+      else if (kind == TK_MULC) {
+        if (const_odd[tape.b[i]]) d.kind = TK_COPY;
+        else { d.kind = TK_CONST; d.a = bool_zero_const; }
+      }
+    }
+    s.ops[k] = d;
+  }
+
+  // ---- launches -------------------------------------------------------------
+  uint32_t l = 0;
+  while (l < n_levels) {
+    const uint64_t width = level_start[l + 1] - level_start[l];
+    s.max_level_width = std::max<uint32_t>(s.max_level_width, (uint32_t)width);
+    Launch L;
+    L.first = (uint32_t)level_start[l];
+    L.level_begin = l;
+    if (width >= opt.narrow_width) {
+      L.count = (uint32_t)width;
+      L.ops_per_wave = 1;
+      L.level_end = l + 1;
+      ++l;
+    } else {
+      uint32_t e = l;
+      while (e < n_levels && level_start[e + 1] - level_start[e] < opt.narrow_width) ++e;
+      L.count = (uint32_t)(level_start[e] - level_start[l]);
+      L.ops_per_wave = std::max<uint32_t>(L.count, 1);
+      L.sequential = true;
+      L.level_end = e;
+      l = e;
+    }
+    if (L.count) s.launches.push_back(L);
+  }
+  return s;
+}
+
+}  // namespace zki

@@ -1,0 +1,53 @@
+// Tape -> device program.  The reference executes backend calls one at a time
+// (rust/src/consumers/evaluator.rs:288-301); the calls only depend on each
+// other through wires, so the tape is re-ordered into dependency levels
+// (every op of a level is independent -> one wide kernel launch), operand
+// handles are renamed to wire-table slots with liveness-based reuse (the
+// reference's only liveness signal, `Free`, never reaches a backend:
+// flattening.rs:10-11), and runs of very narrow levels are fused into
+// sequential launches walked by one wavefront per lane block.
+#pragma once
+#include <stdint.h>
+#include <vector>
+
+#include "tape.hpp"
+
+namespace zki {
+
+struct DevOp {  // == zkgpu::TapeOp (device/replay_kernels.hpp)
+  uint32_t dst, a, b, kind;
+};
+
+struct Launch {
+  uint32_t first = 0;         // index into Schedule::ops
+  uint32_t count = 0;
+  uint32_t ops_per_wave = 1;  // count => one wave walks the whole launch in order
+  bool sequential = false;    // ops depend on each other: no operand prefetch
+  uint32_t level_begin = 0, level_end = 0;
+};
+
+struct ScheduleOptions {
+  bool retain_all = false;          // every value keeps its own slot (wire dumps for parity tests)
+  uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
+  std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
+};
+
+struct Schedule {
+  std::vector<DevOp> ops;
+  std::vector<Launch> launches;
+  std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)
+  std::vector<uint32_t> level_of;   // per tape op
+  uint32_t n_slots = 0;
+  uint32_t n_levels = 0;
+  uint32_t max_level_width = 0;
+  bool retain_all = false;
+  bool boolean_path = false;        // p == 2: bit-packed wires
+  // constant pool in device form: arithmetic = Montgomery words (nwords each);
+  // boolean = one u32 (0/1) per constant
+  std::vector<uint32_t> const_words;
+  uint32_t words_per_const = 0;
+};
+
+Schedule build_schedule(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt);
+
+}  // namespace zki

@@ -1,0 +1,230 @@
+#include "tape.hpp"
+
+#include <string.h>
+
+namespace zki {
+
+const char* tape_kind_name(uint8_t k) {
+  static const char* names[] = {"nop", "add", "mul", "addc", "mulc", "copy", "constant",
+                                "instance", "witness", "assert_zero", "and", "xor", "not"};
+  return k <= TK_NOT ? names[k] : "?";
+}
+
+// ---------------------------------------------------------------- FieldHost
+namespace {
+bool geq8(const uint32_t* a, const uint32_t* b) {
+  for (int i = 7; i >= 0; --i)
+    if (a[i] != b[i]) return a[i] > b[i];
+  return true;
+}
+void sub8(uint32_t* a, const uint32_t* b) {
+  uint64_t borrow = 0;
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t d = (uint64_t)a[i] - b[i] - borrow;
+    a[i] = (uint32_t)d;
+    borrow = (d >> 63) & 1;
+  }
+}
+size_t significant_bytes(const Value& v) {
+  size_t n = v.size();
+  while (n > 0 && v[n - 1] == 0) --n;
+  return n;
+}
+}  // namespace
+
+void FieldHost::add(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) const {
+  uint32_t r[8];
+  uint64_t c = 0;
+  for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)a[i] + b[i];
+    r[i] = (uint32_t)c;
+    c >>= 32;
+  }
+  if (c || geq8(r, p)) sub8(r, p);
+  memcpy(out, r, sizeof r);
+}
+
+void FieldHost::init(const Value& modulus_le) {
+  *this = FieldHost();
+  const size_t n = significant_bytes(modulus_le);
+  if (n == 0) throw Error("Modulus cannot be zero.");  // evaluator.rs:868-869
+  if (n > 32) throw Error("GPU backend: field characteristic wider than 256 bits is not supported");
+  for (size_t i = 0; i < n; ++i) p[i / 4] |= (uint32_t)modulus_le[i] << (8 * (i % 4));
+  for (int i = 7; i >= 0 && bits == 0; --i)
+    if (p[i]) bits = 32 * i + (32 - __builtin_clz(p[i]));
+  if (bits == 2 && p[0] == 2) {
+    is_two = true;
+    nwords = 2;
+    return;
+  }
+  if ((p[0] & 1) == 0) throw Error("GPU backend: even field characteristic other than 2 is not supported");
+  if (bits < 2) throw Error("GPU backend: field characteristic 1 is not supported");
+  nwords = 2 * ((bits + 63) / 64);
+  // R = 2^(32*nwords).  one = R mod p by doubling; r2 = R^2 mod p the same way.
+  uint32_t x[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
+  memcpy(one, x, sizeof x);
+  for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
+  memcpy(r2, x, sizeof x);
+  uint32_t inv = 1;  // Newton iteration for p^{-1} mod 2^32
+  for (int i = 0; i < 5; ++i) inv *= 2 - p[0] * inv;
+  n0inv = 0u - inv;
+}
+
+bool FieldHost::is_canonical(const Value& v) const {
+  const size_t n = significant_bytes(v);
+  if (n > 32) return false;
+  uint32_t w[8] = {0};
+  for (size_t i = 0; i < n; ++i) w[i / 4] |= (uint32_t)v[i] << (8 * (i % 4));
+  return !geq8(w, p);
+}
+
+void FieldHost::reduce(const Value& v, uint32_t out[8]) const {
+  uint32_t r[8] = {0};
+  const uint32_t one_[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  const size_t n = significant_bytes(v);
+  for (size_t bit = n * 8; bit-- > 0;) {
+    add(r, r, r);
+    if ((v[bit / 8] >> (bit % 8)) & 1) add(r, one_, r);
+  }
+  memcpy(out, r, sizeof r);
+}
+
+void FieldHost::to_mont(const uint32_t in[8], uint32_t out[8]) const {
+  uint32_t x[8];
+  memcpy(x, in, sizeof x);
+  for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
+  memcpy(out, x, sizeof x);
+}
+
+// -------------------------------------------------------------- TapeBackend
+void TapeBackend::set_field(const Value& modulus, uint32_t degree, bool is_boolean) {
+  // PlaintextBackend::set_field checks (evaluator.rs:866-875), same strings
+  FieldHost f;
+  f.init(modulus);
+  if (degree != 1) throw Error("Field should be of degree 1");
+  if (field_set_) {
+    if (memcmp(f.p, field_.p, sizeof f.p) != 0 || is_boolean != is_boolean_)
+      throw Error("GPU backend: the field changed between Relation messages");
+    return;
+  }
+  if (is_boolean && !f.is_two) throw Error("GPU backend: boolean gate set over a field with p != 2 is not supported");
+  field_ = f;
+  field_set_ = true;
+  is_boolean_ = is_boolean;
+  modulus_ = modulus;
+}
+
+void TapeBackend::need_field() const {
+  if (!field_set_) throw Error("Modulus is not initiated, used `set_field()` before calling.");
+}
+
+TapeBackend::FieldElement TapeBackend::minus_one() const {  // evaluator.rs:881-886
+  need_field();
+  TapeElement e;
+  e.bytes = modulus_;
+  size_t i = 0;
+  while (i < e.bytes.size() && e.bytes[i] == 0) e.bytes[i++] = 0xff;
+  if (i < e.bytes.size()) e.bytes[i] -= 1;
+  return e;
+}
+
+TapeBackend::Wire TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
+  if (tape_.kind.size() >= 0xFFFFFFF0u) throw Error("GPU backend: tape longer than 2^32 operations");
+  tape_.kind.push_back(kind);
+  tape_.a.push_back(a);
+  tape_.b.push_back(b);
+  if (kind != TK_ASSERT) ++tape_.n_value_ops;
+  return (Wire)(tape_.kind.size() - 1);
+}
+
+TapeBackend::Wire TapeBackend::arith(uint8_t kind, uint32_t a, uint32_t b) {
+  need_field();
+  return push(kind, a, b);  // for p == 2 the scheduler lowers add/mul to xor/and on bit-packed wires
+}
+
+TapeBackend::Wire TapeBackend::bitwise(uint8_t kind, uint32_t a, uint32_t b) {
+  need_field();
+  // PlaintextBackend applies & ^ to the integers and then `% m` (evaluator.rs:924-938);
+  // that only coincides with field arithmetic for p == 2.
+  if (!field_.is_two) throw Error("GPU backend: and/xor/not over a field with p != 2 is not supported");
+  return push(kind, a, b);
+}
+
+uint32_t TapeBackend::intern(const Value& bytes) {
+  auto it = const_index_.find(bytes);
+  if (it != const_index_.end()) return it->second;
+  const uint32_t idx = (uint32_t)tape_.consts.size();
+  tape_.consts.push_back(bytes);
+  const_index_.emplace(bytes, idx);
+  return idx;
+}
+
+TapeBackend::Wire TapeBackend::constant(FieldElement val) {
+  need_field();
+  if (val.kind != TapeElement::LITERAL) throw Error("GPU backend: constant() needs literal bytes");
+  // constant() stores the integer unreduced in the reference (evaluator.rs:896-898);
+  // parity is only claimed for canonical values.
+  if (!field_.is_canonical(val.bytes))
+    throw Error("GPU backend: non-canonical constant (value >= field characteristic) is not supported");
+  return push(TK_CONST, intern(val.bytes), 0);
+}
+
+TapeBackend::Wire TapeBackend::add_constant(const Wire& x, FieldElement c) {
+  need_field();
+  if (c.kind != TapeElement::LITERAL) throw Error("GPU backend: add_constant() needs literal bytes");
+  return push(TK_ADDC, x, intern(c.bytes));  // (a + c) % m: c may be reduced first
+}
+
+TapeBackend::Wire TapeBackend::mul_constant(const Wire& x, FieldElement c) {
+  need_field();
+  if (c.kind != TapeElement::LITERAL) throw Error("GPU backend: mul_constant() needs literal bytes");
+  return push(TK_MULC, x, intern(c.bytes));
+}
+
+void TapeBackend::assert_zero(const Wire& w) {
+  need_field();
+  const uint32_t seq = (uint32_t)tape_.assert_op.size();
+  const Wire op = push(TK_ASSERT, w, seq);
+  tape_.assert_op.push_back(op);
+  tape_.assert_wire.push_back(pending_assert_wire_);
+}
+
+TapeBackend::FieldElement TapeBackend::instance_ref(uint32_t position) {
+  TapeElement e;
+  e.kind = TapeElement::INSTANCE_REF;
+  e.position = position;
+  return e;
+}
+TapeBackend::FieldElement TapeBackend::witness_ref(uint32_t position) {
+  TapeElement e;
+  e.kind = TapeElement::WITNESS_REF;
+  e.position = position;
+  return e;
+}
+TapeBackend::FieldElement TapeBackend::import_instance(const Value& v) {
+  lane0_instances_.push_back(v);
+  return instance_ref((uint32_t)lane0_instances_.size() - 1);
+}
+TapeBackend::FieldElement TapeBackend::import_witness(const Value& v) {
+  lane0_witnesses_.push_back(v);
+  return witness_ref((uint32_t)lane0_witnesses_.size() - 1);
+}
+
+TapeBackend::Wire TapeBackend::instance(FieldElement val) {
+  need_field();
+  if (val.kind != TapeElement::INSTANCE_REF) throw Error("GPU backend: instance() needs a stream position");
+  if (val.position + 1 > tape_.n_instance) tape_.n_instance = val.position + 1;
+  return push(TK_INSTANCE, val.position, 0);
+}
+
+TapeBackend::Wire TapeBackend::witness(const FieldElement* val) {
+  need_field();
+  // PlaintextBackend panics on a missing witness (evaluator.rs:944-946)
+  if (!val) throw Panic("Missing witness value for PlaintextBackend");
+  if (val->kind != TapeElement::WITNESS_REF) throw Error("GPU backend: witness() needs a stream position");
+  if (val->position + 1 > tape_.n_witness) tape_.n_witness = val->position + 1;
+  return push(TK_WITNESS, val->position, 0);
+}
+
+}  // namespace zki

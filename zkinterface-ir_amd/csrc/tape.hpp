@@ -1,0 +1,129 @@
+// TapeBackend: a ZKBackend (rust/src/consumers/evaluator.rs:17-76) whose Wire
+// is a handle into a linear gate tape.  Semantic twin of the reference's
+// IRFlattener (rust/src/consumers/flattening.rs:42-191), which also answers
+// every backend call with a freshly numbered wire; here the calls are kept in
+// memory as the program the HIP kernels replay for a whole batch of witnesses.
+#pragma once
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "sieve/structs.hpp"
+
+namespace zki {
+
+// op kinds shared with the device (device/replay_kernels.hpp OpKind)
+enum TapeKind : uint8_t {
+  TK_NOP = 0, TK_ADD = 1, TK_MUL = 2, TK_ADDC = 3, TK_MULC = 4, TK_COPY = 5, TK_CONST = 6,
+  TK_INSTANCE = 7, TK_WITNESS = 8, TK_ASSERT = 9, TK_AND = 10, TK_XOR = 11, TK_NOT = 12,
+};
+const char* tape_kind_name(uint8_t k);  // names of SURVEY.md Appendix A ("copy", "mul", ...)
+
+constexpr uint32_t kNoWire = 0xFFFFFFFFu;
+
+// Host-side description of GF(p), p < 2^256: limbs and Montgomery constants
+// for the device (device/fp_mont.hpp FieldParams), plus canonicalisation of
+// arbitrary-length little-endian Values.
+struct FieldHost {
+  uint32_t nwords = 0;          // 32-bit words in use: 2, 4, 6 or 8 (64-bit limb granularity)
+  uint32_t bits = 0;
+  bool is_two = false;          // p == 2: Boolean/bit-packed path, no Montgomery form
+  uint32_t p[8] = {0}, r2[8] = {0}, one[8] = {0};
+  uint32_t n0inv = 0;
+
+  void init(const Value& modulus_le);                         // throws zki::Error if unsupported
+  bool is_canonical(const Value& v) const;                    // v < p as integers
+  void reduce(const Value& v, uint32_t out[8]) const;         // v mod p
+  void to_mont(const uint32_t in[8], uint32_t out[8]) const;  // in * R mod p
+  void add(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) const;
+};
+
+struct Tape {
+  // one entry per backend call, in call order; asserts included (no value)
+  std::vector<uint8_t> kind;
+  std::vector<uint32_t> a, b;      // operand handles; const-pool index; input position; assert seq
+  // asserts, in execution order
+  std::vector<uint32_t> assert_op;     // tape index of the k-th assert_zero
+  std::vector<uint64_t> assert_wire;   // local id printed in "Wire_{} (may be weighted) ..."
+  // constant pool: distinct little-endian byte strings
+  std::vector<Value> consts;
+  uint32_t n_instance = 0, n_witness = 0;  // input positions referenced (max + 1)
+  uint64_t n_value_ops = 0;
+
+  size_t size() const { return kind.size(); }
+};
+
+// FieldElement of the recording backend: either literal bytes (constants) or a
+// position in the per-lane instance / witness stream.
+struct TapeElement {
+  enum Kind : uint8_t { LITERAL, INSTANCE_REF, WITNESS_REF } kind = LITERAL;
+  uint32_t position = 0;
+  Value bytes;
+};
+
+class TapeBackend {
+ public:
+  using Wire = uint32_t;
+  using FieldElement = TapeElement;
+
+  static FieldElement from_bytes_le(const Value& v) {  // evaluator.rs:25
+    TapeElement e;
+    e.bytes = v;
+    return e;
+  }
+  void set_field(const Value& modulus, uint32_t degree, bool is_boolean);
+  FieldElement one() const { return literal(1); }
+  FieldElement minus_one() const;
+  FieldElement zero() const { return literal(0); }
+
+  Wire copy(const Wire& w) { return push(TK_COPY, w, 0); }
+  Wire constant(FieldElement val);
+  void assert_zero(const Wire& w);
+  void note_assert_wire(WireId local_id) { pending_assert_wire_ = local_id; }
+  Wire add(const Wire& x, const Wire& y) { return arith(TK_ADD, x, y); }
+  Wire multiply(const Wire& x, const Wire& y) { return arith(TK_MUL, x, y); }
+  Wire add_constant(const Wire& x, FieldElement c);
+  Wire mul_constant(const Wire& x, FieldElement c);
+  Wire and_(const Wire& x, const Wire& y) { return bitwise(TK_AND, x, y); }
+  Wire xor_(const Wire& x, const Wire& y) { return bitwise(TK_XOR, x, y); }
+  Wire not_(const Wire& x) { return bitwise(TK_NOT, x, 0); }
+  Wire instance(FieldElement val);
+  Wire witness(const FieldElement* val);
+
+  // Single-statement use (`evaluate <workspace>`): the values of an Instance /
+  // Witness message become lane 0's input stream, referenced by position.
+  FieldElement import_instance(const Value& v);
+  FieldElement import_witness(const Value& v);
+  static FieldElement instance_ref(uint32_t position);
+  static FieldElement witness_ref(uint32_t position);
+
+  const Tape& tape() const { return tape_; }
+  const FieldHost& field() const { return field_; }
+  bool field_set() const { return field_set_; }
+  bool is_boolean() const { return is_boolean_; }
+  const std::vector<Value>& lane0_instances() const { return lane0_instances_; }
+  const std::vector<Value>& lane0_witnesses() const { return lane0_witnesses_; }
+
+ private:
+  static FieldElement literal(uint8_t v) {
+    TapeElement e;
+    e.bytes.assign(1, v);
+    return e;
+  }
+  Wire push(uint8_t kind, uint32_t a, uint32_t b);
+  Wire arith(uint8_t kind, uint32_t a, uint32_t b);
+  Wire bitwise(uint8_t kind, uint32_t a, uint32_t b);
+  uint32_t intern(const Value& bytes);
+  void need_field() const;
+
+  Tape tape_;
+  FieldHost field_;
+  bool field_set_ = false, is_boolean_ = false;
+  Value modulus_;
+  std::map<Value, uint32_t> const_index_;
+  WireId pending_assert_wire_ = 0;
+  std::vector<Value> lane0_instances_, lane0_witnesses_;
+};
+
+}  // namespace zki

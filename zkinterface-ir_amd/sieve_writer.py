@@ -1,10 +1,13 @@
-"""Test-side FlatBuffers writer for SIEVE IR messages (`.sieve`).
+"""FlatBuffers writer for SIEVE IR messages (`.sieve`): emits synthetic
+workspaces (bench.py workloads) and the circuits used by the tests.
 
 Builds size-prefixed buffers following /root/reference/sieve_ir.fbs (vtable
 slots = the VT_* constants of rust/src/sieve_ir_generated.rs) so
-that circuits used by the reference's own tests can be restated as *data*
-(tuples) and fed both to the oracle and to the product.  Not a translation of
-the reference's builders: a small back-to-front table writer.
+that circuits can be stated as *data* (tuples) and emitted as real workspaces
+the original `zki_sieve` could consume (write half of rust/src/structs/*.rs,
+sinks of rust/src/producers/sink.rs:84-100).  Not a translation of the
+reference's builders: a small back-to-front table writer plus a numpy bulk
+path for million-gate relations.
 
 Gate tuples (mirroring rust/src/structs/gates.rs:17-55):
   ('constant', out, bytes) ('assert_zero', inp) ('copy', out, inp)
@@ -327,31 +330,35 @@ def _binary_gate_block():
     return blob, holes, tag_off, d_off
 
 
-def write_relation_bulk(modulus, gateset, features, pre_gates, tags, outs, lefts, rights, post_gates, degree=1):
-    """Relation message whose directives are pre_gates + N binary gates + post_gates.
-    tags/outs/lefts/rights: numpy arrays (tags = DirectiveSet numbers 4,5,8,9)."""
+def write_relation_segments(modulus, gateset, features, segments, functions=None, degree=1):
+    """Relation message whose directives are the concatenation of `segments`:
+      ('gates', [gate tuples])                      -- any gate, built one by one
+      ('bulk', tags, outs, lefts, rights)           -- numpy arrays of binary gates
+                                                       (tags = DirectiveSet numbers 4 add, 5 mul, 8 and, 9 xor)
+    """
     blob, holes, tag_off, d_off = _binary_gate_block()
-    n = len(tags)
     bs = len(blob)
     block = np.frombuffer(blob, dtype=np.uint8)
-    arr = np.tile(block, n).reshape(n, bs)
-    for h, vals in zip(holes, (outs, lefts, rights)):
-        arr[:, h:h + 8] = np.asarray(vals, dtype='<u8').reshape(n, 1).view(np.uint8).reshape(n, 8)
-    arr[:, tag_off] = np.asarray(tags, dtype=np.uint8)
-    bulk = arr.tobytes()
-
     b = Builder()
     b.minalign = 8
-    post = [_gate(b, g) for g in post_gates]
-    b._align(8, 0)
-    bulk_end = b.size  # end offset of the end of the bulk region
-    b._push(bulk)
-    # block i starts at end offset bulk_end + n*bs - i*bs ; its Directive table is d_off bytes in
-    starts = b.size - np.arange(n, dtype=np.int64) * bs
-    bulk_dirs = (starts - d_off).tolist()
-    pre = [_gate(b, g) for g in pre_gates]
-    # offset vector written with numpy as well
-    offs = np.array(pre + bulk_dirs + post, dtype=np.int64)
+    parts = []  # per segment: int64 array of directive end offsets, in logical order
+    for seg in segments:
+        if seg[0] == 'gates':
+            parts.append(np.array([_gate(b, g) for g in seg[1]], dtype=np.int64))
+        elif seg[0] == 'bulk':
+            _, tags, outs, lefts, rights = seg
+            n = len(tags)
+            arr = np.tile(block, n).reshape(n, bs)
+            for h, vals in zip(holes, (outs, lefts, rights)):
+                arr[:, h:h + 8] = np.ascontiguousarray(np.asarray(vals, dtype='<u8')).view(np.uint8).reshape(n, 8)
+            arr[:, tag_off] = np.asarray(tags, dtype=np.uint8)
+            b._align(8, 0)
+            b._push(arr.tobytes())
+            # block i starts at end offset size - i*bs; its Directive table sits d_off bytes in
+            parts.append(b.size - np.arange(n, dtype=np.int64) * bs - d_off)
+        else:
+            raise ValueError(seg[0])
+    offs = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
     m = len(offs)
     b._align(4, 4 * m)
     base = b.size + 4 * m
@@ -359,9 +366,18 @@ def write_relation_bulk(modulus, gateset, features, pre_gates, tags, outs, lefts
     b._push((pos - offs).astype('<u4').tobytes())
     b._push(struct.pack('<I', m))
     gv = b.size
+    fv = None
+    if functions:
+        fts = []
+        for (name, oc, ic, inc, wc, body) in functions:
+            bv = _gates_vector(b, body)
+            nm = b.string(name)
+            fts.append(b.table([(4, 'off', nm), (6, 'u64', _u64(oc)), (8, 'u64', _u64(ic)), (10, 'u64', _u64(inc)),
+                                (12, 'u64', _u64(wc)), (14, 'off', bv)]))
+        fv = b.offset_vector(fts)
     feat = b.string(features)
     gs = b.string(gateset)
     h = _header(b, modulus, degree)
-    rel = b.table([(4, 'off', h), (6, 'off', gs), (8, 'off', feat), (12, 'off', gv)])
+    rel = b.table([(4, 'off', h), (6, 'off', gs), (8, 'off', feat), (10, 'off', fv), (12, 'off', gv)])
     root = b.table([(4, 'u8', 1), (6, 'off', rel)])
     return b.finish_size_prefixed(root)

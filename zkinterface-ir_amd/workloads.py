@@ -1,0 +1,171 @@
+"""Synthetic SIEVE IR workloads of BASELINE.json / SURVEY.md 8(d), emitted as
+real `.sieve` message streams (the reference publishes no benchmark inputs).
+
+C2 `R_arith`: BN254 scalar field, layered PRNG circuit of W x D Add/Mul gates,
+256 instance + (W-256) witness inputs, 64 output comparisons
+{Instance, MulConstant(p-1), Add, AssertZero}, `Free` after every layer,
+relation split into <= 100,000-gate messages like the reference's GateBuilder
+(rust/src/producers/builder.rs:46-49,72).
+"""
+import numpy as np
+
+from .sieve_writer import int_to_le, write_relation_segments
+
+BN254_R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+MAX_GATES_PER_MESSAGE = 100_000
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    """Stateless splitmix64 finaliser on a numpy uint64 array (wrapping arithmetic)."""
+    with np.errstate(over='ignore'):
+        z = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def _limbs_of(v, n=4):
+    return [np.uint64((v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for i in range(n)]
+
+
+def _cond_sub(limbs, m):
+    """limbs: list of 4 uint64 arrays (little-endian); subtract m where limbs >= m."""
+    ml = _limbs_of(m)
+    # compare from the top limb down
+    ge = np.ones(limbs[0].shape, dtype=bool)
+    decided = np.zeros(limbs[0].shape, dtype=bool)
+    for i in (3, 2, 1, 0):
+        gt = limbs[i] > ml[i]
+        lt = limbs[i] < ml[i]
+        ge = np.where(~decided & gt, True, ge)
+        ge = np.where(~decided & lt, False, ge)
+        decided |= gt | lt
+    out = []
+    borrow = np.zeros(limbs[0].shape, dtype=np.uint64)
+    with np.errstate(over='ignore'):
+        for i in range(4):
+            d = limbs[i] - ml[i]
+            b1 = (limbs[i] < ml[i]).astype(np.uint64)
+            d2 = d - borrow
+            b2 = (d < borrow).astype(np.uint64)
+            out.append(np.where(ge, d2, limbs[i]))
+            borrow = b1 | b2
+    return out
+
+
+def random_field_elements(seed, shape, p=BN254_R):
+    """[shape..., 32] uint8: 4 x splitmix64 words assembled little-endian, reduced mod p."""
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64)
+    limbs = []
+    with np.errstate(over='ignore'):
+        for k in range(4):
+            limbs.append(splitmix64((np.uint64(seed) + idx * np.uint64(4) + np.uint64(k)) & _M64))
+    bits = p.bit_length()
+    if bits < 256:  # p > 2^(bits-1): at most 2^(256-bits+1) multiples to remove
+        for mult in [1 << s for s in range(256 - bits + 1, -1, -1)]:
+            if mult * p < (1 << 256):
+                limbs = _cond_sub(limbs, mult * p)
+    else:
+        limbs = _cond_sub(limbs, p)
+    arr = np.stack(limbs, axis=-1).astype('<u8')  # [n, 4]
+    return arr.view(np.uint8).reshape(tuple(shape) + (32,))
+
+
+class ArithLayered:
+    """The C2 / C3 workload.  Wire ids: layer l occupies [l*W, (l+1)*W); the
+    epilogue uses ids from (D+1)*W upwards."""
+
+    def __init__(self, W=4096, D=256, n_instance0=256, n_out=64, seed=0x5EED0001, p=BN254_R, mul_percent=None):
+        assert n_instance0 <= W and n_out <= W
+        self.W, self.D, self.n_instance0, self.n_out, self.seed, self.p = W, D, n_instance0, n_out, seed, p
+        self.mod_le = int_to_le(p)
+        self.width = 8 * ((p.bit_length() + 63) // 64)
+        self.n_instance = n_instance0 + n_out
+        self.n_witness = W - n_instance0
+        self.n_gates = W * D                      # the Add/Mul gates the metric counts
+        layer = np.arange(1, D + 1, dtype=np.uint64)[:, None]
+        j = np.arange(W, dtype=np.uint64)[None, :]
+        with np.errstate(over='ignore'):
+            h = splitmix64(np.uint64(seed) ^ ((layer << np.uint64(32)) + j))
+            h2 = splitmix64(h)
+        if mul_percent is None:
+            self.is_mul = (h & np.uint64(1)).astype(bool)
+        else:
+            self.is_mul = ((h >> np.uint64(8)) % np.uint64(100)) < np.uint64(mul_percent)
+        self.src_a = (h2 % np.uint64(W)).astype(np.uint32)                        # index inside layer l-1
+        self.src_b = ((h2 >> np.uint64(32)) % np.uint64(W)).astype(np.uint32)
+
+    # ---- relation ---------------------------------------------------------
+    def _segments(self, with_epilogue=True, free_last=True):
+        W, D = self.W, self.D
+        segs = []
+        inputs = [('instance', k) for k in range(self.n_instance0)] + [('witness', k) for k in range(self.n_instance0, W)]
+        segs.append(('gates', inputs, len(inputs)))
+        for l in range(1, D + 1):
+            base_prev, base = (l - 1) * W, l * W
+            tags = np.where(self.is_mul[l - 1], 5, 4).astype(np.uint8)
+            outs = np.arange(base, base + W, dtype=np.uint64)
+            lefts = self.src_a[l - 1].astype(np.uint64) + np.uint64(base_prev)
+            rights = self.src_b[l - 1].astype(np.uint64) + np.uint64(base_prev)
+            segs.append(('bulk', tags, outs, lefts, rights, W))
+            segs.append(('gates', [('free', base_prev, base_prev + W - 1)], 1))
+        if with_epilogue:
+            e = (D + 1) * W
+            neg_one = int_to_le(self.p - 1)
+            ep = []
+            for t in range(self.n_out):
+                w0, w1, w2 = e + 3 * t, e + 3 * t + 1, e + 3 * t + 2
+                ep += [('instance', w0), ('mulc', w1, w0, neg_one), ('add', w2, D * W + t, w1), ('assert_zero', w2)]
+            ep.append(('free', e, e + 3 * self.n_out - 1))
+            segs.append(('gates', ep, len(ep)))
+        if free_last:
+            segs.append(('gates', [('free', D * W, D * W + W - 1)], 1))
+        return segs
+
+    def relation_messages(self, with_epilogue=True, free_last=True):
+        """List of size-prefixed Relation messages, each <= 100,000 directives."""
+        msgs, cur, cur_n = [], [], 0
+        for seg in self._segments(with_epilogue, free_last):
+            n = seg[-1]
+            if cur and cur_n + n > MAX_GATES_PER_MESSAGE:
+                msgs.append(cur)
+                cur, cur_n = [], 0
+            cur.append(seg[:-1])
+            cur_n += n
+        if cur:
+            msgs.append(cur)
+        return [write_relation_segments(self.mod_le, 'arithmetic', 'simple', m) for m in msgs]
+
+    # ---- inputs -----------------------------------------------------------
+    def inputs(self, batch, lane_offset=0):
+        """(instances [batch][n_instance][width], witnesses [batch][n_witness][width]) uint8 arrays.
+        The last n_out instances (expected outputs) are left zero: see set_expected_outputs()."""
+        W = self.W
+        vals = random_field_elements(self.seed + 0x1000 + lane_offset * W * 4, (batch, W), self.p)[..., :self.width]
+        inst = np.zeros((batch, self.n_instance, self.width), dtype=np.uint8)
+        inst[:, :self.n_instance0] = vals[:, :self.n_instance0]
+        wit = np.ascontiguousarray(vals[:, self.n_instance0:])
+        return inst, wit
+
+    def set_expected_outputs(self, inst, outputs, lane_offset=0, corrupt_every=97):
+        """outputs: [batch][n_out] python ints or [batch][n_out][width] uint8.  Lanes whose global index
+        is a multiple of `corrupt_every` get output 0 off by one => those statements are FALSE."""
+        batch = inst.shape[0]
+        out = np.asarray(outputs)
+        if out.dtype != np.uint8:
+            raise TypeError('outputs must be a uint8 array of little-endian values')
+        inst[:, self.n_instance0:] = out.reshape(batch, self.n_out, self.width)
+        bad = [i for i in range(batch) if corrupt_every and (i + lane_offset) % corrupt_every == 0]
+        for i in bad:
+            v = (int.from_bytes(inst[i, self.n_instance0].tobytes(), 'little') + 1) % self.p
+            inst[i, self.n_instance0] = np.frombuffer(v.to_bytes(self.width, 'little'), dtype=np.uint8)
+        return len(bad)
+
+    def output_wire_ids(self):
+        return [self.D * self.W + t for t in range(self.n_out)]
+
+
+def expected_satisfied(batch, lane_offset=0, corrupt_every=97):
+    return batch - sum(1 for i in range(batch) if (i + lane_offset) % corrupt_every == 0)
