@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gate-ops/sec of the SIEVE IR batch evaluator on MI355X.
+
+Workload = BASELINE.json configs[1] (C2): BN254 scalar field, 2^20-gate Add/Mul
+relation (W=4096 x D=256), 1024 witnesses per GPU, synthetic inputs.  One
+"step" = one replay of the whole recorded tape over the GPU's witness batch
+(instance/witness loads + canonicality check, every gate, the 64 AssertZero
+checks, the verdict reduction) and, for N > 1, the RCCL all-reduce of the
+{satisfied, failed} counts.  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+# algorithmic bytes per backend op and witness for a 256-bit field
+BYTES_PER_OP = {1: 96, 2: 96, 10: 96, 11: 96,       # add, mul, and, xor: 2 x 32 B read + 32 B write
+                3: 64, 4: 64, 5: 64, 12: 64,        # addc, mulc, copy, not: 32 B read + 32 B write
+                6: 32,                              # constant: 32 B write
+                7: 64, 8: 64,                       # instance / witness: 32 B read + 32 B write
+                9: 32}                              # assert_zero: 32 B read
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class _DevU64x2:
+    """torch view of the engine's device counters {satisfied, failed}"""
+
+    def __init__(self, ptr):
+        self.__cuda_array_interface__ = {'shape': (2,), 'typestr': '<i8', 'data': (int(ptr), False), 'version': 2}
+
+
+def build_session(zk, wl, batch, lane_offset, lane_group):
+    """probe pass for the expected outputs, then the real session with resident inputs"""
+    t0 = time.time()
+    inst, wit = wl.inputs(batch, lane_offset)
+    probe = zk.Evaluator()
+    probe.declare_inputs(wl.n_instance0, wl.n_witness)
+    for m in wl.relation_messages(with_epilogue=False, free_last=False):
+        probe.ingest_message(m)
+    probe.finalize()
+    probe.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), batch)
+    probe.replay()
+    probe.synchronize()
+    outs = np.zeros((batch, wl.n_out, wl.width), dtype=np.uint8)
+    for t, wid in enumerate(wl.output_wire_ids()):
+        vals = probe.get(wid, batch)
+        outs[:, t] = np.frombuffer(b''.join(v.to_bytes(wl.width, 'little') for v in vals),
+                                   dtype=np.uint8).reshape(batch, wl.width)
+    probe.close()
+    n_bad = wl.set_expected_outputs(inst, outs, lane_offset)
+    t1 = time.time()
+    msgs = wl.relation_messages()
+    t2 = time.time()
+    ev = zk.Evaluator()
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in msgs:
+        ev.ingest_message(m)
+    assert ev.host_violations() == [], ev.host_violations()
+    t3 = time.time()
+    ev.finalize()
+    t4 = time.time()
+    if lane_group:
+        ev.set_lane_group(lane_group)
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    t5 = time.time()
+    host = {'probe_s': t1 - t0, 'emit_sieve_s': t2 - t1, 'ingest_and_record_s': t3 - t2, 'schedule_s': t4 - t3,
+            'h2d_s': t5 - t4, 'relation_bytes': sum(len(m) for m in msgs), 'messages': len(msgs)}
+    return ev, inst, wit, n_bad, msgs, host
+
+
+def cpu_baseline(wl, msgs, inst, wit, gates):
+    """The oracle (literal restatement of the reference Evaluator + PlaintextBackend) on this
+    box's host cores, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    rel = b''.join(msgs)
+    one = oracle_lib.eval_batch(rel, wl.mod_le, inst[:1].tobytes(), wl.n_instance, wit[:1].tobytes(), wl.n_witness,
+                                wl.width, 1, 1)
+    per_lane = max(one[1], 1e-3)
+    threads = min(cores, 64)
+    lanes = int(min(inst.shape[0], max(threads, min(4 * threads, (15.0 / per_lane) * threads))))
+    ok, secs, ops = oracle_lib.eval_batch(rel, wl.mod_le, inst[:lanes].tobytes(), wl.n_instance,
+                                          wit[:lanes].tobytes(), wl.n_witness, wl.width, lanes, threads)
+    return {'value': gates * lanes / secs, 'unit': 'gate-ops/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d witnesses of the same 2^20-gate relation, one reference-style Evaluator run per witness, '
+                      '%d threads, %.1f s wall (single witness: %.2f s)' % (lanes, threads, secs, per_lane),
+            'satisfied_in_sample': int(sum(ok))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-per-gpu', type=int, default=1024)
+    ap.add_argument('--width', type=int, default=4096)
+    ap.add_argument('--depth', type=int, default=256)
+    ap.add_argument('--lane-group', type=int, default=0, help='replay lane groups of this size one after the other')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                     '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU: the replay path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    entry.build() if not os.path.exists(os.path.join(entry.PKG_DIR, 'lib', 'libzkgpu.so')) else None
+    zk = entry.load_package()
+    from zkinterface_ir_amd import workloads
+
+    wl = workloads.ArithLayered(W=args.width, D=args.depth)
+    batch = args.batch_per_gpu
+    lane_offset = rank * batch
+    ev, inst, wit, n_bad, msgs, host = build_session(zk, wl, batch, lane_offset, args.lane_group)
+    gates = wl.n_gates
+    kinds, _, _ = ev.tape()
+    algo_bytes_per_lane = int(sum(BYTES_PER_OP.get(int(k), 0) * int(c) for k, c in zip(*np.unique(kinds, return_counts=True))))
+    info = ev.schedule_info()
+    wide_launches = info['launches'] - info['sequential_launches']
+
+    counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if world > 1 else None
+
+    def step():
+        ev.replay()
+        ev.synchronize()                # verdict words and counts are final on the engine's stream
+        if world > 1:
+            dist.all_reduce(counts_t)   # RCCL over xGMI: {satisfied, failed}, 16 bytes
+
+    for _ in range(args.warmup):
+        step()
+    ev.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ev_ms = []
+    for _ in range(args.steps):
+        step()
+        ev_ms.append(ev.last_replay_ms)
+    ev.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        total = counts_t.cpu().tolist()
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    else:
+        total = list(ev.counts())
+    exp_sat = workloads.expected_satisfied(batch * world)
+    assert total[0] == exp_sat and total[0] + total[1] == batch * world, (total, exp_sat)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = gates * batch * world / (elapsed / args.steps)
+        # roofline of the dominant kernel (replay_kernel<8,false>, one launch per circuit level):
+        # HIP-event time of the replays on the engine's stream / wide launches
+        kernel_ms = float(np.mean(ev_ms)) / max(wide_launches, 1)
+        bytes_per_launch = algo_bytes_per_lane * batch / max(wide_launches, 1)
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses',
+            'value': value, 'unit': 'gate-ops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'u64x4 (GF(p) Montgomery limbs, exact integer)', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
+                                   'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world),
+                       'relation_messages': host['messages'], 'relation_bytes': host['relation_bytes'],
+                       'backend_ops_per_witness': int(len(kinds)), 'levels': info['levels'],
+                       'launches_per_step': info['launches'], 'wire_table_slots': info['slots'],
+                       'wire_table_MB': round(ev.table_bytes / 1e6, 1), 'lane_group': args.lane_group,
+                       'parallelism': 'witness lanes sharded over %d GPU(s); one all-reduce of 2 x u64' % world,
+                       'satisfied': total[0], 'failed': total[1], 'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')}},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'replay_kernel<8,false>', 'launches_per_step': wide_launches,
+                         'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
