@@ -30,6 +30,20 @@ BYTES_PER_OP = {1: 96, 2: 96, 10: 96, 11: 96,       # add, mul, and, xor: 2 x 32
                 7: 64, 8: 64,                       # instance / witness: 32 B read + 32 B write
                 9: 32}                              # assert_zero: 32 B read
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
+
+
+def pmc_traffic(width, batch, nwords_bytes):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; tools/pmc_traffic.py
+    applies the gfx950 corrections).  Only valid for the grid it was measured on."""
+    try:
+        d = json.load(open(PMC_TRAFFIC_JSON))
+    except (OSError, ValueError):
+        return None, None
+    if d.get('grid_size_filter') != width * batch:
+        return None, None
+    return d['traffic_bytes_per_launch'], os.path.relpath(PMC_TRAFFIC_JSON, ROOT)
 
 
 class _DevU64x2:
@@ -185,6 +199,7 @@ def main():
         kernel_ms = float(np.mean(ev_ms)) / max(wide_launches, 1)
         bytes_per_launch = algo_bytes_per_lane * batch / max(wide_launches, 1)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(wl.W, batch, wl.width)
         out = {
             'metric': 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses',
             'value': value, 'unit': 'gate-ops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -199,7 +214,7 @@ def main():
                        'parallelism': 'witness lanes sharded over %d GPU(s); one all-reduce of 2 x u64' % world,
                        'satisfied': total[0], 'failed': total[1], 'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'replay_kernel<8,false>', 'launches_per_step': wide_launches,
                          'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch},
         }
