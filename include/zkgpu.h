@@ -85,6 +85,8 @@ uint64_t zkgpu_tape_asserts(const zkgpu_session* s);
 /* kinds[i] in {1 add,2 mul,3 addc,4 mulc,5 copy,6 constant,7 instance,8 witness,9 assert_zero,
  *              10 and,11 xor,12 not}; a[i], b[i] = operand handles / constant index / position */
 int zkgpu_tape_dump(const zkgpu_session* s, uint8_t* kinds, uint32_t* a, uint32_t* b, uint64_t cap);
+/* local wire id of the k-th assert_zero (the id the violation message prints) */
+int zkgpu_tape_assert_wires(const zkgpu_session* s, uint64_t* local_wire_ids, uint64_t cap);
 uint32_t zkgpu_n_constants(const zkgpu_session* s);
 size_t zkgpu_constant_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap);
 

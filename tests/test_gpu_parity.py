@@ -191,3 +191,34 @@ def test_full_size_c2_properties():
         wv = [int.from_bytes(wit[lane, k].tobytes(), 'little') for k in range(wl.n_witness)]
         ref = oracle_lane(wl.mod_le, iv, wv, msgs, wl.width, trace=False)
         assert ev.get_violations(lane) == ref.violations
+
+
+@pytest.mark.parametrize('seed', range(25))
+def test_random_structured_relations_on_gpu(seed):
+    """functions / for / switch / nested switch / frees: every lane's wire values and violation
+    strings against the oracle (same generator as the CPU-tier fuzz)."""
+    from random_circuits import Gen
+    from test_fuzz_host import FIELDS
+    p, boolean = FIELDS[seed % len(FIELDS)]
+    g = Gen(seed, p, boolean)
+    rel, mod_le = g.relation(n_top=14)
+    lanes = 67
+    rows_i, rows_w = g.lane_inputs(lanes, seed + 1000)
+    ev = zk.Evaluator()
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    ev.ingest_message(rel)
+    ev.finalize(retain_all=True)
+    w = ev.elem_bytes
+    inst, wit = batch_arrays(rows_i, rows_w, w)
+    ev.set_inputs(inst if g.n_inst else None, wit if g.n_wit else None, lanes)
+    ev.replay()
+    ev.synchronize()
+    vals = ev.dump_trace_values(lanes)
+    n_ok = 0
+    for lane in range(lanes):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32)
+        assert ev.get_violations(lane) == ref.violations, (seed, lane)
+        rv = ref.trace_values()
+        assert vals[lane][:len(rv)] == rv, (seed, lane)
+        n_ok += not ref.violations
+    assert ev.counts() == (n_ok, lanes - n_ok)

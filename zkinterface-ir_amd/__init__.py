@@ -70,6 +70,7 @@ def lib():
         'zkgpu_tape_value_ops': (u64, [vp]),
         'zkgpu_tape_asserts': (u64, [vp]),
         'zkgpu_tape_dump': (ci, [vp, vp, vp, vp, u64]),
+        'zkgpu_tape_assert_wires': (ci, [vp, vp, u64]),
         'zkgpu_n_constants': (u32, [vp]),
         'zkgpu_constant_bytes': (sz, [vp, u32, ctypes.c_char_p, sz]),
         'zkgpu_finalize': (ci, [vp, ci]),
@@ -173,6 +174,13 @@ class Evaluator:
         if n:
             self._ck(self.L.zkgpu_tape_dump(self.h, kinds.ctypes.data, a.ctypes.data, b.ctypes.data, n))
         return kinds, a, b
+
+    def assert_wires(self):
+        import numpy as np
+        n = self.n_asserts
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        self._ck(self.L.zkgpu_tape_assert_wires(self.h, out.ctypes.data, n))
+        return out[:n]
 
     def constants(self):
         out = []

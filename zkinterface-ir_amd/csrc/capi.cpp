@@ -229,6 +229,13 @@ int zkgpu_tape_dump(const zkgpu_session* s, uint8_t* kinds, uint32_t* a, uint32_
   }
   return 0;
 }
+int zkgpu_tape_assert_wires(const zkgpu_session* s, uint64_t* local_wire_ids, uint64_t cap) {
+  if (!s) return -1;
+  const Tape& t = s->backend.tape();
+  if (cap < t.assert_wire.size()) return 1;
+  if (!t.assert_wire.empty()) memcpy(local_wire_ids, t.assert_wire.data(), t.assert_wire.size() * 8);
+  return 0;
+}
 uint32_t zkgpu_n_constants(const zkgpu_session* s) { return s ? (uint32_t)s->backend.tape().consts.size() : 0; }
 size_t zkgpu_constant_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap) {
   if (!s || index >= s->backend.tape().consts.size()) return 0;
