@@ -115,6 +115,10 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s);
 /* replay lane groups of this many witnesses one after the other (0 = whole batch at once) */
 int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 
+/* options: "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a
+ * 32-witness slice resident in one CU's LDS when the live wires fit in 160 KiB).  Set before zkgpu_set_inputs*. */
+int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value);
+int zkgpu_uses_lds_path(zkgpu_session* s);           /* 1 / 0, -1 on error (touches the GPU) */
 int zkgpu_replay(zkgpu_session* s);                  /* asynchronous */
 int zkgpu_replay_timed(zkgpu_session* s);            /* per-launch HIP events, synchronous */
 int zkgpu_synchronize(zkgpu_session* s);

@@ -222,3 +222,69 @@ def test_random_structured_relations_on_gpu(seed):
         assert vals[lane][:len(rv)] == rv, (seed, lane)
         n_ok += not ref.violations
     assert ev.counts() == (n_ok, lanes - n_ok)
+
+
+@pytest.mark.parametrize('path', ['hbm', 'lds'])
+@pytest.mark.parametrize('name', ['bool_correct', 'bool_incorrect'])
+def test_boolean_paths_agree_with_oracle(name, path):
+    """GF(2): the HBM-table kernel and the LDS-resident kernel, both against the oracle."""
+    bufs = golden_buffers(name)
+    for retain in (True, False):
+        ev = zk.Evaluator.from_messages(bufs)
+        ev.set_option('bool_path', path)
+        ev.finalize(retain_all=retain)
+        ev.set_inputs_from_messages()
+        assert ev.uses_lds_path() == (path == 'lds')
+        ev.replay()
+        ev.synchronize()
+        ref = OracleRun(buffers=bufs)
+        assert ev.get_violations(0) == ref.violations
+        if retain:
+            rv = ref.trace_values()
+            assert ev.dump_trace_values(1)[0][:len(rv)] == rv
+
+
+@pytest.mark.parametrize('path', ['hbm', 'lds'])
+def test_boolean_layered_batch_against_oracle(path):
+    """small C4-shaped relation, ragged batch spanning several 32- and 64-witness words"""
+    wl = workloads.BoolLayered(W=128, D=10, n_instance0=16, n_out=8)
+    batch = 203
+    inst, wit = wl.inputs(batch)
+    probe = zk.Evaluator()
+    probe.set_option('bool_path', path)
+    probe.declare_inputs(wl.n_instance0, wl.n_witness)
+    for m in wl.relation_messages(with_epilogue=False, free_last=False):
+        probe.ingest_message(m)
+    probe.finalize()
+    probe.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), batch)
+    probe.replay()
+    probe.synchronize()
+    outs = np.zeros((batch, wl.n_out), dtype=np.uint8)
+    for t, wid in enumerate(wl.output_wire_ids()):
+        outs[:, t] = probe.get(wid, batch)   # Evaluator::get on live wires (LDS path: write-back)
+    lane = 77
+    ref = oracle_lane(wl.mod_le, inst[lane, :wl.n_instance0, 0].tolist(), wit[lane, :, 0].tolist(),
+                      wl.relation_messages(with_epilogue=False, free_last=False), 1, trace=False)
+    assert [ref.get(w) for w in wl.output_wire_ids()] == outs[lane].tolist()
+    n_bad = wl.set_expected_outputs(inst, outs)
+    ev = zk.Evaluator()
+    ev.set_option('bool_path', path)
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    msgs = wl.relation_messages()
+    for m in msgs:
+        ev.ingest_message(m)
+    ev.finalize()
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (batch - n_bad, n_bad)
+    for lane in (0, 31, 32, 63, 64, 97, 194, 202):
+        ref = oracle_lane(wl.mod_le, inst[lane, :, 0].tolist(), wit[lane, :, 0].tolist(), msgs, 1, trace=False)
+        assert ev.get_violations(lane) == ref.violations, lane
+    # a value > 1 is not a canonical GF(2) element: flagged, not reduced
+    inst2 = inst.copy()
+    inst2[5, 0, 0] = 3
+    ev.set_inputs(inst2.tobytes(), wit.tobytes(), batch)
+    ev.replay()
+    ev.synchronize()
+    assert 'not canonical' in ev.get_violations(5)[0]

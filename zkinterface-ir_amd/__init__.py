@@ -83,6 +83,8 @@ def lib():
         'zkgpu_set_inputs_device': (ci, [vp, vp, vp, u32]),
         'zkgpu_set_inputs_from_messages': (ci, [vp]),
         'zkgpu_set_lane_group': (ci, [vp, u32]),
+        'zkgpu_set_option': (ci, [vp, ctypes.c_char_p, ctypes.c_char_p]),
+        'zkgpu_uses_lds_path': (ci, [vp]),
         'zkgpu_replay': (ci, [vp]),
         'zkgpu_replay_timed': (ci, [vp]),
         'zkgpu_synchronize': (ci, [vp]),
@@ -247,6 +249,15 @@ class Evaluator:
 
     def set_lane_group(self, lanes):
         self._ck(self.L.zkgpu_set_lane_group(self.h, lanes))
+
+    def set_option(self, key, value):
+        self._ck(self.L.zkgpu_set_option(self.h, key.encode(), value.encode()))
+
+    def uses_lds_path(self):
+        r = self.L.zkgpu_uses_lds_path(self.h)
+        if r < 0:
+            self._ck(1)
+        return bool(r)
 
     def replay(self):
         self._ck(self.L.zkgpu_replay(self.h))

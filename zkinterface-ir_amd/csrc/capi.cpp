@@ -22,6 +22,8 @@ struct zkgpu_session {
   bool retain_all = false;
   uint32_t declared_inst = 0, declared_wit = 0;
   uint32_t lane_group = 0;
+  int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
+  size_t n_pinned = 0;
   std::string last_error;
   std::vector<uint32_t> first_fail, flags;
   std::vector<uint32_t> value_op_index;  // k-th value-returning call -> tape index
@@ -57,6 +59,8 @@ void need_engine(zkgpu_session* s) {
   if (!s->finalized) throw std::runtime_error("zkgpu_finalize() has not been called");
   if (!s->engine) {
     std::unique_ptr<Engine> e(new Engine());
+    e->set_bool_path(s->bool_path);
+    e->set_writeback(s->n_pinned != 0);
     e->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
     e->set_lane_group(s->lane_group);
     s->engine = std::move(e);
@@ -251,6 +255,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     ScheduleOptions opt;
     opt.retain_all = retain_all != 0;
     s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
+    s->n_pinned = opt.pinned.size();
     s->sched = build_schedule(s->backend.tape(), s->backend.field(), opt);
     s->retain_all = opt.retain_all;
     const Tape& t = s->backend.tape();
@@ -342,6 +347,28 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes) {
     s->lane_group = lanes;
     if (s->engine) s->engine->set_lane_group(lanes);
   });
+}
+
+int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
+  return guarded(s, [&] {
+    const std::string k = key ? key : "", v = value ? value : "";
+    if (k == "bool_path") {
+      if (v == "auto") s->bool_path = 0;
+      else if (v == "hbm") s->bool_path = 1;
+      else if (v == "lds") s->bool_path = 2;
+      else throw std::runtime_error("bool_path must be auto, hbm or lds");
+      if (s->engine) s->engine.reset();  // re-created with the new choice on the next replay call
+    } else {
+      throw std::runtime_error("unknown option " + k);
+    }
+  });
+}
+
+int zkgpu_uses_lds_path(zkgpu_session* s) {
+  if (!s) return -1;
+  int r = 0;
+  if (guarded(s, [&] { need_engine(s); r = s->engine->uses_lds_path() ? 1 : 0; }) != 0) return -1;
+  return r;
 }
 
 int zkgpu_replay(zkgpu_session* s) {

@@ -96,6 +96,97 @@ __global__ __launch_bounds__(256) void bool_replay_kernel(const BoolReplayArgs a
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-resident GF(2) replay.  After liveness analysis a Boolean relation keeps
+// few wires alive at once (C4: 30,426 slots).  With 32 witnesses per 32-bit
+// word that is < 160 KiB, i.e. the *whole wire table* of a 32-witness slice
+// fits in one CU's LDS.  One 1024-thread workgroup owns a slice and walks the
+// entire program: the ops of a level are spread over the threads, levels are
+// separated by a workgroup barrier, and no wire value ever travels to HBM.
+// The only streamed data is the program itself (8 bytes per op, identical for
+// every workgroup, so it is served from L2).
+struct LdsOp {  // 8-byte program entry; wide fields are split over the halves that the kind leaves unused
+  unsigned short dst, a, b, kind;
+};
+
+struct BoolLdsArgs {
+  const LdsOp* ops;
+  const u32* launches;      // {first, count, ops_per_wave, sequential} per launch
+  u32 n_launches;
+  u32 n_slots;
+  u32 batch;
+  u32 n_cols;               // 32-witness slices in the batch
+  u32 total_words64;        // 64 * lane blocks (layout of the packed inputs)
+  const u32* consts;
+  const u32* packed_inst;   // u32 view of packed[position][word64]
+  const u32* packed_wit;
+  u32* first_fail;
+  u64* table;               // HBM table (bool_replay_kernel layout) for the optional write-back
+  u32 writeback;
+};
+
+__device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, const BoolLdsArgs& args, u32 col,
+                                         u32 valid_mask) {
+  u32 r;
+  switch (op.kind) {
+    case OP_XOR: r = T[op.a] ^ T[op.b]; break;
+    case OP_AND: r = T[op.a] & T[op.b]; break;
+    case OP_NOT: r = ~T[op.a]; break;
+    case OP_COPY: r = T[op.a]; break;
+    case OP_CONST: r = args.consts[op.a] ? ~0u : 0u; break;
+    case OP_INSTANCE: r = args.packed_inst[(size_t)(op.a | ((u32)op.b << 16)) * (2 * args.total_words64) + col]; break;
+    case OP_WITNESS: r = args.packed_wit[(size_t)(op.a | ((u32)op.b << 16)) * (2 * args.total_words64) + col]; break;
+    case OP_ASSERT: {
+      u32 nz = T[op.a] & valid_mask;
+      const u32 seq = op.dst | ((u32)op.b << 16);
+      while (nz) {
+        const u32 bit = __builtin_ctz(nz);
+        nz &= nz - 1;
+        atomicMin(&args.first_fail[col * 32 + bit], seq);
+      }
+      return;
+    }
+    default: return;
+  }
+  T[op.dst] = r;
+}
+
+__global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) {
+  extern __shared__ __attribute__((aligned(16))) u32 T[];
+  const u32 tid = threadIdx.x;
+  const u32 col = blockIdx.x;
+  const u32 lane0 = col * 32;
+  const u32 valid_mask = lane0 >= args.batch ? 0u
+                         : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
+  for (u32 l = 0; l < args.n_launches; ++l) {
+    const u32 first = args.launches[4 * l], count = args.launches[4 * l + 1], sequential = args.launches[4 * l + 3];
+    const LdsOp* __restrict__ ops = args.ops + first;
+    if (sequential) {
+      if (tid == 0)
+        for (u32 i = 0; i < count; ++i) lds_exec(ops[i], T, args, col, valid_mask);
+    } else {
+      u32 i = tid;
+      // four program entries in flight per thread: the program stream is the only global traffic
+      for (; i + 3 * 1024 < count; i += 4 * 1024) {
+        const LdsOp o0 = ops[i], o1 = ops[i + 1024], o2 = ops[i + 2048], o3 = ops[i + 3072];
+        lds_exec(o0, T, args, col, valid_mask);
+        lds_exec(o1, T, args, col, valid_mask);
+        lds_exec(o2, T, args, col, valid_mask);
+        lds_exec(o3, T, args, col, valid_mask);
+      }
+      for (; i < count; i += 1024) lds_exec(ops[i], T, args, col, valid_mask);
+    }
+    __syncthreads();
+  }
+  if (args.writeback) {
+    // table[lane_block][slot][word64] as u32 halves: col -> (lane block, word64, half)
+    const u32 lb = col / 128, w64 = (col % 128) / 2, half = col % 2;
+    u32* out = reinterpret_cast<u32*>(args.table);
+    for (u32 s = tid; s < args.n_slots; s += 1024)
+      out[(((size_t)lb * args.n_slots + s) * 64 + w64) * 2 + half] = T[s];
+  }
+}
+
 // out[lane][k] = bit of slot slots[k] (one byte per value)
 __global__ __launch_bounds__(64) void bool_dump_slots_kernel(const u64* __restrict__ table, u32 n_slots,
                                                              const u32* __restrict__ slots, u32 n_dump, u32 batch,

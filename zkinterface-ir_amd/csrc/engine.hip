@@ -62,6 +62,8 @@ Engine::~Engine() {
   dfree(d_ops_);
   dfree(d_consts_);
   dfree(d_counts_);
+  dfree(d_lds_ops_);
+  dfree(d_launches_);
   for (void* e : launch_events_) (void)hipEventDestroy((hipEvent_t)e);
   if (ev_begin_) (void)hipEventDestroy((hipEvent_t)ev_begin_);
   if (ev_end_) (void)hipEventDestroy((hipEvent_t)ev_end_);
@@ -84,6 +86,8 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   free_batch();
   dfree(d_ops_);
   dfree(d_consts_);
+  dfree(d_lds_ops_);
+  dfree(d_launches_);
   sched_ = s;
   boolean_ = s.boolean_path;
   nwords_ = f.nwords;
@@ -109,6 +113,52 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   HIP_OK(hipMemset(d_consts_, 0, cbytes));
   if (!s.const_words.empty())
     HIP_OK(hipMemcpy(d_consts_, s.const_words.data(), s.const_words.size() * 4, hipMemcpyHostToDevice));
+  // GF(2): if every live wire of a 32-witness slice fits in one CU's LDS, run LDS-resident
+  constexpr uint32_t kLdsBytes = 160 * 1024;
+  lds_path_ = false;
+  if (boolean_ && bool_path_ != 1) {
+    const bool fits = (uint64_t)s.n_slots * 4 + 64 <= kLdsBytes && s.n_slots <= 0xFFFF;
+    if (fits) {
+      std::vector<zkgpu::LdsOp> lo(s.ops.size());
+      for (size_t i = 0; i < s.ops.size(); ++i) {
+        const DevOp& d = s.ops[i];
+        zkgpu::LdsOp o;
+        o.kind = (unsigned short)d.kind;
+        o.dst = (unsigned short)d.dst;
+        o.a = (unsigned short)d.a;
+        o.b = (unsigned short)d.b;
+        if (d.kind == zkgpu::OP_INSTANCE || d.kind == zkgpu::OP_WITNESS) {  // 32-bit position in a | b << 16
+          o.a = (unsigned short)(d.a & 0xFFFF);
+          o.b = (unsigned short)(d.a >> 16);
+        } else if (d.kind == zkgpu::OP_ASSERT) {                            // 32-bit sequence in dst | b << 16
+          o.dst = (unsigned short)(d.b & 0xFFFF);
+          o.b = (unsigned short)(d.b >> 16);
+        } else if (d.kind == zkgpu::OP_CONST && d.a > 0xFFFF) {
+          throw std::runtime_error("Engine: too many constants for the LDS program encoding");
+        }
+        lo[i] = o;
+      }
+      std::vector<uint32_t> ln(4 * s.launches.size());
+      for (size_t i = 0; i < s.launches.size(); ++i) {
+        ln[4 * i] = s.launches[i].first;
+        ln[4 * i + 1] = s.launches[i].count;
+        ln[4 * i + 2] = s.launches[i].ops_per_wave;
+        ln[4 * i + 3] = s.launches[i].sequential ? 1 : 0;
+      }
+      HIP_OK(hipMalloc(&d_lds_ops_, std::max<size_t>(lo.size() * sizeof(zkgpu::LdsOp), 64)));
+      if (!lo.empty()) HIP_OK(hipMemcpy(d_lds_ops_, lo.data(), lo.size() * sizeof(zkgpu::LdsOp), hipMemcpyHostToDevice));
+      HIP_OK(hipMalloc(&d_launches_, std::max<size_t>(ln.size() * 4, 64)));
+      if (!ln.empty()) HIP_OK(hipMemcpy(d_launches_, ln.data(), ln.size() * 4, hipMemcpyHostToDevice));
+      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&zkgpu::bool_lds_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+      lds_path_ = true;
+    } else if (bool_path_ == 2) {
+      throw std::runtime_error("Engine: the relation keeps " + std::to_string(s.n_slots) +
+                               " wires alive; that does not fit the LDS-resident GF(2) kernel");
+    }
+  }
+  // values must reach the HBM table when somebody can still ask for them
+  lds_writeback_ = s.retain_all;
   loaded_ = true;
 }
 
@@ -239,10 +289,29 @@ void Engine::replay(bool time_each_launch) {
       zkgpu::pack_inputs_kernel<<<dim3((words + 3) / 4, (n_wit_ + 255) / 256), 256, 0, st>>>(
           (const uint8_t*)d_wit_, n_wit_, batch_, words, (zkgpu::u64*)d_packed_wit_, (zkgpu::u32*)d_flags_);
   }
+  if (lds_path_) {
+    zkgpu::BoolLdsArgs a;
+    memset(&a, 0, sizeof a);
+    a.ops = (const zkgpu::LdsOp*)d_lds_ops_;
+    a.launches = (const zkgpu::u32*)d_launches_;
+    a.n_launches = (uint32_t)sched_.launches.size();
+    a.n_slots = sched_.n_slots;
+    a.batch = batch_;
+    a.n_cols = (batch_ + 31) / 32;
+    a.total_words64 = lane_blocks_ * 64;
+    a.consts = (const zkgpu::u32*)d_consts_;
+    a.packed_inst = (const zkgpu::u32*)d_packed_inst_;
+    a.packed_wit = (const zkgpu::u32*)d_packed_wit_;
+    a.first_fail = (zkgpu::u32*)d_first_fail_;
+    a.table = (zkgpu::u64*)d_table_;
+    a.writeback = (lds_writeback_ || force_writeback_) ? 1 : 0;
+    const size_t lds_bytes = ((size_t)sched_.n_slots * 4 + 15) / 16 * 16;
+    zkgpu::bool_lds_kernel<<<a.n_cols, 1024, lds_bytes, st>>>(a);
+  }
   uint32_t group_blocks = lane_blocks_;
   if (lane_group_) group_blocks = std::max<uint32_t>(1, std::min(lane_blocks_, lane_group_ / lanes_per_block_));
   if (time_each_launch) group_blocks = lane_blocks_;  // per-launch events describe whole-batch launches
-  for (uint32_t lb0 = 0; lb0 < lane_blocks_; lb0 += group_blocks)
+  for (uint32_t lb0 = 0; lb0 < lane_blocks_ && !lds_path_; lb0 += group_blocks)
     launch_range(lb0, std::min(group_blocks, lane_blocks_ - lb0), time_each_launch);
   zkgpu::verdict_kernel<<<(batch_ + 255) / 256, 256, 0, st>>>((const zkgpu::u32*)d_first_fail_,
                                                               (const zkgpu::u32*)d_flags_, batch_,
@@ -250,7 +319,7 @@ void Engine::replay(bool time_each_launch) {
   HIP_OK(hipEventRecord((hipEvent_t)ev_end_, st));
   HIP_OK(hipGetLastError());
   timings_.clear();
-  if (time_each_launch) {
+  if (time_each_launch && !lds_path_) {
     HIP_OK(hipStreamSynchronize(st));
     for (size_t li = 0; li < sched_.launches.size(); ++li) {
       LaunchTiming t;

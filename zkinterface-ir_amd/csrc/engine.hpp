@@ -36,6 +36,9 @@ class Engine {
   // Limit how many lanes are replayed together (0 = all): lane groups run one
   // after the other so that a group's live wires stay in the 256 MiB Infinity Cache.
   void set_lane_group(uint32_t lanes) { lane_group_ = lanes; }
+  // GF(2): 0 = pick automatically, 1 = force the HBM-table kernel, 2 = require the LDS-resident kernel
+  void set_bool_path(int mode) { bool_path_ = mode; }
+  bool uses_lds_path() const { return lds_path_; }
 
   void replay(bool time_each_launch = false);  // asynchronous on the engine's stream
   void synchronize();
@@ -81,6 +84,16 @@ class Engine {
   const void* d_wit_ = nullptr;
   void* d_packed_inst_ = nullptr;  // GF(2) path
   void* d_packed_wit_ = nullptr;
+  void* d_lds_ops_ = nullptr;       // 8-byte program for the LDS-resident GF(2) kernel
+  void* d_launches_ = nullptr;
+  int bool_path_ = 0;
+  bool lds_path_ = false;
+  bool lds_writeback_ = false;
+  bool force_writeback_ = false;
+ public:
+  // pinned wires (Evaluator::get) need the LDS-resident values written back to HBM
+  void set_writeback(bool on) { force_writeback_ = on; }
+ private:
   unsigned char field_params_[128];  // zkgpu::FieldParams, opaque here
 };
 

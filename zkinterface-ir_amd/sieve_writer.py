@@ -330,11 +330,26 @@ def _binary_gate_block():
     return blob, holes, tag_off, d_off
 
 
+def _unary_gate_block():
+    """Directive -> Gate{output,input} (GateNot / GateCopy layout) as a self-contained block."""
+    b = Builder()
+    o = b.table([(4, 'u64', 0x1111111111111111)])
+    i = b.table([(4, 'u64', 0x2222222222222222)])
+    t = b.table([(4, 'off', o), (6, 'off', i)])
+    d = b.table([(4, 'u8', 0x7f), (6, 'off', t)])
+    b._align(8, 0)
+    blob = b''.join(reversed(b.chunks))
+    holes = [blob.index(struct.pack('<Q', v)) for v in (0x1111111111111111, 0x2222222222222222)]
+    assert blob.count(b'\x7f') == 1
+    return blob, holes, blob.index(b'\x7f'), len(blob) - d
+
+
 def write_relation_segments(modulus, gateset, features, segments, functions=None, degree=1):
     """Relation message whose directives are the concatenation of `segments`:
       ('gates', [gate tuples])                      -- any gate, built one by one
       ('bulk', tags, outs, lefts, rights)           -- numpy arrays of binary gates
                                                        (tags = DirectiveSet numbers 4 add, 5 mul, 8 and, 9 xor)
+      ('bulk1', tags, outs, ins)                    -- numpy arrays of unary gates (3 copy, 10 not)
     """
     blob, holes, tag_off, d_off = _binary_gate_block()
     bs = len(blob)
@@ -356,6 +371,18 @@ def write_relation_segments(modulus, gateset, features, segments, functions=None
             b._push(arr.tobytes())
             # block i starts at end offset size - i*bs; its Directive table sits d_off bytes in
             parts.append(b.size - np.arange(n, dtype=np.int64) * bs - d_off)
+        elif seg[0] == 'bulk1':
+            _, tags, outs, ins = seg
+            ublob, uholes, utag, ud_off = _unary_gate_block()
+            ubs = len(ublob)
+            n = len(tags)
+            arr = np.tile(np.frombuffer(ublob, dtype=np.uint8), n).reshape(n, ubs)
+            for h, vals in zip(uholes, (outs, ins)):
+                arr[:, h:h + 8] = np.ascontiguousarray(np.asarray(vals, dtype='<u8')).view(np.uint8).reshape(n, 8)
+            arr[:, utag] = np.asarray(tags, dtype=np.uint8)
+            b._align(8, 0)
+            b._push(arr.tobytes())
+            parts.append(b.size - np.arange(n, dtype=np.int64) * ubs - ud_off)
         else:
             raise ValueError(seg[0])
     offs = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)

@@ -167,5 +167,90 @@ class ArithLayered:
         return [self.D * self.W + t for t in range(self.n_out)]
 
 
+class BoolLayered:
+    """The C4 workload: GF(2), gateset `boolean`, W x D layered And/Xor/Not circuit
+    (45 / 45 / 10 %), n_instance0 instance + (W - n_instance0) witness bits, n_out outputs compared by
+    {Instance, Xor, AssertZero}.  One byte per input value."""
+
+    def __init__(self, W=16384, D=640, n_instance0=1024, n_out=64, seed=0xB001C4):
+        self.W, self.D, self.n_instance0, self.n_out, self.seed, self.p = W, D, n_instance0, n_out, seed, 2
+        self.mod_le = bytes([2])
+        self.width = 1
+        self.n_instance = n_instance0 + n_out
+        self.n_witness = W - n_instance0
+        self.n_gates = W * D
+        layer = np.arange(1, D + 1, dtype=np.uint64)[:, None]
+        j = np.arange(W, dtype=np.uint64)[None, :]
+        with np.errstate(over='ignore'):
+            h = splitmix64(np.uint64(seed) ^ ((layer << np.uint64(32)) + j))
+            h2 = splitmix64(h)
+        r = (h >> np.uint64(8)) % np.uint64(100)
+        self.kind = np.where(r < 45, 8, np.where(r < 90, 9, 10)).astype(np.uint8)  # and / xor / not
+        self.src_a = (h2 % np.uint64(W)).astype(np.uint32)
+        self.src_b = ((h2 >> np.uint64(32)) % np.uint64(W)).astype(np.uint32)
+
+    def _segments(self, with_epilogue=True, free_last=True):
+        W, D = self.W, self.D
+        inputs = [('instance', k) for k in range(self.n_instance0)] + [('witness', k) for k in range(self.n_instance0, W)]
+        segs = [('gates', inputs, len(inputs))]
+        for l in range(1, D + 1):
+            base_prev, base = (l - 1) * W, l * W
+            k = self.kind[l - 1]
+            outs = np.arange(base, base + W, dtype=np.uint64)
+            a = self.src_a[l - 1].astype(np.uint64) + np.uint64(base_prev)
+            b = self.src_b[l - 1].astype(np.uint64) + np.uint64(base_prev)
+            binary = k != 10
+            if binary.any():
+                segs.append(('bulk', k[binary], outs[binary], a[binary], b[binary], int(binary.sum())))
+            if (~binary).any():
+                segs.append(('bulk1', k[~binary], outs[~binary], a[~binary], int((~binary).sum())))
+            segs.append(('gates', [('free', base_prev, base_prev + W - 1)], 1))
+        if with_epilogue:
+            e = (D + 1) * W
+            ep = []
+            for t in range(self.n_out):
+                w0, w1 = e + 2 * t, e + 2 * t + 1
+                ep += [('instance', w0), ('xor', w1, D * W + t, w0), ('assert_zero', w1)]
+            ep.append(('free', e, e + 2 * self.n_out - 1))
+            segs.append(('gates', ep, len(ep)))
+        if free_last:
+            segs.append(('gates', [('free', D * W, D * W + W - 1)], 1))
+        return segs
+
+    def relation_messages(self, with_epilogue=True, free_last=True):
+        msgs, cur, cur_n = [], [], 0
+        for seg in self._segments(with_epilogue, free_last):
+            n = seg[-1]
+            if cur and cur_n + n > MAX_GATES_PER_MESSAGE:
+                msgs.append(cur)
+                cur, cur_n = [], 0
+            cur.append(seg[:-1])
+            cur_n += n
+        if cur:
+            msgs.append(cur)
+        return [write_relation_segments(self.mod_le, 'boolean', 'simple', m) for m in msgs]
+
+    def inputs(self, batch, lane_offset=0):
+        idx = (np.arange(batch * self.W, dtype=np.uint64) + np.uint64(lane_offset * self.W)).reshape(batch, self.W)
+        with np.errstate(over='ignore'):
+            bits = (splitmix64(np.uint64(self.seed + 77) + idx) & np.uint64(1)).astype(np.uint8)
+        inst = np.zeros((batch, self.n_instance, 1), dtype=np.uint8)
+        inst[:, :self.n_instance0, 0] = bits[:, :self.n_instance0]
+        wit = np.ascontiguousarray(bits[:, self.n_instance0:, None])
+        return inst, wit
+
+    def set_expected_outputs(self, inst, outputs, lane_offset=0, corrupt_every=97):
+        """outputs: [batch][n_out] uint8 bits"""
+        batch = inst.shape[0]
+        inst[:, self.n_instance0:, 0] = np.asarray(outputs, dtype=np.uint8).reshape(batch, self.n_out)
+        bad = [i for i in range(batch) if corrupt_every and (i + lane_offset) % corrupt_every == 0]
+        for i in bad:
+            inst[i, self.n_instance0, 0] ^= 1
+        return len(bad)
+
+    def output_wire_ids(self):
+        return [self.D * self.W + t for t in range(self.n_out)]
+
+
 def expected_satisfied(batch, lane_offset=0, corrupt_every=97):
     return batch - sum(1 for i in range(batch) if (i + lane_offset) % corrupt_every == 0)
