@@ -29,6 +29,10 @@ BYTES_PER_OP = {1: 96, 2: 96, 10: 96, 11: 96,       # add, mul, and, xor: 2 x 32
                 6: 32,                              # constant: 32 B write
                 7: 64, 8: 64,                       # instance / witness: 32 B read + 32 B write
                 9: 32}                              # assert_zero: 32 B read
+# GF(2), bit-packed wires: one bit per operand / result
+BYTES_PER_OP_BOOL = {1: 0.375, 2: 0.375, 10: 0.375, 11: 0.375, 3: 0.25, 4: 0.25, 5: 0.25, 12: 0.25, 6: 0.125,
+                     7: 1.125, 8: 1.125,            # one input byte read + one bit written
+                     9: 0.125}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
 
@@ -53,11 +57,13 @@ class _DevU64x2:
         self.__cuda_array_interface__ = {'shape': (2,), 'typestr': '<i8', 'data': (int(ptr), False), 'version': 2}
 
 
-def build_session(zk, wl, batch, lane_offset, lane_group):
+def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None):
     """probe pass for the expected outputs, then the real session with resident inputs"""
     t0 = time.time()
     inst, wit = wl.inputs(batch, lane_offset)
     probe = zk.Evaluator()
+    if bool_path:
+        probe.set_option('bool_path', bool_path)
     probe.declare_inputs(wl.n_instance0, wl.n_witness)
     for m in wl.relation_messages(with_epilogue=False, free_last=False):
         probe.ingest_message(m)
@@ -70,12 +76,16 @@ def build_session(zk, wl, batch, lane_offset, lane_group):
         vals = probe.get(wid, batch)
         outs[:, t] = np.frombuffer(b''.join(v.to_bytes(wl.width, 'little') for v in vals),
                                    dtype=np.uint8).reshape(batch, wl.width)
+    if wl.p == 2:
+        outs = outs[:, :, 0]
     probe.close()
     n_bad = wl.set_expected_outputs(inst, outs, lane_offset)
     t1 = time.time()
     msgs = wl.relation_messages()
     t2 = time.time()
     ev = zk.Evaluator()
+    if bool_path:
+        ev.set_option('bool_path', bool_path)
     ev.declare_inputs(wl.n_instance, wl.n_witness)
     for m in msgs:
         ev.ingest_message(m)
@@ -107,8 +117,8 @@ def cpu_baseline(wl, msgs, inst, wit, gates):
     ok, secs, ops = oracle_lib.eval_batch(rel, wl.mod_le, inst[:lanes].tobytes(), wl.n_instance,
                                           wit[:lanes].tobytes(), wl.n_witness, wl.width, lanes, threads)
     return {'value': gates * lanes / secs, 'unit': 'gate-ops/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d witnesses of the same 2^20-gate relation, one reference-style Evaluator run per witness, '
-                      '%d threads, %.1f s wall (single witness: %.2f s)' % (lanes, threads, secs, per_lane),
+            'sample': '%d witnesses of the same %d-gate relation, one reference-style Evaluator run per witness, '
+                      '%d threads, %.1f s wall (single witness: %.2f s)' % (lanes, gates, threads, secs, per_lane),
             'satisfied_in_sample': int(sum(ok))}
 
 
@@ -117,9 +127,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch-per-gpu', type=int, default=1024)
-    ap.add_argument('--width', type=int, default=4096)
-    ap.add_argument('--depth', type=int, default=256)
+    ap.add_argument('--workload', choices=['c2', 'c4'], default='c2',
+                    help='c2 = BASELINE configs[1] (headline); c4 = GF(2) 10M-gate relation, batch 4096')
+    ap.add_argument('--batch-per-gpu', type=int, default=0)
+    ap.add_argument('--width', type=int, default=0)
+    ap.add_argument('--depth', type=int, default=0)
+    ap.add_argument('--bool-path', choices=['auto', 'hbm', 'lds'], default='auto')
     ap.add_argument('--lane-group', type=int, default=0, help='replay lane groups of this size one after the other')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -146,15 +159,23 @@ def main():
     zk = entry.load_package()
     from zkinterface_ir_amd import workloads
 
-    wl = workloads.ArithLayered(W=args.width, D=args.depth)
-    batch = args.batch_per_gpu
+    if args.workload == 'c2':
+        wl = workloads.ArithLayered(W=args.width or 4096, D=args.depth or 256)
+        batch = args.batch_per_gpu or 1024
+        bytes_table, bool_path = BYTES_PER_OP, None
+    else:
+        wl = workloads.BoolLayered(W=args.width or 16384, D=args.depth or 640,
+                                   wiring=os.environ.get('ZKI_C4_WIRING', 'random'))
+        batch = args.batch_per_gpu or 4096
+        bytes_table, bool_path = BYTES_PER_OP_BOOL, args.bool_path
     lane_offset = rank * batch
-    ev, inst, wit, n_bad, msgs, host = build_session(zk, wl, batch, lane_offset, args.lane_group)
+    ev, inst, wit, n_bad, msgs, host = build_session(zk, wl, batch, lane_offset, args.lane_group, bool_path)
     gates = wl.n_gates
     kinds, _, _ = ev.tape()
-    algo_bytes_per_lane = int(sum(BYTES_PER_OP.get(int(k), 0) * int(c) for k, c in zip(*np.unique(kinds, return_counts=True))))
+    algo_bytes_per_lane = float(sum(bytes_table.get(int(k), 0) * int(c) for k, c in zip(*np.unique(kinds, return_counts=True))))
     info = ev.schedule_info()
-    wide_launches = info['launches'] - info['sequential_launches']
+    lds = args.workload == 'c4' and ev.uses_lds_path()
+    wide_launches = 1 if lds else info['launches'] - info['sequential_launches']
 
     counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if world > 1 else None
 
@@ -199,14 +220,25 @@ def main():
         kernel_ms = float(np.mean(ev_ms)) / max(wide_launches, 1)
         bytes_per_launch = algo_bytes_per_lane * batch / max(wide_launches, 1)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(wl.W, batch, wl.width)
+        traffic, traffic_src = pmc_traffic(wl.W, batch, wl.width) if args.workload == 'c2' else (None, None)
+        if args.workload == 'c2':
+            metric = 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses'
+            dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
+            wl_name = ('BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
+                       'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
+            kernel = 'replay_kernel<8,false>'
+        else:
+            metric = 'gate-ops/sec (whole node), GF(2), 10M-gate And/Xor/Not relation, bit-packed batched witnesses'
+            dtype = 'u1 (GF(2), %d witnesses per word)' % (32 if lds else 64)
+            wl_name = ('BASELINE configs[3]: GF(2), %d-gate And/Xor/Not relation (W=%d x D=%d), witness batch=%d '
+                       'per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
+            kernel = 'bool_lds_kernel (wire table resident in LDS)' if lds else 'bool_replay_kernel'
         out = {
-            'metric': 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses',
+            'metric': metric,
             'value': value, 'unit': 'gate-ops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'u64x4 (GF(p) Montgomery limbs, exact integer)', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
-                                   'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world),
+            'dtype': dtype, 'data': 'synthetic',
+            'config': {'workload': wl_name,
                        'relation_messages': host['messages'], 'relation_bytes': host['relation_bytes'],
                        'backend_ops_per_witness': int(len(kinds)), 'levels': info['levels'],
                        'launches_per_step': info['launches'], 'wire_table_slots': info['slots'],
@@ -215,7 +247,7 @@ def main():
                        'satisfied': total[0], 'failed': total[1], 'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'replay_kernel<8,false>', 'launches_per_step': wide_launches,
+                         'kernel': kernel, 'launches_per_step': wide_launches,
                          'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch},
         }
         if not args.no_cpu_baseline:

@@ -109,11 +109,19 @@ struct LdsOp {  // 8-byte program entry; wide fields are split over the halves t
   unsigned short dst, a, b, kind;
 };
 
+// The program is cut into kind-uniform chunks of at most kLdsRows rows of 2048 ops (the host sorts a
+// level by kind and pads every kind to a multiple of 2048 with ops writing a scratch slot), so the
+// inner loop carries no per-op decode: chunk = {first op, rows, kind | barrier_after << 8 | sequential << 9, -}.
+// A thread fetches two consecutive ops per row with one 16-byte load (8-byte loads stream at ~0.6x
+// the 16-byte rate, MI355X_MICROARCH.md).
+constexpr int kLdsRows = 4;
+constexpr int kLdsRowOps = 2048;
+
 struct BoolLdsArgs {
   const LdsOp* ops;
-  const u32* launches;      // {first, count, ops_per_wave, sequential} per launch
-  u32 n_launches;
-  u32 n_slots;
+  const u32* chunks;
+  u32 n_chunks;
+  u32 n_slots;              // including the scratch slot
   u32 batch;
   u32 n_cols;               // 32-witness slices in the batch
   u32 total_words64;        // 64 * lane blocks (layout of the packed inputs)
@@ -151,6 +159,82 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
   T[op.dst] = r;
 }
 
+// All ops of a chunk belong to one level, hence are mutually independent: every operand read is
+// issued before the first result is written, so LDS latency is paid once per chunk, not per op.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: usable as an asm operand
+
+template <u32 KIND, bool FULL>
+__device__ __forceinline__ void lds_rows(const u32x4 (&raw)[kLdsRows], u32 rows, u32* __restrict__ T) {
+  u32 x[2 * kLdsRows], y[2 * kLdsRows];
+#pragma unroll
+  for (int j = 0; j < kLdsRows; ++j) {
+    if (FULL || (u32)j < rows) {
+      x[2 * j] = T[raw[j].x >> 16];
+      x[2 * j + 1] = T[raw[j].z >> 16];
+      if (KIND == OP_XOR || KIND == OP_AND) {
+        y[2 * j] = T[raw[j].y & 0xFFFF];
+        y[2 * j + 1] = T[raw[j].w & 0xFFFF];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kLdsRows; ++j) {
+    if (FULL || (u32)j < rows) {
+      u32 r0, r1;
+      if (KIND == OP_XOR) { r0 = x[2 * j] ^ y[2 * j]; r1 = x[2 * j + 1] ^ y[2 * j + 1]; }
+      else if (KIND == OP_AND) { r0 = x[2 * j] & y[2 * j]; r1 = x[2 * j + 1] & y[2 * j + 1]; }
+      else if (KIND == OP_NOT) { r0 = ~x[2 * j]; r1 = ~x[2 * j + 1]; }
+      else { r0 = x[2 * j]; r1 = x[2 * j + 1]; }
+      T[raw[j].x & 0xFFFF] = r0;
+      T[raw[j].z & 0xFFFF] = r1;
+    }
+  }
+}
+
+// wave-uniform table read on the scalar path (s_load): a vector load here would sit in vmcnt and
+// force the program prefetch to drain
+__device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* q = (cu32*)(unsigned long long)table;
+  return q[__builtin_amdgcn_readfirstlane(idx)];
+}
+
+// workgroup barrier for LDS data only: waits for this wave's LDS traffic, not for the global loads of
+// the program prefetch (a plain __syncthreads() would drain them: vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Program-stream loads hidden from hipcc's s_waitcnt bookkeeping (cdna_hip_programming.md 5.7): the
+// compiler would drain vmcnt(0) at every join of the kind/rows branches; here the waits are counted by
+// hand.  The destination registers are only consumed behind lds_wait_vm<N>, which names them "+v".
+__device__ __forceinline__ void lds_gload16(u32x4& dst, const u32x4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_vm(u32x4 (&b)[kLdsRows]) {
+  static_assert(kLdsRows == 4, "operand list below names 4 rows");
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void lds_simple_chunk(const u32x4 (&buf)[kLdsRows], u32 rows, u32 flags,
+                                                 u32* __restrict__ T) {
+  const u32 kind = flags & 0xFF;
+  if (rows == kLdsRows) {
+    if (kind == OP_XOR) lds_rows<OP_XOR, true>(buf, rows, T);
+    else if (kind == OP_AND) lds_rows<OP_AND, true>(buf, rows, T);
+    else if (kind == OP_NOT) lds_rows<OP_NOT, true>(buf, rows, T);
+    else lds_rows<OP_COPY, true>(buf, rows, T);
+  } else {
+    if (kind == OP_XOR) lds_rows<OP_XOR, false>(buf, rows, T);
+    else if (kind == OP_AND) lds_rows<OP_AND, false>(buf, rows, T);
+    else if (kind == OP_NOT) lds_rows<OP_NOT, false>(buf, rows, T);
+    else lds_rows<OP_COPY, false>(buf, rows, T);
+  }
+  if ((flags >> 8) & 1) lds_barrier();
+}
+
 __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) {
   extern __shared__ __attribute__((aligned(16))) u32 T[];
   const u32 tid = threadIdx.x;
@@ -158,32 +242,63 @@ __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) 
   const u32 lane0 = col * 32;
   const u32 valid_mask = lane0 >= args.batch ? 0u
                          : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
-  for (u32 l = 0; l < args.n_launches; ++l) {
-    const u32 first = args.launches[4 * l], count = args.launches[4 * l + 1], sequential = args.launches[4 * l + 3];
-    const LdsOp* __restrict__ ops = args.ops + first;
-    if (sequential) {
-      if (tid == 0)
-        for (u32 i = 0; i < count; ++i) lds_exec(ops[i], T, args, col, valid_mask);
-    } else {
-      u32 i = tid;
-      // four program entries in flight per thread: the program stream is the only global traffic
-      for (; i + 3 * 1024 < count; i += 4 * 1024) {
-        const LdsOp o0 = ops[i], o1 = ops[i + 1024], o2 = ops[i + 2048], o3 = ops[i + 3072];
-        lds_exec(o0, T, args, col, valid_mask);
-        lds_exec(o1, T, args, col, valid_mask);
-        lds_exec(o2, T, args, col, valid_mask);
-        lds_exec(o3, T, args, col, valid_mask);
+  const u32x4* __restrict__ prog = reinterpret_cast<const u32x4*>(args.ops) + tid;
+  u32 c = 0;
+  while (c < args.n_chunks) {
+    c = __builtin_amdgcn_readfirstlane(c);
+    const u32 first = lds_sload(args.chunks, 4 * c), rows = lds_sload(args.chunks, 4 * c + 1),
+              flags = lds_sload(args.chunks, 4 * c + 2), run = lds_sload(args.chunks, 4 * c + 3);
+    if (run == 0) {
+      // generic chunk: inputs, constants, asserts, NOP padding, or a sequential (narrow-level) segment
+      if ((flags >> 9) & 1) {
+        if (tid == 0)
+          for (u32 i = 0; i < rows; ++i) lds_exec(args.ops[first + i], T, args, col, valid_mask);
+      } else {
+        for (u32 j = 0; j < 2 * rows; ++j) lds_exec(args.ops[first + j * 1024 + tid], T, args, col, valid_mask);
       }
-      for (; i < count; i += 1024) lds_exec(ops[i], T, args, col, valid_mask);
+      if ((flags >> 8) & 1) __syncthreads();
+      ++c;
+      continue;
     }
+    // A run of `run` simple chunks (xor / and / not / copy).  The program stream is the only global
+    // traffic and all waves want it at the same moment (levels are barrier-synchronised), so it is
+    // latency-limited: three chunks (3 x 64 KiB per CU) stay in flight.  Fetches are unconditional
+    // (index clamped to the run), the body holds no other vector-memory op, and the barrier does not
+    // drain vmcnt, so the compiler emits counted vmcnt waits.
+    const u32 e = c + run;
+    u32x4 b0[kLdsRows], b1[kLdsRows], b2[kLdsRows];
+    auto fetch = [&](u32x4 (&buf)[kLdsRows], u32 cc) {
+      const u32x4* src = prog + (lds_sload(args.chunks, 4 * min(cc, e - 1)) >> 1);
+#pragma unroll
+      for (int j = 0; j < kLdsRows; ++j) lds_gload16(buf[j], src + j * 1024);
+    };
+    // in flight at every wait: the chunk about to run + the two behind it = 12 loads -> vmcnt(8)
+    fetch(b0, c);
+    fetch(b1, c + 1);
+    for (; c < e; c += 3) {
+      fetch(b2, c + 2);
+      lds_wait_vm<2 * kLdsRows>(b0);
+      lds_simple_chunk(b0, lds_sload(args.chunks, 4 * c + 1), lds_sload(args.chunks, 4 * c + 2), T);
+      fetch(b0, c + 3);
+      lds_wait_vm<2 * kLdsRows>(b1);
+      if (c + 1 < e) lds_simple_chunk(b1, lds_sload(args.chunks, 4 * c + 5), lds_sload(args.chunks, 4 * c + 6), T);
+      fetch(b1, c + 4);
+      lds_wait_vm<2 * kLdsRows>(b2);
+      if (c + 2 < e) lds_simple_chunk(b2, lds_sload(args.chunks, 4 * c + 9), lds_sload(args.chunks, 4 * c + 10), T);
+    }
+    c = e;
+    // drain the clamped over-fetches before their registers can be reused
+    lds_wait_vm<0>(b0);
+    lds_wait_vm<0>(b1);
+    lds_wait_vm<0>(b2);
     __syncthreads();
   }
   if (args.writeback) {
     // table[lane_block][slot][word64] as u32 halves: col -> (lane block, word64, half)
     const u32 lb = col / 128, w64 = (col % 128) / 2, half = col % 2;
     u32* out = reinterpret_cast<u32*>(args.table);
-    for (u32 s = tid; s < args.n_slots; s += 1024)
-      out[(((size_t)lb * args.n_slots + s) * 64 + w64) * 2 + half] = T[s];
+    for (u32 s = tid; s < args.n_slots - 1; s += 1024)
+      out[(((size_t)lb * (args.n_slots - 1) + s) * 64 + w64) * 2 + half] = T[s];
   }
 }
 

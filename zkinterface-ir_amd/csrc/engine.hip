@@ -117,11 +117,11 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   constexpr uint32_t kLdsBytes = 160 * 1024;
   lds_path_ = false;
   if (boolean_ && bool_path_ != 1) {
-    const bool fits = (uint64_t)s.n_slots * 4 + 64 <= kLdsBytes && s.n_slots <= 0xFFFF;
+    const bool fits = ((uint64_t)s.n_slots + 1) * 4 + 64 <= kLdsBytes && s.n_slots < 0xFFFF;
     if (fits) {
-      std::vector<zkgpu::LdsOp> lo(s.ops.size());
-      for (size_t i = 0; i < s.ops.size(); ++i) {
-        const DevOp& d = s.ops[i];
+      // program in 8-byte entries, every non-sequential launch padded with NOPs to a multiple of 1024
+      // ops and cut into chunks of <= kLdsRows rows (device/bool_kernels.hpp)
+      auto encode = [](const DevOp& d) {
         zkgpu::LdsOp o;
         o.kind = (unsigned short)d.kind;
         o.dst = (unsigned short)d.dst;
@@ -136,14 +136,62 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
         } else if (d.kind == zkgpu::OP_CONST && d.a > 0xFFFF) {
           throw std::runtime_error("Engine: too many constants for the LDS program encoding");
         }
-        lo[i] = o;
+        return o;
+      };
+      std::vector<zkgpu::LdsOp> lo;
+      std::vector<uint32_t> ln;
+      lo.reserve(s.ops.size() + 4096 * s.launches.size());
+      const unsigned short scratch = (unsigned short)s.n_slots;  // extra slot: target of the padding ops
+      for (const Launch& L : s.launches) {
+        if (L.sequential) {
+          const uint32_t first = (uint32_t)lo.size();
+          for (uint32_t k = 0; k < L.count; ++k) lo.push_back(encode(s.ops[L.first + k]));
+          ln.insert(ln.end(), {first, L.count, (1u << 9) | (1u << 8), 0u});
+          continue;
+        }
+        // ops of a level arrive sorted by kind (schedule.cpp): one padded run per kind
+        uint32_t k = 0;
+        while (k < L.count) {
+          const uint32_t kind = s.ops[L.first + k].kind;
+          uint32_t e = k;
+          while (e < L.count && s.ops[L.first + e].kind == kind) ++e;
+          if (lo.size() & 1) lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});  // 16-B aligned rows
+          const uint32_t first = (uint32_t)lo.size();
+          for (uint32_t q = k; q < e; ++q) lo.push_back(encode(s.ops[L.first + q]));
+          const bool simple = kind == zkgpu::OP_XOR || kind == zkgpu::OP_AND || kind == zkgpu::OP_NOT || kind == zkgpu::OP_COPY;
+          // padding: simple kinds re-do a harmless op into the scratch slot; others are NOPs
+          zkgpu::LdsOp pad{scratch, 0, 0, (unsigned short)(simple ? kind : (uint32_t)zkgpu::OP_NOP)};
+          while ((lo.size() - first) % zkgpu::kLdsRowOps) lo.push_back(pad);
+          const uint32_t rows = ((uint32_t)lo.size() - first) / zkgpu::kLdsRowOps;
+          const bool last_kind = e >= L.count;
+          for (uint32_t r = 0; r < rows; r += zkgpu::kLdsRows) {
+            const uint32_t n = std::min<uint32_t>(zkgpu::kLdsRows, rows - r);
+            const uint32_t barrier = (last_kind && r + n >= rows) ? 1u : 0u;
+            ln.insert(ln.end(), {first + r * zkgpu::kLdsRowOps, n, kind | (barrier << 8), 0u});
+          }
+          k = e;
+        }
       }
-      std::vector<uint32_t> ln(4 * s.launches.size());
-      for (size_t i = 0; i < s.launches.size(); ++i) {
-        ln[4 * i] = s.launches[i].first;
-        ln[4 * i + 1] = s.launches[i].count;
-        ln[4 * i + 2] = s.launches[i].ops_per_wave;
-        ln[4 * i + 3] = s.launches[i].sequential ? 1 : 0;
+      // chunk field 3: for the first chunk of a run of simple chunks, the run length; 0 = generic chunk
+      {
+        const size_t nc = ln.size() / 4;
+        auto is_simple = [&](size_t c) {
+          const uint32_t f = ln[4 * c + 2], kind = f & 0xFF;
+          return !((f >> 9) & 1) && (kind == zkgpu::OP_XOR || kind == zkgpu::OP_AND || kind == zkgpu::OP_NOT ||
+                                     kind == zkgpu::OP_COPY);
+        };
+        for (size_t c = 0; c < nc;) {
+          if (!is_simple(c)) { ln[4 * c + 3] = 0; ++c; continue; }
+          size_t e = c;
+          while (e < nc && is_simple(e)) ++e;
+          ln[4 * c + 3] = (uint32_t)(e - c);
+          for (size_t q = c + 1; q < e; ++q) ln[4 * q + 3] = 0;
+          c = e;
+        }
+        // rows past a short chunk are fetched (and ignored): keep them inside the allocation
+        for (int k = 0; k < zkgpu::kLdsRows * zkgpu::kLdsRowOps; ++k)
+          lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});
+        n_lds_chunks_ = (uint32_t)nc;
       }
       HIP_OK(hipMalloc(&d_lds_ops_, std::max<size_t>(lo.size() * sizeof(zkgpu::LdsOp), 64)));
       if (!lo.empty()) HIP_OK(hipMemcpy(d_lds_ops_, lo.data(), lo.size() * sizeof(zkgpu::LdsOp), hipMemcpyHostToDevice));
@@ -293,9 +341,9 @@ void Engine::replay(bool time_each_launch) {
     zkgpu::BoolLdsArgs a;
     memset(&a, 0, sizeof a);
     a.ops = (const zkgpu::LdsOp*)d_lds_ops_;
-    a.launches = (const zkgpu::u32*)d_launches_;
-    a.n_launches = (uint32_t)sched_.launches.size();
-    a.n_slots = sched_.n_slots;
+    a.chunks = (const zkgpu::u32*)d_launches_;
+    a.n_chunks = n_lds_chunks_;
+    a.n_slots = sched_.n_slots + 1;  // + scratch slot of the padding ops
     a.batch = batch_;
     a.n_cols = (batch_ + 31) / 32;
     a.total_words64 = lane_blocks_ * 64;
@@ -305,7 +353,7 @@ void Engine::replay(bool time_each_launch) {
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.table = (zkgpu::u64*)d_table_;
     a.writeback = (lds_writeback_ || force_writeback_) ? 1 : 0;
-    const size_t lds_bytes = ((size_t)sched_.n_slots * 4 + 15) / 16 * 16;
+    const size_t lds_bytes = (((size_t)sched_.n_slots + 1) * 4 + 15) / 16 * 16;
     zkgpu::bool_lds_kernel<<<a.n_cols, 1024, lds_bytes, st>>>(a);
   }
   uint32_t group_blocks = lane_blocks_;

@@ -86,6 +86,7 @@ class Engine {
   void* d_packed_wit_ = nullptr;
   void* d_lds_ops_ = nullptr;       // 8-byte program for the LDS-resident GF(2) kernel
   void* d_launches_ = nullptr;
+  uint32_t n_lds_chunks_ = 0;
   int bool_path_ = 0;
   bool lds_path_ = false;
   bool lds_writeback_ = false;

@@ -172,7 +172,7 @@ class BoolLayered:
     (45 / 45 / 10 %), n_instance0 instance + (W - n_instance0) witness bits, n_out outputs compared by
     {Instance, Xor, AssertZero}.  One byte per input value."""
 
-    def __init__(self, W=16384, D=640, n_instance0=1024, n_out=64, seed=0xB001C4):
+    def __init__(self, W=16384, D=640, n_instance0=1024, n_out=64, seed=0xB001C4, wiring='random'):
         self.W, self.D, self.n_instance0, self.n_out, self.seed, self.p = W, D, n_instance0, n_out, seed, 2
         self.mod_le = bytes([2])
         self.width = 1
@@ -188,6 +188,9 @@ class BoolLayered:
         self.kind = np.where(r < 45, 8, np.where(r < 90, 9, 10)).astype(np.uint8)  # and / xor / not
         self.src_a = (h2 % np.uint64(W)).astype(np.uint32)
         self.src_b = ((h2 >> np.uint64(32)) % np.uint64(W)).astype(np.uint32)
+        if wiring == 'identity':  # experiment only: gate j reads wires j and j+1 of the previous layer
+            self.src_a = np.broadcast_to(np.arange(W, dtype=np.uint32), (D, W)).copy()
+            self.src_b = (self.src_a + 1) % W
 
     def _segments(self, with_epilogue=True, free_last=True):
         W, D = self.W, self.D
