@@ -86,6 +86,8 @@ def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None):
     ev = zk.Evaluator()
     if bool_path:
         ev.set_option('bool_path', bool_path)
+    if os.environ.get('ZKI_SORT_BY_OPERAND'):
+        ev.set_option('sort_by_operand', os.environ['ZKI_SORT_BY_OPERAND'])
     ev.declare_inputs(wl.n_instance, wl.n_witness)
     for m in msgs:
         ev.ingest_message(m)

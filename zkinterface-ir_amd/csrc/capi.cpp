@@ -23,6 +23,7 @@ struct zkgpu_session {
   uint32_t declared_inst = 0, declared_wit = 0;
   uint32_t lane_group = 0;
   int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
+  bool sort_by_operand = true;
   size_t n_pinned = 0;
   std::string last_error;
   std::vector<uint32_t> first_fail, flags;
@@ -254,6 +255,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
     ScheduleOptions opt;
     opt.retain_all = retain_all != 0;
+    opt.sort_by_operand = s->sort_by_operand;
     s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
     s->n_pinned = opt.pinned.size();
     s->sched = build_schedule(s->backend.tape(), s->backend.field(), opt);
@@ -358,6 +360,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       else if (v == "lds") s->bool_path = 2;
       else throw std::runtime_error("bool_path must be auto, hbm or lds");
       if (s->engine) s->engine.reset();  // re-created with the new choice on the next replay call
+    } else if (k == "sort_by_operand") {
+      s->sort_by_operand = v != "0";
     } else {
       throw std::runtime_error("unknown option " + k);
     }

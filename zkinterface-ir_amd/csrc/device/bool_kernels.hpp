@@ -30,6 +30,9 @@ struct BoolReplayArgs {
 };
 
 // raw[lane][n_vals] bytes -> packed[pos][word]; flags lanes holding a value > 1.
+// One wave = 64 witnesses x 256 positions.  Each lane reads 16 of its bytes per load (rows are
+// 16-byte aligned when n_vals % 16 == 0), every byte position is turned into a 64-bit word by a
+// wave ballot, and lane b keeps / stores the word of position k + b: one store per 16 positions.
 __global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restrict__ raw, u32 n_vals, u32 batch,
                                                           u32 total_words, u64* __restrict__ packed,
                                                           u32* __restrict__ lane_flags) {
@@ -43,7 +46,23 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restr
   const u32 k1 = min(n_vals, k0 + 256);
   const uint8_t* row = raw + (size_t)lane_g * n_vals;
   bool bad = false;
-  for (u32 k = k0; k < k1; ++k) {
+  u32 k = k0;
+  if ((n_vals & 15) == 0 && ((size_t)raw & 15) == 0) {
+    for (; k + 16 <= k1; k += 16) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (valid) v = *reinterpret_cast<const uint4*>(row + k);
+      const u32 w[4] = {v.x, v.y, v.z, v.w};
+      bad |= ((v.x | v.y | v.z | v.w) & 0xFEFEFEFEu) != 0;
+      u64 mine = 0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        const u64 m = __ballot((w[b >> 2] >> (8 * (b & 3))) & 1);
+        if (lane == (u32)b) mine = m;
+      }
+      if (lane < 16) packed[(size_t)(k + lane) * total_words + word] = mine;
+    }
+  }
+  for (; k < k1; ++k) {
     const uint8_t v = valid ? row[k] : 0;
     bad |= v > 1;
     const u64 m = __ballot(v & 1);

@@ -108,6 +108,21 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
     if (!opt.retain_all && l > 0) {
       for (uint32_t h = expire_head[l - 1]; h != kInf; h = expire_next[h]) free_slots.push_back(s.slot_of[h]);
     }
+    if (opt.sort_by_operand) {
+      // inside a (level, kind) run, order the ops by the slot of their first operand: gates that read
+      // the same wire become neighbours (same workgroup), so the repeat read is an L1/L2 hit
+      uint64_t k = level_start[l];
+      while (k < level_start[l + 1]) {
+        uint64_t e = k;
+        const uint8_t kind = tape.kind[order[k]];
+        while (e < level_start[l + 1] && tape.kind[order[e]] == kind) ++e;
+        if (n_inputs(kind) >= 1 && e - k > 1)
+          std::stable_sort(order.begin() + k, order.begin() + e, [&](uint32_t x, uint32_t y) {
+            return s.slot_of[tape.a[x]] < s.slot_of[tape.a[y]];
+          });
+        k = e;
+      }
+    }
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
       const uint32_t i = order[k];
       if (tape.kind[i] == TK_ASSERT || tape.kind[i] == TK_NOP) continue;

@@ -29,6 +29,7 @@ struct Launch {
 struct ScheduleOptions {
   bool retain_all = false;          // every value keeps its own slot (wire dumps for parity tests)
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
+  bool sort_by_operand = true;      // order a level's ops by first-operand slot (cache locality)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
 };
 
