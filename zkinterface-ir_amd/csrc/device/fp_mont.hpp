@@ -81,9 +81,68 @@ __device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const Fi
   return r;
 }
 
-// Montgomery product a*b*R^{-1} mod p (CIOS over 32-bit words), canonical out.
+// (acc_hi : acc_lo) += x * y with a 96-bit accumulator: one v_mad_u64_u32 whose carry-out (VCC) is
+// folded into the third word by one v_addc_co_u32.  hipcc's own lowering of the same arithmetic from
+// C spends ~5 instructions per word product (zero-extension moves + a 64-bit add).
+#define ZKGPU_MADC(lo, hi, x, y)                                                              \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                \
+      : "+v"(lo), "+v"(hi)                                                                    \
+      : "v"(x), "v"(y)                                                                        \
+      : "vcc")
+
+// Montgomery product a*b*R^{-1} mod p, product-scanning (column by column) form, canonical out.
+// Per column k: acc += sum a[i]*b[k-i] + sum m[i]*p[k-i]; m[k] = acc * n0inv makes the low word 0;
+// the accumulator then shifts down one word.  2*N^2 + N word products, 2 instructions each.
 template <int N>
 __device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
+  u64 lo = 0;
+  u32 hi = 0;
+  u32 m[N], t[N + 1], pw[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) pw[i] = fp.p[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) ZKGPU_MADC(lo, hi, a.w[i], b.w[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; ++i) ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+    m[k] = (u32)lo * fp.n0inv;
+    ZKGPU_MADC(lo, hi, m[k], pw[0]);
+    lo = (lo >> 32) | ((u64)hi << 32);
+    hi = 0;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N; ++k) {
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) {
+      ZKGPU_MADC(lo, hi, a.w[i], b.w[k - i]);
+      ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+    }
+    t[k - N] = (u32)lo;
+    lo = (lo >> 32) | ((u64)hi << 32);
+    hi = 0;
+  }
+  t[N] = (u32)lo;
+  // t < 2p here; one conditional subtraction.
+  Fp<N> d;
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    u64 x = (u64)t[i] - fp.p[i] - borrow;
+    d.w[i] = (u32)x;
+    borrow = (x >> 63) & 1;
+  }
+  const bool use_d = (t[N] != 0) | (borrow == 0);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = use_d ? d.w[i] : t[i];
+  return r;
+}
+
+// Reference form of the same product (CIOS over 32-bit words, plain C): kept for A/B builds
+// (-DZKGPU_MUL_PLAIN_C in tools/kbench.hip) and as the readable statement of the arithmetic.
+template <int N>
+__device__ __forceinline__ Fp<N> fp_mul_plain(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
   u32 t[N + 2];
 #pragma unroll
   for (int i = 0; i < N + 2; ++i) t[i] = 0;
