@@ -140,6 +140,39 @@ int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, ui
 int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out);
 uint64_t zkgpu_table_bytes(const zkgpu_session* s);
 
+/* ---- 4. R1CS (ir-to-zkif path) ---------------------------------------------------------------------
+ * The reference's `ToR1CSConverter` (rust/src/consumers/to_r1cs.rs:93-393) is a ZKBackend that emits one
+ * zkinterface BilinearConstraint A*B=C per backend call and, with use_witness, the assignment of every
+ * variable.  zkgpu_r1cs_from_tape derives the same constraint system from the recorded tape (variable 0
+ * is the constant one, :117; variables are numbered in allocation order); the assignment of a batch is
+ * what the replay leaves in the wire table (zkgpu_finalize(retain_all=1)); zkgpu_r1cs_check evaluates
+ * <a,w>*<b,w> = <c,w> for every row and lane on the GPU (the job of the zkinterface Simulator the
+ * reference's tests call, :583-589). */
+int zkgpu_r1cs_from_tape(zkgpu_session* s, int use_correction);
+/* out[0]=rows out[1]=variables out[2]=terms out[3]=distinct coefficients */
+int zkgpu_r1cs_info(const zkgpu_session* s, uint64_t out[4]);
+/* row_ptr: 3 entries per row (start of A, B, C in the term arrays) + final end; var_of_op[i] = variable of
+ * tape op i (0xFFFF...F for assert_zero).  Any pointer may be NULL. */
+int zkgpu_r1cs_export(const zkgpu_session* s, uint32_t* row_ptr, uint64_t* term_var, uint32_t* term_coef,
+                      uint64_t* var_of_op);
+size_t zkgpu_r1cs_coef_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap);
+/* A caller-supplied constraint system in CSR form over the session's wire table (retain_all): a term's
+ * variable is the index of a value-returning backend call (k < zkgpu_tape_value_ops), an extra variable
+ * (k - value_ops < n_extra_vars, stored behind the program's slots) or 0xFFFF...F for the constant one;
+ * term_coef indexes coef_bytes (n_coefs little-endian strings of coef_width bytes). */
+int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_ptr, const uint64_t* term_var,
+                        const uint32_t* term_coef, const uint8_t* coef_bytes, uint32_t coef_width, uint32_t n_coefs,
+                        uint32_t n_extra_vars);
+/* rows [first_row, first_row+n_rows): write <a,w>*<b,w> into the single variable of C (witness generation
+ * of product rows; the rows of one call must not depend on each other) */
+int zkgpu_r1cs_assign(zkgpu_session* s, uint32_t first_row, uint32_t n_rows);
+int zkgpu_r1cs_check(zkgpu_session* s);                       /* asynchronous: all rows, all lanes */
+/* first_fail_row[lane] = smallest violated row or ZKGPU_NO_FAIL; counts = {lanes satisfying all rows, others} */
+int zkgpu_r1cs_results(zkgpu_session* s, uint32_t* first_fail_row, uint64_t counts[2]);
+/* value of a variable of a loaded CSR for every lane: out[lane][elem_bytes] */
+int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out);
+float zkgpu_r1cs_last_ms(const zkgpu_session* s);             /* HIP-event time of the last check */
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,3 +288,94 @@ def test_boolean_layered_batch_against_oracle(path):
     ev.replay()
     ev.synchronize()
     assert 'not canonical' in ev.get_violations(5)[0]
+
+
+@pytest.mark.parametrize('name', ['arith_101_correct', 'arith_101_incorrect', 'arith_bn254_correct'])
+def test_r1cs_of_a_relation_is_satisfied_by_the_replayed_wires(name):
+    """ir-to-zkif: rows from the tape (to_r1cs.rs rules), assignment = the wire table, row check on the
+    GPU.  A statement is TRUE iff its R1CS instance is satisfied; a failing assert is its own row."""
+    bufs = golden_buffers(name)
+    ev = zk.Evaluator.from_messages(bufs)
+    ev.finalize(retain_all=True)
+    ev.r1cs_from_tape()
+    ev.set_inputs_from_messages()
+    ev.replay()
+    ev.r1cs_check()
+    ff, counts = ev.r1cs_results(1)
+    ref = OracleRun(buffers=bufs)
+    assert counts == ((1, 0) if not ref.violations else (0, 1))
+    rows, _ = ev.r1cs_export()
+    if ref.violations:
+        assert rows[int(ff[0])][2] == [(0, 0)]  # the violated row is an assert_zero row
+    else:
+        assert int(ff[0]) == zk.NO_FAIL
+
+
+def test_r1cs_batched_matches_evaluation_counts():
+    lanes = 70
+    _, _, rel = circuits.arith_example(circuits.BN254_R)
+    rows_i, rows_w = _batched_example(circuits.BN254_R, lanes)
+    ev = zk.Evaluator()
+    ev.declare_inputs(3, 4)
+    ev.ingest_message(rel)
+    ev.finalize(retain_all=True)
+    ev.r1cs_from_tape()
+    inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+    ev.set_inputs(inst, wit, lanes)
+    ev.replay()
+    ev.synchronize()
+    ev.r1cs_check()
+    ff, counts = ev.r1cs_results(lanes)
+    assert counts == ev.counts()
+    first, _ = ev.lane_results(lanes)
+    assert [(int(x) == zk.NO_FAIL) for x in ff] == [(int(x) == zk.NO_FAIL) for x in first]
+
+
+@pytest.mark.parametrize('p', [101, circuits.BN254_R])
+def test_r1cs_csr_rows_with_coefficients(p):
+    """caller-supplied CSR (3+3 term products with random coefficients): witness generation by the
+    row kernel level by level, values against Python integers, then the check; one false row."""
+    wl = workloads.R1csSynthetic(M=300, n_base=24, n_coefs=50, seed=5, p=p)
+    batch = 67
+    ev = zk.Evaluator()
+    ev.declare_inputs(0, wl.n_witness)
+    ev.ingest_message(wl.base_relation())
+    ev.finalize(retain_all=True)
+    row_ptr, tv, tc, cb = wl.csr()
+    # append a false row: (z_0) * (one) = (z_0 + 1)
+    one = len(cb) - 1
+    z0 = wl.n_base + 1
+    t0 = int(row_ptr[-1])
+    row_ptr = np.concatenate([row_ptr, np.array([t0 + 1, t0 + 2, t0 + 4], dtype=np.uint32)])
+    tv = np.concatenate([tv, np.array([z0, 2 ** 64 - 1, z0, 2 ** 64 - 1], dtype=np.uint64)])
+    tc = np.concatenate([tc, np.array([one] * 4, dtype=np.uint32)])
+    ev.r1cs_load_csr(row_ptr, tv, tc, cb, wl.width, wl.M)
+    w = wl.witnesses(batch)
+    ev.set_inputs(None, w.tobytes(), batch)
+    ev.replay()
+    lo = 0
+    for hi in wl.level_bounds:
+        ev.r1cs_assign(lo, int(hi) - lo)
+        lo = int(hi)
+    assert lo == wl.M
+    # expected output variable E := z_last (all lanes honest), reload the base variables
+    zl = ev.r1cs_get_var(wl.last_z, batch)
+    for lane in range(batch):
+        w[lane, wl.n_base] = np.frombuffer(zl[lane].to_bytes(wl.width, 'little'), dtype=np.uint8)
+    ev.set_inputs(None, w.tobytes(), batch)
+    ev.replay()
+    # values of a few z against Python integers
+    coefs = [int.from_bytes(cb[i].tobytes(), 'little') for i in range(len(cb))]
+    for lane in (0, 33, batch - 1):
+        val = {k: int.from_bytes(w[lane, k].tobytes(), 'little') for k in range(wl.n_witness)}
+        for r in range(wl.M):
+            terms = [(int(tv[7 * r + k]), coefs[int(tc[7 * r + k])]) for k in range(6)]
+            a = sum(c * val[v] for v, c in terms[:3]) % p
+            b = sum(c * val[v] for v, c in terms[3:]) % p
+            val[wl.n_base + 1 + r] = a * b % p
+        for var in (wl.n_base + 1, wl.n_base + 1 + wl.M // 2, wl.last_z):
+            assert ev.r1cs_get_var(var, batch)[lane] == val[var]
+    ev.r1cs_check()
+    ff, counts = ev.r1cs_results(batch)
+    assert counts == (0, batch)            # the appended false row fails in every lane
+    assert all(int(x) == wl.M + 1 for x in ff)

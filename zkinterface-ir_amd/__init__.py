@@ -98,6 +98,16 @@ def lib():
         'zkgpu_dump_trace_values': (ci, [vp, u64, u64, vp]),
         'zkgpu_get_wire': (ci, [vp, u64, vp]),
         'zkgpu_table_bytes': (u64, [vp]),
+        'zkgpu_r1cs_from_tape': (ci, [vp, ci]),
+        'zkgpu_r1cs_info': (ci, [vp, u64p]),
+        'zkgpu_r1cs_export': (ci, [vp, vp, vp, vp, vp]),
+        'zkgpu_r1cs_coef_bytes': (sz, [vp, u32, ctypes.c_char_p, sz]),
+        'zkgpu_r1cs_load_csr': (ci, [vp, u32, vp, vp, vp, vp, u32, u32, u32]),
+        'zkgpu_r1cs_assign': (ci, [vp, u32, u32]),
+        'zkgpu_r1cs_check': (ci, [vp]),
+        'zkgpu_r1cs_results': (ci, [vp, vp, u64p]),
+        'zkgpu_r1cs_get_var': (ci, [vp, u64, vp]),
+        'zkgpu_r1cs_last_ms': (ctypes.c_float, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header and library disagree
@@ -324,6 +334,73 @@ class Evaluator:
             return None
         self._ck(rc)
         return [int.from_bytes(buf.raw[l * w:(l + 1) * w], 'little') for l in range(batch)]
+
+    # -- R1CS (ir-to-zkif) -----------------------------------------------------------
+    def r1cs_from_tape(self, use_correction=False):
+        self._ck(self.L.zkgpu_r1cs_from_tape(self.h, 1 if use_correction else 0))
+
+    def r1cs_info(self):
+        out = (ctypes.c_uint64 * 4)()
+        self._ck(self.L.zkgpu_r1cs_info(self.h, out))
+        return dict(zip(['rows', 'vars', 'terms', 'coefs'], list(out)))
+
+    def r1cs_export(self):
+        """(rows, var_of_op): rows = list of (A, B, C), each a list of (variable, coefficient int)"""
+        import numpy as np
+        info = self.r1cs_info()
+        row_ptr = np.zeros(3 * info['rows'] + 1, dtype=np.uint32)
+        tv = np.zeros(max(info['terms'], 1), dtype=np.uint64)
+        tc = np.zeros(max(info['terms'], 1), dtype=np.uint32)
+        vo = np.zeros(max(self.L.zkgpu_tape_len(self.h), 1), dtype=np.uint64)
+        self._ck(self.L.zkgpu_r1cs_export(self.h, row_ptr.ctypes.data, tv.ctypes.data, tc.ctypes.data, vo.ctypes.data))
+        coefs = []
+        for i in range(info['coefs']):
+            n = self.L.zkgpu_r1cs_coef_bytes(self.h, i, None, 0)
+            buf = ctypes.create_string_buffer(max(n, 1))
+            self.L.zkgpu_r1cs_coef_bytes(self.h, i, buf, n)
+            coefs.append(int.from_bytes(buf.raw[:n], 'little'))
+        rows = []
+        for r in range(info['rows']):
+            parts = []
+            for k in range(3):
+                t0, t1 = int(row_ptr[3 * r + k]), int(row_ptr[3 * r + k + 1])
+                parts.append([(int(tv[t]), coefs[int(tc[t])]) for t in range(t0, t1)])
+            rows.append(tuple(parts))
+        return rows, vo[:self.L.zkgpu_tape_len(self.h)]
+
+    def r1cs_load_csr(self, row_ptr, term_var, term_coef, coef_bytes, coef_width, n_extra_vars):
+        import numpy as np
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        term_var = np.ascontiguousarray(term_var, dtype=np.uint64)
+        term_coef = np.ascontiguousarray(term_coef, dtype=np.uint32)
+        coef_bytes = np.ascontiguousarray(coef_bytes, dtype=np.uint8)
+        n_rows = (len(row_ptr) - 1) // 3
+        self._ck(self.L.zkgpu_r1cs_load_csr(self.h, n_rows, row_ptr.ctypes.data, term_var.ctypes.data,
+                                            term_coef.ctypes.data, coef_bytes.ctypes.data, coef_width,
+                                            coef_bytes.size // coef_width, n_extra_vars))
+
+    def r1cs_assign(self, first_row, n_rows):
+        self._ck(self.L.zkgpu_r1cs_assign(self.h, first_row, n_rows))
+
+    def r1cs_check(self):
+        self._ck(self.L.zkgpu_r1cs_check(self.h))
+
+    def r1cs_results(self, batch):
+        import numpy as np
+        ff = np.zeros(batch, dtype=np.uint32)
+        counts = (ctypes.c_uint64 * 2)()
+        self._ck(self.L.zkgpu_r1cs_results(self.h, ff.ctypes.data, counts))
+        return ff, (int(counts[0]), int(counts[1]))
+
+    def r1cs_get_var(self, var, batch):
+        w = self.elem_bytes
+        buf = ctypes.create_string_buffer(max(batch * w, 1))
+        self._ck(self.L.zkgpu_r1cs_get_var(self.h, var, buf))
+        return [int.from_bytes(buf.raw[l * w:(l + 1) * w], 'little') for l in range(batch)]
+
+    @property
+    def r1cs_last_ms(self):
+        return float(self.L.zkgpu_r1cs_last_ms(self.h))
 
     @property
     def table_bytes(self):

@@ -8,6 +8,7 @@
 #include "../../include/zkgpu.h"
 #include "engine.hpp"
 #include "evaluator.hpp"
+#include "r1cs.hpp"
 #include "schedule.hpp"
 #include "tape.hpp"
 
@@ -25,6 +26,12 @@ struct zkgpu_session {
   int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
   bool sort_by_operand = true;
   size_t n_pinned = 0;
+  R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
+  bool r1cs_ready = false, r1cs_on_device = false, r1cs_loaded_csr = false;
+  std::vector<R1csRowDev> r1cs_rows_dev;
+  std::vector<R1csTermDev> r1cs_terms_dev;
+  std::vector<uint32_t> r1cs_coef_words;
+  uint32_t r1cs_extra_vars = 0;
   std::string last_error;
   std::vector<uint32_t> first_fail, flags;
   std::vector<uint32_t> value_op_index;  // k-th value-returning call -> tape index
@@ -64,6 +71,7 @@ void need_engine(zkgpu_session* s) {
     e->set_writeback(s->n_pinned != 0);
     e->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
     e->set_lane_group(s->lane_group);
+    if (s->r1cs_extra_vars) e->reserve_extra_slots(s->r1cs_extra_vars);
     s->engine = std::move(e);
   }
 }
@@ -129,6 +137,81 @@ void put_value(const Value& v, uint8_t* dst, uint32_t width) {
   }
   memset(dst, 0, width);
   memcpy(dst, v.data(), n);
+}
+
+}  // namespace
+
+// ---- R1CS ---------------------------------------------------------------------------------------
+namespace {
+
+// coefficient pool -> Montgomery words; coefficient 1 -> 0xFFFFFFFF (no multiply), 0 -> term dropped
+struct CoefMap {
+  std::vector<uint32_t> index;  // per host coefficient: device index, 0xFFFFFFFF (one) or 0xFFFFFFFE (zero)
+  std::vector<uint32_t> words;
+};
+CoefMap device_coefs(const std::vector<Value>& coefs, const FieldHost& f) {
+  CoefMap m;
+  m.index.resize(coefs.size());
+  for (size_t i = 0; i < coefs.size(); ++i) {
+    uint32_t r[8], mont[8];
+    f.reduce(coefs[i], r);
+    bool zero = true, one = r[0] == 1;
+    for (int k = 0; k < 8; ++k) {
+      zero &= r[k] == 0;
+      if (k) one &= r[k] == 0;
+    }
+    if (zero) { m.index[i] = 0xFFFFFFFEu; continue; }
+    if (one) { m.index[i] = 0xFFFFFFFFu; continue; }
+    f.to_mont(r, mont);
+    m.index[i] = (uint32_t)(m.words.size() / f.nwords);
+    m.words.insert(m.words.end(), mont, mont + f.nwords);
+  }
+  return m;
+}
+
+// rows in `var -> slot` form for the device; slot_of_var(var) returns 0xFFFFFFFF for the constant one
+template <class SlotOf>
+void build_device_rows(zkgpu_session* s, SlotOf&& slot_of_var) {
+  const R1cs& r = s->r1cs;
+  const CoefMap cm = device_coefs(r.coefs, s->backend.field());
+  s->r1cs_rows_dev.clear();
+  s->r1cs_terms_dev.clear();
+  for (size_t row = 0; row < r.n_rows(); ++row) {
+    R1csRowDev d;
+    d.first = (uint32_t)s->r1cs_terms_dev.size();
+    uint32_t n[3] = {0, 0, 0};
+    bool b_is_one = false;
+    for (int part = 0; part < 3; ++part) {
+      const uint32_t t0 = r.row_ptr[3 * row + part], t1 = r.row_ptr[3 * row + part + 1];
+      for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = cm.index[r.terms[t].coef];
+        if (c == 0xFFFFFFFEu) continue;  // zero coefficient
+        R1csTermDev td;
+        td.slot = slot_of_var(r.terms[t].var);
+        td.coef = c;
+        s->r1cs_terms_dev.push_back(td);
+        ++n[part];
+      }
+      if (part == 1 && n[1] == 1) {
+        const R1csTermDev& last = s->r1cs_terms_dev.back();
+        b_is_one = last.slot == 0xFFFFFFFFu && last.coef == 0xFFFFFFFFu;
+      }
+    }
+    if (n[0] > 255 || n[1] > 255 || n[2] > 255) throw std::runtime_error("R1CS row with more than 255 terms in one combination");
+    d.counts = n[0] | (n[1] << 8) | (n[2] << 16) | ((b_is_one ? 1u : 0u) << 24);
+    s->r1cs_rows_dev.push_back(d);
+  }
+  s->r1cs_coef_words = cm.words;
+  s->r1cs_on_device = false;
+}
+
+void r1cs_to_device(zkgpu_session* s) {
+  need_engine(s);
+  if (!s->r1cs_ready) throw std::runtime_error("no R1CS: call zkgpu_r1cs_from_tape or zkgpu_r1cs_load_csr");
+  if (!s->r1cs_on_device) {
+    s->engine->r1cs_upload(s->r1cs_rows_dev, s->r1cs_terms_dev, s->r1cs_coef_words);
+    s->r1cs_on_device = true;
+  }
 }
 
 }  // namespace
@@ -476,6 +559,128 @@ int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out) {
     if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
   });
 }
+
+int zkgpu_r1cs_from_tape(zkgpu_session* s, int use_correction) {
+  return guarded(s, [&] {
+    if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
+    if (s->backend.field().is_two) throw std::runtime_error("R1CS conversion on the GPU path needs an odd field characteristic");
+    const Tape& t = s->backend.tape();
+    Value modulus(32, 0);
+    for (int i = 0; i < 32; ++i) modulus[i] = (uint8_t)(s->backend.field().p[i / 4] >> (8 * (i % 4)));
+    s->r1cs = r1cs_from_tape(t, s->backend.field(), modulus, use_correction != 0);
+    s->r1cs_ready = true;
+    s->r1cs_loaded_csr = false;
+    s->r1cs_extra_vars = 0;
+    s->r1cs_rows_dev.clear();
+    if (s->finalized && s->retain_all && !use_correction) {
+      std::vector<uint32_t> slot_of_var(s->r1cs.n_vars, 0xFFFFFFFFu);
+      for (size_t i = 0; i < t.size(); ++i)
+        if (t.kind[i] != TK_COPY && t.kind[i] != TK_ASSERT && s->r1cs.var_of_op[i] != kNoVar)
+          slot_of_var[s->r1cs.var_of_op[i]] = s->sched.slot_of[i];
+      build_device_rows(s, [&](uint64_t var) { return var == kVarOne ? 0xFFFFFFFFu : slot_of_var[var]; });
+    }
+  });
+}
+
+int zkgpu_r1cs_info(const zkgpu_session* s, uint64_t out[4]) {
+  if (!s || !s->r1cs_ready) return 1;
+  out[0] = s->r1cs.n_rows();
+  out[1] = s->r1cs.n_vars;
+  out[2] = s->r1cs.terms.size();
+  out[3] = s->r1cs.coefs.size();
+  return 0;
+}
+
+int zkgpu_r1cs_export(const zkgpu_session* s, uint32_t* row_ptr, uint64_t* term_var, uint32_t* term_coef,
+                      uint64_t* var_of_op) {
+  if (!s || !s->r1cs_ready) return 1;
+  const R1cs& r = s->r1cs;
+  if (row_ptr && !r.row_ptr.empty()) memcpy(row_ptr, r.row_ptr.data(), r.row_ptr.size() * 4);
+  for (size_t i = 0; i < r.terms.size(); ++i) {
+    if (term_var) term_var[i] = r.terms[i].var;
+    if (term_coef) term_coef[i] = r.terms[i].coef;
+  }
+  if (var_of_op && !r.var_of_op.empty()) memcpy(var_of_op, r.var_of_op.data(), r.var_of_op.size() * 8);
+  return 0;
+}
+
+size_t zkgpu_r1cs_coef_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap) {
+  if (!s || !s->r1cs_ready || index >= s->r1cs.coefs.size()) return 0;
+  const Value& v = s->r1cs.coefs[index];
+  if (out && cap >= v.size() && !v.empty()) memcpy(out, v.data(), v.size());
+  return v.size();
+}
+
+int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_ptr, const uint64_t* term_var,
+                        const uint32_t* term_coef, const uint8_t* coef_bytes, uint32_t coef_width, uint32_t n_coefs,
+                        uint32_t n_extra_vars) {
+  return guarded(s, [&] {
+    if (!s->finalized || !s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) first: variables are tape values");
+    if (s->engine) throw std::runtime_error("load the CSR before the first zkgpu_set_inputs* call (the table is sized once)");
+    R1cs r;
+    r.row_ptr.assign(row_ptr, row_ptr + 3 * (size_t)n_rows + 1);
+    const size_t n_terms = r.row_ptr.back();
+    r.terms.resize(n_terms);
+    for (size_t i = 0; i < n_terms; ++i) r.terms[i] = R1csTerm{term_var[i], term_coef[i]};
+    for (uint32_t i = 0; i < n_coefs; ++i)
+      r.coefs.emplace_back(coef_bytes + (size_t)i * coef_width, coef_bytes + (size_t)(i + 1) * coef_width);
+    const uint64_t n_ops = s->value_op_index.size();
+    r.n_vars = n_ops + n_extra_vars;
+    s->r1cs = std::move(r);
+    s->r1cs_ready = true;
+    s->r1cs_loaded_csr = true;
+    s->r1cs_extra_vars = n_extra_vars;
+    const uint32_t base = s->sched.n_slots;
+    build_device_rows(s, [&](uint64_t var) -> uint32_t {
+      if (var == ~0ull) return 0xFFFFFFFFu;
+      if (var < n_ops) return s->sched.slot_of[s->value_op_index[var]];
+      if (var - n_ops >= n_extra_vars) throw std::runtime_error("R1CS term names a variable out of range");
+      return base + (uint32_t)(var - n_ops);
+    });
+  });
+}
+
+int zkgpu_r1cs_assign(zkgpu_session* s, uint32_t first_row, uint32_t n_rows) {
+  return guarded(s, [&] {
+    r1cs_to_device(s);
+    s->engine->r1cs_run(true, first_row, n_rows);
+  });
+}
+
+int zkgpu_r1cs_check(zkgpu_session* s) {
+  return guarded(s, [&] {
+    r1cs_to_device(s);
+    s->engine->r1cs_begin_check();
+    s->engine->r1cs_run(false, 0, (uint32_t)s->r1cs_rows_dev.size());
+    s->engine->r1cs_finish_check();
+  });
+}
+
+int zkgpu_r1cs_results(zkgpu_session* s, uint32_t* first_fail_row, uint64_t counts[2]) {
+  return guarded(s, [&] {
+    need_engine(s);
+    std::vector<uint32_t> ff;
+    s->engine->r1cs_results(first_fail_row ? &ff : nullptr, counts);
+    if (first_fail_row && !ff.empty()) memcpy(first_fail_row, ff.data(), ff.size() * 4);
+  });
+}
+
+int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out) {
+  return guarded(s, [&] {
+    need_engine(s);
+    if (!s->r1cs_ready || !s->r1cs_loaded_csr) throw std::runtime_error("zkgpu_r1cs_get_var needs a CSR loaded with zkgpu_r1cs_load_csr");
+    const uint64_t n_ops = s->value_op_index.size();
+    uint32_t slot;
+    if (var < n_ops) slot = s->sched.slot_of[s->value_op_index[var]];
+    else if (var - n_ops < s->r1cs_extra_vars) slot = s->sched.n_slots + (uint32_t)(var - n_ops);
+    else throw std::runtime_error("variable out of range");
+    std::vector<uint8_t> tmp;
+    s->engine->dump_slots(std::vector<uint32_t>(1, slot), &tmp);
+    if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+  });
+}
+
+float zkgpu_r1cs_last_ms(const zkgpu_session* s) { return (s && s->engine) ? s->engine->last_r1cs_ms() : 0.f; }
 
 uint64_t zkgpu_table_bytes(const zkgpu_session* s) { return (s && s->engine) ? s->engine->table_bytes() : 0; }
 

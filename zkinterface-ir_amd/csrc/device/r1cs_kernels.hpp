@@ -1,0 +1,91 @@
+// R1CS row kernel: <a,w> * <b,w> against <c,w> for every row and every witness lane.
+// Stands in for the zkinterface `Simulator` the reference's tests call on ToR1CSConverter output
+// (rust/src/consumers/to_r1cs.rs:583-589,628-634; the crate itself is not under /root/reference).
+//
+// One wave = one row x 64 witnesses.  Row descriptors and terms are wave-uniform (scalar loads);
+// each term is one 2-KiB gather from the wire table (same layout as the replay kernels); the linear
+// combinations live in registers.  Algorithmic bytes: 32 B per term and witness.
+#pragma once
+#include "replay_kernels.hpp"
+
+namespace zkgpu {
+
+struct R1csRow {
+  u32 first;
+  u32 counts;  // nA | nB << 8 | nC << 16 | flags << 24
+};
+struct R1csTerm {
+  u32 slot;  // 0xFFFFFFFF: the constant one
+  u32 coef;  // 0xFFFFFFFF: coefficient 1
+};
+constexpr u32 kR1csBIsOne = 1u;
+
+struct R1csArgs {
+  const R1csRow* rows;
+  const R1csTerm* terms;
+  const u32* coefs;      // Montgomery form, N words each
+  u32 first_row, n_rows; // rows [first_row, first_row + n_rows) of this launch
+  const uint4* table;    // read side
+  uint4* table_out;      // ASSIGN: same table
+  u32 n_slots;
+  u32 batch;
+  u32* first_fail;       // CHECK: min failing row per lane
+};
+
+template <int N>
+__device__ __forceinline__ Fp<N> r1cs_lincomb(const R1csArgs& args, const uint4* __restrict__ T, u32 t0, u32 n,
+                                              const FieldParams& fp) {
+  Fp<N> acc;
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc.w[i] = 0;
+  for (u32 t = t0; t < t0 + n; ++t) {
+    const R1csTerm term = args.terms[t];
+    Fp<N> v;
+    if (term.slot == 0xFFFFFFFFu) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) v.w[i] = fp.one[i];
+    } else {
+      v = wire_load<N>(T + (size_t)term.slot * Layout<N>::kRecord);
+    }
+    if (term.coef != 0xFFFFFFFFu) v = fp_mul<N>(v, fp_load_const<N>(args.coefs + (size_t)term.coef * N), fp);
+    acc = fp_add<N>(acc, v, fp);
+  }
+  return acc;
+}
+
+// ASSIGN = false: compare and record the first failing row per lane.
+// ASSIGN = true : C must be a single term with coefficient 1; its slot receives <a,w>*<b,w>.
+template <int N, bool ASSIGN>
+__global__ __launch_bounds__(256) void r1cs_row_kernel(const R1csArgs args, const FieldParams fp) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 lb = blockIdx.y;
+  const u32 r = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (r >= args.n_rows) return;
+  const u32 row = args.first_row + r;
+  const R1csRow d = args.rows[row];
+  const u32 na = d.counts & 0xFF, nb = (d.counts >> 8) & 0xFF, nc = (d.counts >> 16) & 0xFF, flags = d.counts >> 24;
+  const uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
+  Fp<N> prod = r1cs_lincomb<N>(args, T, d.first, na, fp);
+  if (!(flags & kR1csBIsOne)) {
+    const Fp<N> b = r1cs_lincomb<N>(args, T, d.first + na, nb, fp);
+    prod = fp_mul<N>(prod, b, fp);
+  }
+  if (ASSIGN) {
+    const R1csTerm out = args.terms[d.first + na + nb];
+    uint4* __restrict__ O = args.table_out + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
+    wire_store<N>(O + (size_t)out.slot * Layout<N>::kRecord, prod);
+  } else {
+    const Fp<N> c = r1cs_lincomb<N>(args, T, d.first + na + nb, nc, fp);
+    u32 diff = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) diff |= prod.w[i] ^ c.w[i];
+    const u32 lane_g = lb * 64 + lane;
+    const bool bad = diff != 0 && lane_g < args.batch;
+    if (__ballot(bad) != 0ull) {
+      if (bad) atomicMin(&args.first_fail[lane_g], row);
+    }
+  }
+}
+
+}  // namespace zkgpu

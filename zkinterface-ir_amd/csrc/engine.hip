@@ -6,6 +6,7 @@
 #include <string>
 
 #include "device/bool_kernels.hpp"
+#include "device/r1cs_kernels.hpp"
 #include "device/replay_kernels.hpp"
 #include "engine.hpp"
 
@@ -20,6 +21,8 @@ void check(hipError_t e, const char* what) {
 #define HIP_OK(x) check((x), #x)
 
 static_assert(sizeof(DevOp) == sizeof(zkgpu::TapeOp), "DevOp must match the device TapeOp");
+static_assert(sizeof(R1csRowDev) == sizeof(zkgpu::R1csRow) && sizeof(R1csTermDev) == sizeof(zkgpu::R1csTerm),
+              "host and device R1CS records must match");
 static_assert(sizeof(zkgpu::FieldParams) <= 128, "FieldParams must fit Engine::field_params_");
 
 template <typename T>
@@ -64,6 +67,12 @@ Engine::~Engine() {
   dfree(d_counts_);
   dfree(d_lds_ops_);
   dfree(d_launches_);
+  dfree(d_r1cs_rows_);
+  dfree(d_r1cs_terms_);
+  dfree(d_r1cs_coefs_);
+  dfree(d_r1cs_counts_);
+  if (ev_r1cs_begin_) (void)hipEventDestroy((hipEvent_t)ev_r1cs_begin_);
+  if (ev_r1cs_end_) (void)hipEventDestroy((hipEvent_t)ev_r1cs_end_);
   for (void* e : launch_events_) (void)hipEventDestroy((hipEvent_t)e);
   if (ev_begin_) (void)hipEventDestroy((hipEvent_t)ev_begin_);
   if (ev_end_) (void)hipEventDestroy((hipEvent_t)ev_end_);
@@ -78,6 +87,7 @@ void Engine::free_batch() {
   dfree(d_wit_own_);
   dfree(d_packed_inst_);
   dfree(d_packed_wit_);
+  dfree(d_r1cs_fail_);
   d_inst_ = d_wit_ = nullptr;
   batch_ = 0;
 }
@@ -218,7 +228,9 @@ void Engine::set_batch(uint32_t batch) {
   batch_ = batch;
   lane_blocks_ = (batch + lanes_per_block_ - 1) / lanes_per_block_;
   const uint64_t rec_bytes = boolean_ ? 64 * 8 : (uint64_t)((nwords_ + 3) / 4) * 64 * 16;
-  table_bytes_ = (uint64_t)lane_blocks_ * sched_.n_slots * rec_bytes;
+  if (boolean_ && extra_slots_) throw std::runtime_error("Engine: extra slots are only supported for arithmetic fields");
+  table_slots_ = sched_.n_slots + extra_slots_;
+  table_bytes_ = (uint64_t)lane_blocks_ * table_slots_ * rec_bytes;
   size_t free_b = 0, total_b = 0;
   HIP_OK(hipMemGetInfo(&free_b, &total_b));
   if (table_bytes_ > (uint64_t)(0.92 * (double)free_b))
@@ -228,6 +240,7 @@ void Engine::set_batch(uint32_t batch) {
   const size_t padded_lanes = (size_t)lane_blocks_ * lanes_per_block_;
   HIP_OK(hipMalloc(&d_first_fail_, padded_lanes * 4));
   HIP_OK(hipMalloc(&d_flags_, padded_lanes * 4));
+  HIP_OK(hipMalloc(&d_r1cs_fail_, padded_lanes * 4));
   if (boolean_) {
     const size_t words = (size_t)lane_blocks_ * 64;
     HIP_OK(hipMalloc(&d_packed_inst_, std::max<size_t>((size_t)n_inst_ * words * 8, 64)));
@@ -288,7 +301,7 @@ void Engine::launch_range(uint32_t lb0, uint32_t lbs, bool time_each) {
       a.n_ops = L.count;
       a.ops_per_wave = L.ops_per_wave;
       a.table = (uint4*)d_table_;
-      a.n_slots = sched_.n_slots;
+      a.n_slots = table_slots_;
       a.batch = batch_;
       a.lb_base = lb0;
       a.consts = (const zkgpu::u32*)d_consts_;
@@ -379,6 +392,95 @@ void Engine::replay(bool time_each_launch) {
   }
 }
 
+void Engine::reserve_extra_slots(uint32_t n) {
+  if (batch_) throw std::runtime_error("Engine: reserve_extra_slots() must precede set_batch()");
+  extra_slots_ = n;
+}
+
+void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<R1csTermDev>& terms,
+                         const std::vector<uint32_t>& coef_words) {
+  if (boolean_) throw std::runtime_error("Engine: the R1CS row kernel needs an arithmetic field");
+  dfree(d_r1cs_rows_);
+  dfree(d_r1cs_terms_);
+  dfree(d_r1cs_coefs_);
+  HIP_OK(hipMalloc(&d_r1cs_rows_, std::max<size_t>(rows.size() * sizeof(R1csRowDev), 64)));
+  HIP_OK(hipMalloc(&d_r1cs_terms_, std::max<size_t>(terms.size() * sizeof(R1csTermDev), 64)));
+  HIP_OK(hipMalloc(&d_r1cs_coefs_, std::max<size_t>(coef_words.size() * 4, 64)));
+  if (!rows.empty()) HIP_OK(hipMemcpy(d_r1cs_rows_, rows.data(), rows.size() * sizeof(R1csRowDev), hipMemcpyHostToDevice));
+  if (!terms.empty()) HIP_OK(hipMemcpy(d_r1cs_terms_, terms.data(), terms.size() * sizeof(R1csTermDev), hipMemcpyHostToDevice));
+  if (!coef_words.empty()) HIP_OK(hipMemcpy(d_r1cs_coefs_, coef_words.data(), coef_words.size() * 4, hipMemcpyHostToDevice));
+  r1cs_rows_ = (uint32_t)rows.size();
+  if (!d_r1cs_counts_) HIP_OK(hipMalloc(&d_r1cs_counts_, 16));
+  if (!ev_r1cs_begin_) {
+    hipEvent_t a, b;
+    HIP_OK(hipEventCreate(&a));
+    HIP_OK(hipEventCreate(&b));
+    ev_r1cs_begin_ = a;
+    ev_r1cs_end_ = b;
+  }
+}
+
+void Engine::r1cs_begin_check() {
+  if (!batch_ || !d_r1cs_rows_) throw std::runtime_error("Engine: R1CS rows or batch not set");
+  hipStream_t st = (hipStream_t)stream_;
+  HIP_OK(hipEventRecord((hipEvent_t)ev_r1cs_begin_, st));
+  HIP_OK(hipMemsetAsync(d_r1cs_fail_, 0xFF, (size_t)lane_blocks_ * lanes_per_block_ * 4, st));
+  HIP_OK(hipMemsetAsync(d_r1cs_counts_, 0, 16, st));
+}
+
+void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
+  if (!batch_ || !d_r1cs_rows_) throw std::runtime_error("Engine: R1CS rows or batch not set");
+  if ((uint64_t)first_row + n_rows > r1cs_rows_) throw std::runtime_error("Engine: R1CS row range out of bounds");
+  if (!n_rows) return;
+  hipStream_t st = (hipStream_t)stream_;
+  zkgpu::FieldParams fp;
+  memcpy(&fp, field_params_, sizeof fp);
+  zkgpu::R1csArgs a;
+  memset(&a, 0, sizeof a);
+  a.rows = (const zkgpu::R1csRow*)d_r1cs_rows_;
+  a.terms = (const zkgpu::R1csTerm*)d_r1cs_terms_;
+  a.coefs = (const zkgpu::u32*)d_r1cs_coefs_;
+  a.first_row = first_row;
+  a.n_rows = n_rows;
+  a.table = (const uint4*)d_table_;
+  a.table_out = (uint4*)d_table_;
+  a.n_slots = table_slots_;
+  a.batch = batch_;
+  a.first_fail = (zkgpu::u32*)d_r1cs_fail_;
+  const dim3 grid((n_rows + 3) / 4, lane_blocks_);
+#define ZK_R1CS(N)                                                                     \
+  case N:                                                                              \
+    if (assign) zkgpu::r1cs_row_kernel<N, true><<<grid, 256, 0, st>>>(a, fp);          \
+    else zkgpu::r1cs_row_kernel<N, false><<<grid, 256, 0, st>>>(a, fp);                \
+    break;
+  switch (nwords_) {
+    ZK_R1CS(2) ZK_R1CS(4) ZK_R1CS(6) ZK_R1CS(8)
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
+#undef ZK_R1CS
+  HIP_OK(hipGetLastError());
+}
+
+void Engine::r1cs_finish_check() {
+  hipStream_t st = (hipStream_t)stream_;
+  zkgpu::verdict_kernel<<<(batch_ + 255) / 256, 256, 0, st>>>((const zkgpu::u32*)d_r1cs_fail_,
+                                                              (const zkgpu::u32*)d_flags_, batch_,
+                                                              (unsigned long long*)d_r1cs_counts_);
+  HIP_OK(hipEventRecord((hipEvent_t)ev_r1cs_end_, st));
+  HIP_OK(hipGetLastError());
+}
+
+void Engine::r1cs_results(std::vector<uint32_t>* first_fail_row, uint64_t counts[2]) {
+  HIP_OK(hipStreamSynchronize((hipStream_t)stream_));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)ev_r1cs_begin_, (hipEvent_t)ev_r1cs_end_) == hipSuccess) last_r1cs_ms_ = ms;
+  if (first_fail_row) {
+    first_fail_row->resize(batch_);
+    HIP_OK(hipMemcpy(first_fail_row->data(), d_r1cs_fail_, (size_t)batch_ * 4, hipMemcpyDeviceToHost));
+  }
+  if (counts) HIP_OK(hipMemcpy(counts, d_r1cs_counts_, 16, hipMemcpyDeviceToHost));
+}
+
 void Engine::synchronize() {
   HIP_OK(hipStreamSynchronize((hipStream_t)stream_));
   float ms = 0.f;
@@ -419,10 +521,10 @@ void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>
   } else {
     const uint4* T = (const uint4*)d_table_;
     switch (nwords_) {
-      case 2: zkgpu::dump_slots_kernel<2><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 4: zkgpu::dump_slots_kernel<4><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 6: zkgpu::dump_slots_kernel<6><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 8: zkgpu::dump_slots_kernel<8><<<dim3(k, lb64), 64, 0, st>>>(T, sched_.n_slots, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 2: zkgpu::dump_slots_kernel<2><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 4: zkgpu::dump_slots_kernel<4><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 6: zkgpu::dump_slots_kernel<6><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 8: zkgpu::dump_slots_kernel<8><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
       default: break;
     }
   }

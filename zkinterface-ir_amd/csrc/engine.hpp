@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "r1cs.hpp"
 #include "schedule.hpp"
 
 namespace zki {
@@ -51,6 +52,19 @@ class Engine {
   // out[lane][k][elem_bytes]: canonical value of slot slots[k] for every lane
   void dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out);
 
+  // ---- R1CS rows over the same wire table (arithmetic fields) ----------------------------------
+  // extra table slots behind the program's own (variables assigned by r1cs_run(assign=true)); call
+  // before set_batch()
+  void reserve_extra_slots(uint32_t n);
+  uint32_t program_slots() const { return sched_.n_slots; }
+  void r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<R1csTermDev>& terms,
+                   const std::vector<uint32_t>& coef_words);
+  void r1cs_begin_check();                                        // reset the failing-row words
+  void r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows);  // asynchronous
+  void r1cs_finish_check();                                       // counts; records the event time
+  void r1cs_results(std::vector<uint32_t>* first_fail_row, uint64_t counts[2]);
+  float last_r1cs_ms() const { return last_r1cs_ms_; }
+
   uint64_t table_bytes() const { return table_bytes_; }
   uint32_t batch() const { return batch_; }
 
@@ -84,6 +98,16 @@ class Engine {
   const void* d_wit_ = nullptr;
   void* d_packed_inst_ = nullptr;  // GF(2) path
   void* d_packed_wit_ = nullptr;
+  void* d_r1cs_rows_ = nullptr;
+  void* d_r1cs_terms_ = nullptr;
+  void* d_r1cs_coefs_ = nullptr;
+  void* d_r1cs_fail_ = nullptr;
+  void* d_r1cs_counts_ = nullptr;
+  void* ev_r1cs_begin_ = nullptr;
+  void* ev_r1cs_end_ = nullptr;
+  uint32_t r1cs_rows_ = 0;
+  uint32_t extra_slots_ = 0, table_slots_ = 0;
+  float last_r1cs_ms_ = 0.f;
   void* d_lds_ops_ = nullptr;       // 8-byte program for the LDS-resident GF(2) kernel
   void* d_launches_ = nullptr;
   uint32_t n_lds_chunks_ = 0;

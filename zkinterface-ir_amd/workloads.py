@@ -255,5 +255,83 @@ class BoolLayered:
         return [self.D * self.W + t for t in range(self.n_out)]
 
 
+class R1csSynthetic:
+    """The C5 workload: M rows over n_base + M variables over BN254.  Row i is
+    (sum of 3 coef*var) * (sum of 3 coef*var) = z_i with the six variables drawn from the variables that
+    exist before z_i (base variables and earlier z) and coefficients from a pool of random field
+    elements; z_i is fresh and is assigned the product, so the system is satisfiable.  One last row
+    compares z_{M-1} with a per-lane expected value held in an extra base variable (the handle used to
+    make every 97th lane unsatisfied).  Rows are emitted sorted by dependency level so that the
+    witness generation of one level is a single independent launch."""
+
+    def __init__(self, M=1 << 20, n_base=4096, n_coefs=1 << 16, seed=0xC5, p=BN254_R):
+        self.M, self.n_base, self.p, self.seed = M, n_base, p, seed
+        self.width = 8 * ((p.bit_length() + 63) // 64)
+        self.mod_le = int_to_le(p)
+        self.n_witness = n_base + 1  # + the expected-output variable E
+        rng = np.random.default_rng(seed)
+        # variable ids (caller space of zkgpu_r1cs_load_csr): base k -> k, E -> n_base, z_i -> n_base + 1 + i
+        hi = (np.arange(M, dtype=np.int64) + n_base)[:, None]           # row i may use vars < n_base + i
+        picks = (rng.random((M, 6)) * hi).astype(np.int64)               # in [0, n_base + i)
+        picks = np.where(picks >= n_base, picks + 1, picks)              # skip E's id
+        self.coef_idx = rng.integers(0, n_coefs, size=(M, 6), dtype=np.int64)
+        self.coefs = random_field_elements(seed + 17, (n_coefs,), p)[:, :self.width]
+        # dependency levels (sequential by construction: row i only sees earlier z)
+        level = [0] * (n_base + 1 + M)
+        pl = picks.tolist()
+        for i in range(M):
+            r = pl[i]
+            level[n_base + 1 + i] = 1 + max(level[r[0]], level[r[1]], level[r[2]], level[r[3]], level[r[4]], level[r[5]])
+        lv = np.array(level[n_base + 1:], dtype=np.int64)
+        order = np.argsort(lv, kind='stable')
+        self.row_level = lv[order]
+        self.n_levels = int(lv.max())
+        # renumber z so that the emitted row r defines extra variable r
+        new_id = np.empty(M, dtype=np.int64)
+        new_id[order] = np.arange(M, dtype=np.int64)
+        zmask = picks > n_base
+        picks = np.where(zmask, n_base + 1 + new_id[np.clip(picks - n_base - 1, 0, M - 1)], picks)
+        self.picks = picks[order]
+        self.coef_idx = self.coef_idx[order]
+        self.last_z = n_base + 1 + int(new_id[M - 1])   # any z would do; keep the original last row
+        self.level_bounds = np.searchsorted(self.row_level, np.arange(1, self.n_levels + 2))
+
+    def csr(self):
+        """(row_ptr, term_var, term_coef, coef_bytes) for M product rows + the final comparison row"""
+        M = self.M
+        one = 1 << 16  # coefficient index of the literal 1 appended to the pool below
+        coef_bytes = np.concatenate([self.coefs, np.frombuffer((1).to_bytes(self.width, 'little'), dtype=np.uint8)[None, :]])
+        one = len(coef_bytes) - 1
+        tv = np.empty((M, 7), dtype=np.uint64)
+        tc = np.empty((M, 7), dtype=np.uint32)
+        tv[:, :6] = self.picks
+        tv[:, 6] = np.arange(M, dtype=np.uint64) + np.uint64(self.n_base + 1)
+        tc[:, :6] = self.coef_idx
+        tc[:, 6] = one
+        row_ptr = np.empty(3 * (M + 1) + 1, dtype=np.uint32)
+        base = (np.arange(M, dtype=np.uint32) * 7)
+        row_ptr[0:3 * M:3] = base
+        row_ptr[1:3 * M:3] = base + 3
+        row_ptr[2:3 * M:3] = base + 6
+        # final row: (z_last * 1) * (one) = (E * 1)
+        t0 = 7 * M
+        row_ptr[3 * M:3 * M + 4] = [t0, t0 + 1, t0 + 2, t0 + 3]
+        term_var = np.concatenate([tv.reshape(-1), np.array([self.last_z, 0xFFFFFFFFFFFFFFFF, self.n_base], dtype=np.uint64)])
+        term_coef = np.concatenate([tc.reshape(-1), np.array([one, one, one], dtype=np.uint32)])
+        return row_ptr, term_var, term_coef, coef_bytes
+
+    def base_relation(self):
+        """a relation that only loads the n_base + 1 base variables (witness gates)"""
+        from .sieve_writer import write_relation
+        gates = [('witness', k) for k in range(self.n_witness)]
+        return write_relation(self.mod_le, 'arithmetic', 'simple', [], gates)
+
+    def witnesses(self, batch, lane_offset=0):
+        w = random_field_elements(self.seed + 0x2000 + lane_offset * self.n_witness * 4, (batch, self.n_witness), self.p)
+        w = np.ascontiguousarray(w[..., :self.width])
+        w[:, self.n_base] = 0
+        return w
+
+
 def expected_satisfied(batch, lane_offset=0, corrupt_every=97):
     return batch - sum(1 for i in range(batch) if (i + lane_offset) % corrupt_every == 0)
