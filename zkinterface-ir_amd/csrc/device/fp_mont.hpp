@@ -139,6 +139,67 @@ __device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const Fi
   return r;
 }
 
+// sum_k v[k]*c[k]*R^{-1} mod p with ONE Montgomery reduction for the whole sum (lazy reduction): the K
+// double-width products are accumulated column by column next to the m*p products of the reduction.
+// K*N^2 + N^2 + N word products instead of K*(2*N^2 + N).  The unreduced result is below
+// K*p*p/R + p < (K+1)*p, hence up to K conditional subtractions.
+template <int N, int K>
+__device__ __forceinline__ Fp<N> fp_dot(const Fp<N> (&v)[K], const Fp<N> (&c)[K], const FieldParams& fp) {
+  static_assert(K >= 1 && K <= 4, "the 32-bit carry word of the accumulator holds 2*K*N carries");
+  u64 lo = 0;
+  u32 hi = 0;
+  u32 m[N], t[N + 1], pw[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) pw[i] = fp.p[i];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+#pragma unroll
+      for (int i = 0; i <= k; ++i) ZKGPU_MADC(lo, hi, v[q].w[i], c[q].w[k - i]);
+    }
+#pragma unroll
+    for (int i = 0; i < k; ++i) ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+    m[k] = (u32)lo * fp.n0inv;
+    ZKGPU_MADC(lo, hi, m[k], pw[0]);
+    lo = (lo >> 32) | ((u64)hi << 32);
+    hi = 0;
+  }
+#pragma unroll
+  for (int k = N; k < 2 * N; ++k) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+#pragma unroll
+      for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC(lo, hi, v[q].w[i], c[q].w[k - i]);
+    }
+#pragma unroll
+    for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+    t[k - N] = (u32)lo;
+    lo = (lo >> 32) | ((u64)hi << 32);
+    hi = 0;
+  }
+  t[N] = (u32)lo;
+#pragma unroll
+  for (int round = 0; round < K; ++round) {
+    u32 d[N];
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      u64 x = (u64)t[i] - fp.p[i] - borrow;
+      d[i] = (u32)x;
+      borrow = (x >> 63) & 1;
+    }
+    const bool ge = (t[N] != 0) | (borrow == 0);  // t >= p
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = ge ? d[i] : t[i];
+    t[N] = ge ? t[N] - (u32)borrow : t[N];
+  }
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = t[i];
+  return r;
+}
+
 // Reference form of the same product (CIOS over 32-bit words, plain C): kept for A/B builds
 // (-DZKGPU_MUL_PLAIN_C in tools/kbench.hip) and as the readable statement of the arithmetic.
 template <int N>

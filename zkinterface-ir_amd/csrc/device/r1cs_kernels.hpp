@@ -33,22 +33,63 @@ struct R1csArgs {
 };
 
 template <int N>
+__device__ __forceinline__ Fp<N> r1cs_term_value(const R1csTerm term, const uint4* __restrict__ T,
+                                                 const FieldParams& fp) {
+  Fp<N> v;
+  if (term.slot == 0xFFFFFFFFu) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v.w[i] = fp.one[i];
+  } else {
+    v = wire_load<N>(T + (size_t)term.slot * Layout<N>::kRecord);
+  }
+  return v;
+}
+template <int N>
+__device__ __forceinline__ Fp<N> r1cs_term_coef(const R1csArgs& args, const R1csTerm term, const FieldParams& fp) {
+  if (term.coef == 0xFFFFFFFFu) {
+    Fp<N> c;
+#pragma unroll
+    for (int i = 0; i < N; ++i) c.w[i] = fp.one[i];
+    return c;
+  }
+  return fp_load_const<N>(args.coefs + (size_t)term.coef * N);
+}
+
+// A linear combination, three terms at a time: the three gathers are issued together and, when a
+// coefficient other than 1 is present, the three products share one Montgomery reduction (fp_dot).
+template <int N>
 __device__ __forceinline__ Fp<N> r1cs_lincomb(const R1csArgs& args, const uint4* __restrict__ T, u32 t0, u32 n,
                                               const FieldParams& fp) {
   Fp<N> acc;
 #pragma unroll
   for (int i = 0; i < N; ++i) acc.w[i] = 0;
-  for (u32 t = t0; t < t0 + n; ++t) {
-    const R1csTerm term = args.terms[t];
-    Fp<N> v;
-    if (term.slot == 0xFFFFFFFFu) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) v.w[i] = fp.one[i];
+  u32 t = t0;
+  const u32 end = t0 + n;
+  while (t < end) {
+    const u32 m = min(3u, end - t);
+    const R1csTerm e0 = args.terms[t];
+    const R1csTerm e1 = args.terms[t + (m > 1 ? 1 : 0)];
+    const R1csTerm e2 = args.terms[t + (m > 2 ? 2 : 0)];
+    const bool plain = e0.coef == 0xFFFFFFFFu && (m < 2 || e1.coef == 0xFFFFFFFFu) && (m < 3 || e2.coef == 0xFFFFFFFFu);
+    Fp<N> v[3];
+    v[0] = r1cs_term_value<N>(e0, T, fp);
+    if (m > 1) v[1] = r1cs_term_value<N>(e1, T, fp);
+    if (m > 2) v[2] = r1cs_term_value<N>(e2, T, fp);
+    if (plain) {
+      acc = fp_add<N>(acc, v[0], fp);
+      if (m > 1) acc = fp_add<N>(acc, v[1], fp);
+      if (m > 2) acc = fp_add<N>(acc, v[2], fp);
+    } else if (m == 3) {
+      Fp<N> c[3] = {r1cs_term_coef<N>(args, e0, fp), r1cs_term_coef<N>(args, e1, fp), r1cs_term_coef<N>(args, e2, fp)};
+      acc = fp_add<N>(acc, fp_dot<N, 3>(v, c, fp), fp);
+    } else if (m == 2) {
+      Fp<N> v2[2] = {v[0], v[1]};
+      Fp<N> c2[2] = {r1cs_term_coef<N>(args, e0, fp), r1cs_term_coef<N>(args, e1, fp)};
+      acc = fp_add<N>(acc, fp_dot<N, 2>(v2, c2, fp), fp);
     } else {
-      v = wire_load<N>(T + (size_t)term.slot * Layout<N>::kRecord);
+      acc = fp_add<N>(acc, fp_mul<N>(v[0], r1cs_term_coef<N>(args, e0, fp), fp), fp);
     }
-    if (term.coef != 0xFFFFFFFFu) v = fp_mul<N>(v, fp_load_const<N>(args.coefs + (size_t)term.coef * N), fp);
-    acc = fp_add<N>(acc, v, fp);
+    t += m;
   }
   return acc;
 }
