@@ -343,7 +343,7 @@ def main():
                          'kernel': kernel, 'launches_per_step': wide_launches,
                          'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates)
         print(json.dumps(out))
     if world > 1:

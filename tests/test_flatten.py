@@ -1,0 +1,49 @@
+"""The flattened workspace emitted from the tape is equisatisfiable with the original statement and
+carries the same values: the reference's own acceptance test for IRFlattener
+(rust/src/consumers/flattening.rs:194-252 test_validate_flattening / test_evaluate_flattening)."""
+import pytest
+
+import circuits
+from helpers import golden_buffers
+from oracle_lib import OracleRun
+from test_host_tape import INPUTS
+import zkinterface_ir_amd as zk
+from zkinterface_ir_amd import flatten as fl
+from zkinterface_ir_amd import sieve_writer as sw
+
+
+@pytest.mark.parametrize('name', sorted(INPUTS))
+def test_flattened_relation_re_evaluates_like_the_original(name):
+    p, inst, wit = INPUTS[name]
+    bufs = golden_buffers(name)
+    ev = zk.Evaluator.from_messages(bufs)
+    mod_le = sw.int_to_le(p)
+    rel, positions = fl.flatten(ev, mod_le, boolean=(p == 2))
+    fi, fw = fl.flattened_inputs(mod_le, [sw.int_to_le(v) for v in inst], [sw.int_to_le(v) for v in wit], positions)
+    orig = OracleRun(buffers=bufs)
+    flat = OracleRun(buffers=[fi, fw, rel])
+    assert (flat.violations == []) == (orig.violations == [])
+    # simple gates only: one backend call per gate, plus the `copy` the reference inserts in front of an
+    # unweighted AssertZero (evaluator.rs:352-356) -- drop those and the two traces coincide
+    k1, _, _ = ev.tape()
+    fv, fk = flat.trace_values(), flat.trace_kinds()
+    vals, kinds_seen, pos = [], [], 0
+    for k in k1:
+        if pos >= len(fv):
+            break
+        if int(k) == 9:
+            assert fk[pos] == 'copy'
+            pos += 1
+        else:
+            vals.append(fv[pos])
+            kinds_seen.append(fk[pos])
+            pos += 1
+    n = len(orig.trace_values())
+    assert vals[:n] == orig.trace_values()
+    assert kinds_seen[:n] == orig.trace_kinds()
+    if not orig.violations:
+        assert pos == len(fv) and len(vals) == n
+    # the product records the flattened relation too, with the same asserts
+    ev2 = zk.Evaluator.from_messages([fi, fw, rel])
+    assert ev2.host_violations() == []
+    assert ev2.n_asserts == ev.n_asserts and ev2.n_value_ops == ev.n_value_ops + ev.n_asserts

@@ -172,3 +172,68 @@ def test_relation_is_split_into_100k_gate_messages():
         ev.ingest_message(m)
     assert ev.host_violations() == []
     assert ev.n_value_ops == 4096 * 51 + 64 * 4 and ev.n_asserts == 64
+
+
+def _sim_lane(ev, p, inst, wit):
+    ops, launches, consts, slot_of = ev.schedule_dump()
+    info = ev.schedule_info()
+    slots, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p,
+                                               inst, wit, shuffle_seed=3)
+    return slots, ff, slot_of, info
+
+
+def test_state_persists_across_relation_messages():
+    """Scope, functions and queues live across messages (evaluator.rs:158-170,273-284); the
+    iterator map does not (:286).  A function defined in message 1 is called from message 2."""
+    from zkinterface_ir_amd import sieve_writer as sw
+    mod = bytes([101])
+    inst = sw.write_instance(mod, [bytes([7]), bytes([9])])
+    wit = sw.write_witness(mod, [bytes([3])])
+    fn = [('sq', 1, 1, 0, 0, [('mul', 0, 1, 1)])]
+    rel1 = sw.write_relation(mod, 'arithmetic', '@function', fn, [('instance', 0), ('witness', 1), ('call', 'sq', [2], [1])])
+    rel2 = sw.write_relation(mod, 'arithmetic', '@function,@for', [], [
+        ('instance', 3), ('call', 'sq', [4], [2]),                # 3^2 = 9, 9^2 = 81
+        ('for', 'i', 0, 1, [(5, 6)], ('call', 'sq', [('add', ('name', 'i'), ('const', 5))], [('add', ('name', 'i'), ('const', 3))])),
+        ('mulc', 7, 3, bytes([100])), ('add', 8, 2, 7), ('assert_zero', 8),  # 9 - instance[1] == 0
+        ('free', 0, 8)])
+    bufs = [inst, wit, rel1, rel2]
+    ref = OracleRun(buffers=bufs)
+    assert ref.violations == [] and ref.n_live_wires() == 0
+    ev = zk.Evaluator.from_messages(bufs)
+    assert ev.host_violations() == []
+    ev.finalize(retain_all=True)
+    slots, ff, slot_of, info = _sim_lane(ev, 101, [7, 9], [3])
+    assert ff is None
+    kinds, _, _ = ev.tape()
+    vals = [program_sim.from_device_form(slots[slot_of[i]], 101, info['words_per_const'])
+            for i in range(len(kinds)) if kinds[i] != 9]
+    assert vals == ref.trace_values()
+    # an unknown iterator name is a panic in the reference (iterators.rs:399-400): latched as such
+    rel3 = sw.write_relation(mod, 'arithmetic', '@function,@for', [], [
+        ('constant', 20, bytes([2])),
+        ('for', 'i', 0, 0, [21], ('call', 'sq', [('add', ('name', 'j'), ('const', 21))], [('const', 20)]))])
+    got = zk.Evaluator.from_messages(bufs + [rel3]).host_violations()
+    ref3 = OracleRun(buffers=bufs + [rel3])
+    assert ref3.panicked and got == ref3.violations and 'Unknown iterator name j' in got[0]
+
+
+def test_sparse_wire_ids_and_empty_streams():
+    """ids beyond the dense scope range, zero instances / witnesses, and an empty relation"""
+    from zkinterface_ir_amd import sieve_writer as sw
+    mod = bytes([101])
+    big = (1 << 40) + 5
+    rel = sw.write_relation(mod, 'arithmetic', 'simple', [], [
+        ('constant', big, bytes([5])), ('constant', big + 1, bytes([96])), ('add', 2 ** 63, big, big + 1),
+        ('assert_zero', 2 ** 63), ('free', big, big + 1), ('free', 2 ** 63, None)])
+    ref = OracleRun(buffers=[rel])
+    assert ref.violations == []
+    ev = zk.Evaluator.from_messages([rel])
+    assert ev.host_violations() == [] and ev.n_instance == 0 and ev.n_witness == 0
+    ev.finalize()
+    _, ff, _, _ = _sim_lane(ev, 101, [], [])
+    assert ff is None
+    empty = sw.write_relation(mod, 'arithmetic', 'simple', [], [])
+    assert zk.Evaluator.from_messages([empty]).host_violations() == OracleRun(buffers=[empty]).violations == [
+        'Did not receive any gate to verify.']
+    # a truncated stream ends quietly (read_exact fails -> end of stream, utils.rs:27-41)
+    assert zk.Evaluator.from_messages([rel[:-3]]).host_violations() == OracleRun(buffers=[rel[:-3]]).violations

@@ -186,9 +186,13 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       a = na;
       b = nb;
     } else if (i + 1 < end) {
+      // sequential segment (e.g. the square-and-multiply ladder of a Switch weight,
+      // evaluator.rs:801-820): the next op usually consumes the value just produced -- forward it
+      // from registers instead of reading the wire table back.
+      const u32 produced = has_out ? op.dst : 0xFFFFFFFFu;
       op = args.ops[i + 1];
-      if (needs_a(op.kind)) a = wire_load<N>(T + (size_t)op.a * REC);
-      if (needs_b(op.kind)) b = wire_load<N>(T + (size_t)op.b * REC);
+      if (needs_a(op.kind)) a = (op.a == produced) ? r : wire_load<N>(T + (size_t)op.a * REC);
+      if (needs_b(op.kind)) b = (op.b == produced) ? r : wire_load<N>(T + (size_t)op.b * REC);
     }
   }
 }
