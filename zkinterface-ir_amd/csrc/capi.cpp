@@ -1,4 +1,5 @@
 // extern "C" surface declared in include/zkgpu.h.
+#include <stdlib.h>
 #include <string.h>
 
 #include <memory>
@@ -25,6 +26,7 @@ struct zkgpu_session {
   uint32_t lane_group = 0;
   int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
   bool sort_by_operand = true;
+  uint32_t n_streams = 2;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
   bool r1cs_ready = false, r1cs_on_device = false, r1cs_loaded_csr = false;
@@ -71,6 +73,7 @@ void need_engine(zkgpu_session* s) {
     e->set_writeback(s->n_pinned != 0);
     e->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
     e->set_lane_group(s->lane_group);
+    e->set_streams(s->n_streams);
     if (s->r1cs_extra_vars) e->reserve_extra_slots(s->r1cs_extra_vars);
     s->engine = std::move(e);
   }
@@ -443,6 +446,9 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       else if (v == "lds") s->bool_path = 2;
       else throw std::runtime_error("bool_path must be auto, hbm or lds");
       if (s->engine) s->engine.reset();  // re-created with the new choice on the next replay call
+    } else if (k == "streams") {
+      s->n_streams = (uint32_t)std::max(1, std::min(4, atoi(v.c_str())));
+      if (s->engine) s->engine->set_streams(s->n_streams);
     } else if (k == "sort_by_operand") {
       s->sort_by_operand = v != "0";
     } else {

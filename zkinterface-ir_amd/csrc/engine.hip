@@ -51,6 +51,17 @@ Engine::Engine() {
   hipStream_t st;
   HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   stream_ = st;
+  hipEvent_t ef;
+  HIP_OK(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+  ev_fork_ = ef;
+  for (int k = 0; k < 3; ++k) {
+    hipStream_t side;
+    hipEvent_t ej;
+    HIP_OK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    side_streams_[k] = side;
+    ev_join_[k] = ej;
+  }
   hipEvent_t e0, e1;
   HIP_OK(hipEventCreate(&e0));
   HIP_OK(hipEventCreate(&e1));
@@ -76,6 +87,11 @@ Engine::~Engine() {
   for (void* e : launch_events_) (void)hipEventDestroy((hipEvent_t)e);
   if (ev_begin_) (void)hipEventDestroy((hipEvent_t)ev_begin_);
   if (ev_end_) (void)hipEventDestroy((hipEvent_t)ev_end_);
+  if (ev_fork_) (void)hipEventDestroy((hipEvent_t)ev_fork_);
+  for (int k = 0; k < 3; ++k) {
+    if (ev_join_[k]) (void)hipEventDestroy((hipEvent_t)ev_join_[k]);
+    if (side_streams_[k]) (void)hipStreamDestroy((hipStream_t)side_streams_[k]);
+  }
   if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
 }
 
@@ -267,60 +283,79 @@ void Engine::use_device_inputs(const void* d_inst, const void* d_wit) {
   d_wit_ = d_wit;
 }
 
-void Engine::launch_range(uint32_t lb0, uint32_t lbs, bool time_each) {
-  hipStream_t st = (hipStream_t)stream_;
+void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
   const DevOp* ops = (const DevOp*)d_ops_;
   zkgpu::FieldParams fp;
   memcpy(&fp, field_params_, sizeof fp);
-  size_t ev = 0;
+  const Launch& L = sched_.launches[li];
+  const uint32_t waves = (L.count + L.ops_per_wave - 1) / L.ops_per_wave;
+  const dim3 grid((waves + 3) / 4, lbs);
+  if (boolean_) {
+    zkgpu::BoolReplayArgs a;
+    memset(&a, 0, sizeof a);
+    a.ops = (const zkgpu::TapeOp*)(ops + L.first);
+    a.n_ops = L.count;
+    a.ops_per_wave = L.ops_per_wave;
+    a.table = (zkgpu::u64*)d_table_;
+    a.n_slots = sched_.n_slots;
+    a.batch = batch_;
+    a.lb_base = lb0;
+    a.total_words = lane_blocks_ * 64;
+    a.consts = (const zkgpu::u32*)d_consts_;
+    a.packed_inst = (const zkgpu::u64*)d_packed_inst_;
+    a.packed_wit = (const zkgpu::u64*)d_packed_wit_;
+    a.first_fail = (zkgpu::u32*)d_first_fail_;
+    zkgpu::bool_replay_kernel<<<grid, 256, 0, st>>>(a);
+    return;
+  }
+  zkgpu::ReplayArgs a;
+  memset(&a, 0, sizeof a);
+  a.ops = (const zkgpu::TapeOp*)(ops + L.first);
+  a.n_ops = L.count;
+  a.ops_per_wave = L.ops_per_wave;
+  a.table = (uint4*)d_table_;
+  a.n_slots = table_slots_;
+  a.batch = batch_;
+  a.lb_base = lb0;
+  a.consts = (const zkgpu::u32*)d_consts_;
+  a.inst = (const uint8_t*)d_inst_;
+  a.wit = (const uint8_t*)d_wit_;
+  a.n_inst = n_inst_;
+  a.n_wit = n_wit_;
+  a.first_fail = (zkgpu::u32*)d_first_fail_;
+  a.lane_flags = (zkgpu::u32*)d_flags_;
+  switch (nwords_) {
+    case 2: launch_arith<2>(a, fp, L.sequential, grid, st); break;
+    case 4: launch_arith<4>(a, fp, L.sequential, grid, st); break;
+    case 6: launch_arith<6>(a, fp, L.sequential, grid, st); break;
+    case 8: launch_arith<8>(a, fp, L.sequential, grid, st); break;
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
+}
+
+void Engine::launch_range(uint32_t lb0, uint32_t lbs, bool time_each) {
+  hipStream_t st = (hipStream_t)stream_;
+  // lane blocks split into `parts` contiguous shares, one per stream; the launches of the shares are
+  // issued interleaved so that every queue always has the next level ready
+  uint32_t parts = time_each ? 1 : std::min<uint32_t>(n_streams_, lbs);
+  if (parts < 1) parts = 1;
+  uint32_t begin[kMaxStreams + 1];
+  for (uint32_t p = 0; p <= parts; ++p) begin[p] = lb0 + (uint32_t)((uint64_t)lbs * p / parts);
+  if (parts > 1) {  // fork: the side streams start after everything already queued on the main one
+    HIP_OK(hipEventRecord((hipEvent_t)ev_fork_, st));
+    for (uint32_t p = 1; p < parts; ++p)
+      HIP_OK(hipStreamWaitEvent((hipStream_t)side_streams_[p - 1], (hipEvent_t)ev_fork_, 0));
+  }
   for (size_t li = 0; li < sched_.launches.size(); ++li) {
-    const Launch& L = sched_.launches[li];
-    const uint32_t waves = (L.count + L.ops_per_wave - 1) / L.ops_per_wave;
-    const dim3 grid((waves + 3) / 4, lbs);
     if (time_each) HIP_OK(hipEventRecord((hipEvent_t)launch_events_[2 * li], st));
-    if (boolean_) {
-      zkgpu::BoolReplayArgs a;
-      memset(&a, 0, sizeof a);
-      a.ops = (const zkgpu::TapeOp*)(ops + L.first);
-      a.n_ops = L.count;
-      a.ops_per_wave = L.ops_per_wave;
-      a.table = (zkgpu::u64*)d_table_;
-      a.n_slots = sched_.n_slots;
-      a.batch = batch_;
-      a.lb_base = lb0;
-      a.total_words = lane_blocks_ * 64;
-      a.consts = (const zkgpu::u32*)d_consts_;
-      a.packed_inst = (const zkgpu::u64*)d_packed_inst_;
-      a.packed_wit = (const zkgpu::u64*)d_packed_wit_;
-      a.first_fail = (zkgpu::u32*)d_first_fail_;
-      zkgpu::bool_replay_kernel<<<grid, 256, 0, st>>>(a);
-    } else {
-      zkgpu::ReplayArgs a;
-      memset(&a, 0, sizeof a);
-      a.ops = (const zkgpu::TapeOp*)(ops + L.first);
-      a.n_ops = L.count;
-      a.ops_per_wave = L.ops_per_wave;
-      a.table = (uint4*)d_table_;
-      a.n_slots = table_slots_;
-      a.batch = batch_;
-      a.lb_base = lb0;
-      a.consts = (const zkgpu::u32*)d_consts_;
-      a.inst = (const uint8_t*)d_inst_;
-      a.wit = (const uint8_t*)d_wit_;
-      a.n_inst = n_inst_;
-      a.n_wit = n_wit_;
-      a.first_fail = (zkgpu::u32*)d_first_fail_;
-      a.lane_flags = (zkgpu::u32*)d_flags_;
-      switch (nwords_) {
-        case 2: launch_arith<2>(a, fp, L.sequential, grid, st); break;
-        case 4: launch_arith<4>(a, fp, L.sequential, grid, st); break;
-        case 6: launch_arith<6>(a, fp, L.sequential, grid, st); break;
-        case 8: launch_arith<8>(a, fp, L.sequential, grid, st); break;
-        default: throw std::runtime_error("Engine: unsupported limb count");
-      }
-    }
+    for (uint32_t p = 0; p < parts; ++p)
+      launch_one(li, begin[p], begin[p + 1] - begin[p], p == 0 ? stream_ : side_streams_[p - 1]);
     if (time_each) HIP_OK(hipEventRecord((hipEvent_t)launch_events_[2 * li + 1], st));
-    (void)ev;
+  }
+  for (uint32_t p = 1; p < parts; ++p) {  // join
+    HIP_OK(hipEventRecord((hipEvent_t)ev_join_[p - 1], (hipStream_t)side_streams_[p - 1]));
+    HIP_OK(hipStreamWaitEvent(st, (hipEvent_t)ev_join_[p - 1], 0));
   }
   HIP_OK(hipGetLastError());
 }

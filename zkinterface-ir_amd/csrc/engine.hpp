@@ -37,6 +37,10 @@ class Engine {
   // Limit how many lanes are replayed together (0 = all): lane groups run one
   // after the other so that a group's live wires stay in the 256 MiB Infinity Cache.
   void set_lane_group(uint32_t lanes) { lane_group_ = lanes; }
+  // Replay the lane blocks as `n` interleaved halves on `n` HIP streams (1..4): the levels of one
+  // half fill the kernel-boundary bubbles and wave tails of the other.
+  void set_streams(uint32_t n) { n_streams_ = n < 1 ? 1 : (n > kMaxStreams ? kMaxStreams : n); }
+  static constexpr uint32_t kMaxStreams = 4;
   // GF(2): 0 = pick automatically, 1 = force the HBM-table kernel, 2 = require the LDS-resident kernel
   void set_bool_path(int mode) { bool_path_ = mode; }
   bool uses_lds_path() const { return lds_path_; }
@@ -71,6 +75,7 @@ class Engine {
  private:
   void free_batch();
   void launch_range(uint32_t lb0, uint32_t lbs, bool time_each);
+  void launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream);
 
   Schedule sched_;  // host copy (launch list)
   bool loaded_ = false;
@@ -83,6 +88,10 @@ class Engine {
   std::vector<LaunchTiming> timings_;
 
   void* stream_ = nullptr;
+  void* side_streams_[3] = {nullptr, nullptr, nullptr};
+  void* ev_fork_ = nullptr;
+  void* ev_join_[3] = {nullptr, nullptr, nullptr};
+  uint32_t n_streams_ = 2;
   void* ev_begin_ = nullptr;
   void* ev_end_ = nullptr;
   std::vector<void*> launch_events_;
