@@ -115,7 +115,9 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s);
 /* replay lane groups of this many witnesses one after the other (0 = whole batch at once) */
 int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 
-/* options: "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a
+/* options: "max_tape_ops" = N (default 2^30: loops are unrolled, this bounds a corrupt loop bound),
+ * "streams" = 1..4 (lane shares replayed concurrently, default 2), "sort_by_operand" = 0|1,
+ * "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a
  * 32-witness slice resident in one CU's LDS when the live wires fit in 160 KiB).  Set before zkgpu_set_inputs*. */
 int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value);
 int zkgpu_uses_lds_path(zkgpu_session* s);           /* 1 / 0, -1 on error (touches the GPU) */

@@ -214,7 +214,11 @@ struct Table {
     return true;
   }
 };
-static inline uint32_t vec_len(const Buf& b, size_t v) { return b.u32(v); }
+static inline uint32_t vec_len(const Buf& b, size_t v) {
+  const uint32_t n = b.u32(v);
+  if ((size_t)n > b.n - (v + 4 <= b.n ? v + 4 : b.n)) throw Err("panic: flatbuffer vector length exceeds the message");
+  return n;
+}
 static inline Table vec_table(const Buf& b, size_t v, uint32_t i) {
   size_t e = v + 4 + 4 * (size_t)i;
   Table t;
@@ -269,7 +273,15 @@ static inline WireList wirelist_from(const Table& t) {
 }
 
 // structs/iterators.rs:35-114
+// guards of the test machine (a corrupt message may hold a zero / cyclic offset)
+struct OracleNesting {
+  static int& depth() { static thread_local int d = 0; return d; }
+  OracleNesting() { if (++depth() > 256) { --depth(); throw Err("panic: tables nested deeper than 256 levels"); } }
+  ~OracleNesting() { --depth(); }
+};
+
 static inline IterExprWireNumber iterexpr_from(const Table& t) {
+  OracleNesting guard;
   IterExprWireNumber r;
   uint8_t ty = t.get_u8(4);
   Table v = t.get_table(6);
@@ -324,6 +336,7 @@ static inline std::vector<Gate> gates_vector(const Buf& b, size_t v);
 
 // structs/gates.rs:60-259
 static inline Gate gate_from(const Table& d) {
+  OracleNesting guard;
   Gate g;
   const uint8_t ty = d.get_u8(4);
   const Table t = d.get_table(6);

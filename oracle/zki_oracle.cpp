@@ -47,8 +47,9 @@ struct PlaintextBackend {
   std::vector<BigUint> trace_val;
   uint64_t n_ops = 0, n_asserts = 0;
 
+  uint64_t max_ops = 1ull << 30;  // guard for the test machine only: a corrupt loop bound unrolls forever
   BigUint rec(TraceKind k, BigUint v) {
-    ++n_ops;
+    if (++n_ops > max_ops) throw Err("oracle guard: more than max_ops backend operations");
     if (trace_on) {
       trace_kind.push_back(k);
       trace_val.push_back(v);
@@ -125,6 +126,7 @@ static std::vector<WireId> expand_wirelist(const WireList& wl) {
       if (e.last <= e.first)
         throw Err("In WireRange, last WireId (" + std::to_string(e.last) +
                   ") must be strictly greater than first WireId (" + std::to_string(e.first) + ").");
+      if (e.last - e.first >= (1ull << 28)) throw Err("oracle guard: wire list expands to more than 2^28 wires");
       for (WireId w = e.first;; ++w) {
         out.push_back(w);
         if (w == e.last) break;
@@ -160,6 +162,7 @@ static std::vector<WireId> evaluate_iterexpr_list(const IterExprList& l, const I
       out.push_back(evaluate_iterexpr(e.first, known));
     } else {
       uint64_t a = evaluate_iterexpr(e.first, known), b = evaluate_iterexpr(e.last, known);
+      if (a <= b && b - a >= (1ull << 28)) throw Err("oracle guard: wire list expands to more than 2^28 wires");
       if (a <= b)
         for (uint64_t w = a;; ++w) {
           out.push_back(w);
@@ -209,6 +212,11 @@ static void ingest_gate(const Gate& gate, Ctx& c, Scope& scope, Iterators& known
 static void ingest_subcircuit(const std::vector<Gate>& subcircuit, Ctx& c, const std::vector<WireId>& output_list,
                               const std::vector<WireId>& input_list, Scope& scope, Iterators& known_iterators,
                               Queue& instances, Queue& witnesses, const BigUint* weight) {
+  struct Depth {  // guard of the test machine: self-recursive functions overflow the stack in the reference
+    Depth() { if (++d() > 2000) { --d(); throw Err("subcircuits nested deeper than 2000 calls"); } }
+    ~Depth() { --d(); }
+    static int& d() { static thread_local int v = 0; return v; }
+  } depth_guard;
   Scope new_scope;
   for (size_t idx = 0; idx < input_list.size(); ++idx) {
     const BigUint& i = get(scope, input_list[idx]);
@@ -553,6 +561,7 @@ void* zko_new(int trace_on) {
   return s;
 }
 void zko_free(void* h) { delete (Session*)h; }
+void zko_set_max_ops(void* h, uint64_t n) { ((Session*)h)->backend.max_ops = n; }
 
 // A buffer holding one or more size-prefixed messages (Source::from_buffers).
 void zko_ingest_buffer(void* h, const uint8_t* p, size_t n) { session_ingest_stream(*(Session*)h, p, n); }

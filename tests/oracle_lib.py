@@ -23,6 +23,7 @@ def load():
     lib.zko_new.restype = ctypes.c_void_p
     lib.zko_new.argtypes = [ctypes.c_int]
     lib.zko_free.argtypes = [ctypes.c_void_p]
+    lib.zko_set_max_ops.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
     lib.zko_ingest_buffer.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
     lib.zko_ingest_files.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
     lib.zko_n_violations.argtypes = [ctypes.c_void_p]
@@ -54,9 +55,11 @@ def load():
 class OracleRun:
     """One reference-Evaluator run over a sequence of message buffers."""
 
-    def __init__(self, buffers=None, files=None, trace=True, width=32):
+    def __init__(self, buffers=None, files=None, trace=True, width=32, max_ops=None):
         self.lib = load()
         self.h = self.lib.zko_new(1 if trace else 0)
+        if max_ops:
+            self.lib.zko_set_max_ops(self.h, max_ops)
         self.width = width
         if files is not None:
             arr = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
@@ -73,7 +76,7 @@ class OracleRun:
     @property
     def violations(self):
         n = self.lib.zko_n_violations(self.h)
-        return [self.lib.zko_violation(self.h, i).decode() for i in range(n)]
+        return [self.lib.zko_violation(self.h, i).decode('utf-8', 'replace') for i in range(n)]
 
     @property
     def panicked(self):

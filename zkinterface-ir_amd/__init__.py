@@ -148,7 +148,7 @@ class Evaluator:
 
     def _ck(self, rc):
         if rc != 0:
-            raise ZkGpuError(self.L.zkgpu_last_error(self.h).decode())
+            raise ZkGpuError(self.L.zkgpu_last_error(self.h).decode('utf-8', 'replace'))
 
     # -- Evaluator::from_messages / ingest_message ------------------------------
     def ingest_message(self, data):
@@ -160,8 +160,10 @@ class Evaluator:
         self._ck(self.L.zkgpu_ingest_paths(self.h, arr, len(paths)))
 
     @classmethod
-    def from_messages(cls, buffers):
+    def from_messages(cls, buffers, **options):
         ev = cls()
+        for k, v in options.items():
+            ev.set_option(k, str(v))
         for b in buffers:
             ev.ingest_message(b)
         return ev
@@ -173,7 +175,7 @@ class Evaluator:
         n = self.L.zkgpu_host_violations(self.h, None, 0)
         buf = ctypes.create_string_buffer(n + 1)
         self.L.zkgpu_host_violations(self.h, buf, n + 1)
-        s = buf.value.decode()
+        s = buf.value.decode('utf-8', 'replace')
         return s.split('\n') if s else []
 
     # -- tape --------------------------------------------------------------------
@@ -311,7 +313,7 @@ class Evaluator:
         n = self.L.zkgpu_lane_violations(self.h, lane, None, 0)
         buf = ctypes.create_string_buffer(n + 1)
         self.L.zkgpu_lane_violations(self.h, lane, buf, n + 1)
-        s = buf.value.decode()
+        s = buf.value.decode('utf-8', 'replace')
         return s.split('\n') if s else []
 
     def dump_trace_values(self, batch, first=0, count=None):

@@ -446,6 +446,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       else if (v == "lds") s->bool_path = 2;
       else throw std::runtime_error("bool_path must be auto, hbm or lds");
       if (s->engine) s->engine.reset();  // re-created with the new choice on the next replay call
+    } else if (k == "max_tape_ops") {
+      s->backend.set_max_ops(strtoull(v.c_str(), nullptr, 10));
     } else if (k == "streams") {
       s->n_streams = (uint32_t)std::max(1, std::min(4, atoi(v.c_str())));
       if (s->engine) s->engine->set_streams(s->n_streams);

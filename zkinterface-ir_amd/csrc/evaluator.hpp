@@ -275,6 +275,20 @@ class Evaluator {
   static void ingest_subcircuit(const Subcircuit& subcircuit, Env& e, const std::vector<WireId>& output_list,
                                 const std::vector<WireId>& input_list, Scope& scope, IteratorScope& known_iterators,
                                 Queue& instances, Queue& witnesses, const Wire* weight) {
+    // a function that (indirectly) calls itself would recurse until the stack is gone (it does in the
+    // reference); refuse at a depth no legitimate relation reaches
+    struct Depth {
+      explicit Depth(int* d) : d_(d) {
+        if (++*d_ > 2000) {
+          --*d_;
+          throw Error("subcircuits nested deeper than 2000 calls");
+        }
+      }
+      ~Depth() { --*d_; }
+      int* d_;
+    };
+    static thread_local int depth = 0;
+    Depth guard(&depth);
     Scope new_scope;
     for (size_t idx = 0; idx < input_list.size(); ++idx) {
       const Wire& i = get(scope, input_list[idx]);

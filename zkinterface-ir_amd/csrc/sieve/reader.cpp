@@ -54,6 +54,7 @@ class Bytes {
     if (at > n_ || len > n_ - at) throw Panic("flatbuffer: vector past end of message");
     return p_ + at;
   }
+  size_t size() const { return n_; }
 
  private:
   const uint8_t* p_;
@@ -99,7 +100,10 @@ class Tab {
 class Vec {  // vector of offsets to tables, or raw bytes
  public:
   Vec() = default;
-  Vec(const Bytes* b, size_t at) : b_(b), at_(at), n_(b->read<uint32_t>(at)) {}
+  Vec(const Bytes* b, size_t at) : b_(b), at_(at), n_(b->read<uint32_t>(at)) {
+    // a length that cannot fit in the message is corruption: refuse before anything is reserved
+    if ((size_t)n_ > b->size() - std::min(b->size(), at + 4)) throw Panic("flatbuffer: vector length exceeds the message");
+  }
   explicit operator bool() const { return b_ != nullptr; }
   uint32_t size() const { return n_; }
   Tab table(uint32_t i) const {
@@ -131,6 +135,21 @@ bool Tab::bytes(uint16_t slot, Value* out) const {
   out->assign(p, p + v.size());
   return true;
 }
+
+// Nested tables (iterator expressions, subcircuits) are walked recursively; a zero or cyclic offset in a
+// corrupt message must not recurse without end.
+constexpr int kMaxNesting = 256;
+struct NestingGuard {
+  explicit NestingGuard(int* d) : depth(d) {
+    if (++*depth > kMaxNesting) {
+      --*depth;
+      throw Panic("flatbuffer: tables nested deeper than 256 levels");
+    }
+  }
+  ~NestingGuard() { --*depth; }
+  int* depth;
+};
+thread_local int g_nesting = 0;
 
 WireId need_wire(const Tab& t, uint16_t slot, const char* what) {
   Tab w = t.child(slot);
@@ -180,6 +199,7 @@ WireList need_wirelist(const Tab& t, uint16_t slot, const char* what) {
 }
 
 IterExpr decode_iterexpr(const Tab& t) {  // structs/iterators.rs:35-114
+  NestingGuard guard(&g_nesting);
   IterExpr e;
   const uint8_t ty = t.scalar<uint8_t>(vt::ELEMENT_TYPE);
   Tab v = t.child(vt::ELEMENT);
@@ -268,6 +288,7 @@ CaseInvoke decode_case(const Tab& t) {  // structs/function.rs:132-172
 }
 
 Gate decode_gate(const Tab& directive) {  // structs/gates.rs:60-259
+  NestingGuard guard(&g_nesting);
   Gate g;
   const uint8_t ty = directive.scalar<uint8_t>(vt::ELEMENT_TYPE);
   if (ty == 0 || ty > (uint8_t)GateKind::For) throw Error("No gate type");
@@ -513,6 +534,16 @@ Message read_message(const uint8_t* data, size_t len) {
   return msg;
 }
 
+namespace {
+// The reference materialises every expanded list (wire.rs:178-203) and would exhaust memory on an
+// absurd range; the host refuses instead.
+constexpr uint64_t kMaxExpandedWires = 1ull << 28;
+void check_expansion(uint64_t have, uint64_t first, uint64_t last) {
+  if (last - first >= kMaxExpandedWires || have + (last - first) >= kMaxExpandedWires)
+    throw Error("wire list expands to more than 2^28 wires");
+}
+}  // namespace
+
 std::vector<WireId> expand_wirelist(const WireList& list) {
   std::vector<WireId> out;
   for (const WireRange& r : list) {
@@ -523,6 +554,7 @@ std::vector<WireId> expand_wirelist(const WireList& list) {
     if (r.last <= r.first)
       throw Error("In WireRange, last WireId (" + std::to_string(r.last) +
                   ") must be strictly greater than first WireId (" + std::to_string(r.first) + ").");
+    check_expansion(out.size(), r.first, r.last);
     for (WireId w = r.first; w <= r.last; ++w) {
       out.push_back(w);
       if (w == UINT64_MAX) break;
@@ -577,6 +609,7 @@ std::vector<WireId> evaluate_iterexpr_list(const IterExprList& list, const Itera
       continue;
     }
     const uint64_t b = eval_iterexpr(r.last, known);
+    if (a <= b) check_expansion(out.size(), a, b);
     for (uint64_t w = a; w <= b; ++w) {  // first..=last: empty when first > last
       out.push_back(w);
       if (w == UINT64_MAX) break;

@@ -130,7 +130,9 @@ TapeBackend::FieldElement TapeBackend::minus_one() const {  // evaluator.rs:881-
 }
 
 TapeBackend::Wire TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
-  if (tape_.kind.size() >= 0xFFFFFFF0u) throw Error("GPU backend: tape longer than 2^32 operations");
+  if (tape_.kind.size() >= max_ops_ || tape_.kind.size() >= 0xFFFFFFF0u)
+    throw Error("GPU backend: the relation unrolls to more than " + std::to_string(max_ops_) +
+                " backend operations (option max_tape_ops)");
   tape_.kind.push_back(kind);
   tape_.a.push_back(a);
   tape_.b.push_back(b);

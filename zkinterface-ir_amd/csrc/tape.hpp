@@ -99,6 +99,8 @@ class TapeBackend {
   static FieldElement witness_ref(uint32_t position);
 
   const Tape& tape() const { return tape_; }
+  // Loops are unrolled into the tape; a limit keeps a corrupt or hostile bound from exhausting the host.
+  void set_max_ops(uint64_t n) { max_ops_ = n; }
   const FieldHost& field() const { return field_; }
   bool field_set() const { return field_set_; }
   bool is_boolean() const { return is_boolean_; }
@@ -123,6 +125,7 @@ class TapeBackend {
   Value modulus_;
   std::map<Value, uint32_t> const_index_;
   WireId pending_assert_wire_ = 0;
+  uint64_t max_ops_ = 1ull << 30;
   std::vector<Value> lane0_instances_, lane0_witnesses_;
 };
 
