@@ -125,7 +125,7 @@ def cpu_baseline(wl, msgs, inst, wit, gates):
             'satisfied_in_sample': int(sum(ok))}
 
 
-def bench_c5(args, zk, workloads, world, rank, dist, torch):
+def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
     """BASELINE configs[4]: 2^20-row R1CS over BN254 (3+3+1 terms per row), witness batch 1024 per GPU.
     step = the row check <a,w>*<b,w> = <c,w> of every row for every lane + the count reduction."""
     M = args.width or (1 << 20)
@@ -181,10 +181,10 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch):
     elapsed = time.perf_counter() - ts
     total = list(counts)
     if world > 1:
-        t = torch.tensor(total + [0], dtype=torch.float64, device='cuda')
+        t = torch.tensor(total + [0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t)
         total = [int(t[0].item()), int(t[1].item())]
-        tm = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        tm = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         elapsed = float(tm.item())
     assert total[0] == workloads.expected_satisfied(batch * world) and total[1] == batch * world - total[0], total
@@ -243,17 +243,25 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU: the replay path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    # one process per GPU.  ZKI_DIST_BACKEND=gloo (+ several ranks on one card) is the rehearsal mode used
+    # on single-GPU boxes: same sharding and reductions, collectives on CPU tensors.
+    backend = os.environ.get('ZKI_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    red_dev = 'cuda' if backend == 'nccl' else 'cpu'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
 
     entry.build() if not os.path.exists(os.path.join(entry.PKG_DIR, 'lib', 'libzkgpu.so')) else None
     zk = entry.load_package()
     from zkinterface_ir_amd import workloads
 
     if args.workload == 'c5':
-        return bench_c5(args, zk, workloads, world, rank, dist, torch)
+        return bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev)
     if args.workload == 'c2':
         wl = workloads.ArithLayered(W=args.width or 4096, D=args.depth or 256)
         batch = args.batch_per_gpu or 1024
@@ -274,12 +282,16 @@ def main():
     wide_launches = 1 if lds else info['launches'] - info['sequential_launches']
 
     counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if world > 1 else None
+    reduced = torch.zeros(2, dtype=torch.int64, device=red_dev) if world > 1 else None
 
     def step():
         ev.replay()
         ev.synchronize()                # verdict words and counts are final on the engine's stream
         if world > 1:
-            dist.all_reduce(counts_t)   # RCCL over xGMI: {satisfied, failed}, 16 bytes
+            reduced.copy_(counts_t)     # 16 bytes out of the engine's counter words
+            dist.all_reduce(reduced)    # RCCL over xGMI: {satisfied, failed}
+            # the collective runs on RCCL's stream: finish it before the next replay resets the counters
+            torch.cuda.current_stream().synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -299,8 +311,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if world > 1:
-        total = counts_t.cpu().tolist()
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        total = reduced.cpu().tolist()
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     else:

@@ -1,0 +1,48 @@
+"""The public header is plain C and a C program can drive the recording half without a GPU."""
+import os
+import subprocess
+
+import pytest
+
+from helpers import REF_EXAMPLES, ROOT
+import zkinterface_ir_amd as zk
+
+
+def test_header_compiles_as_c99_and_c_example_records(tmp_path):
+    exe = str(tmp_path / 'evaluate_workspace')
+    subprocess.check_call(['gcc', '-std=c99', '-Wall', '-Werror', '-pedantic', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'examples', 'evaluate_workspace.c'),
+                           '-L', os.path.dirname(zk.LIB_PATH), '-lzkgpu',
+                           '-Wl,-rpath,' + os.path.dirname(zk.LIB_PATH), '-o', exe])
+    out = subprocess.check_output([exe, '--record-only'] + REF_EXAMPLES, text=True)
+    assert 'backend calls 210 (asserts 2)' in out
+
+
+@pytest.mark.gpu
+def test_c_example_and_cli_print_the_reference_verdicts(tmp_path):
+    import io
+    from zkinterface_ir_amd import cli
+    exe = str(tmp_path / 'evaluate_workspace')
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'examples', 'evaluate_workspace.c'),
+                           '-L', os.path.dirname(zk.LIB_PATH), '-lzkgpu',
+                           '-Wl,-rpath,' + os.path.dirname(zk.LIB_PATH), '-o', exe])
+    r = subprocess.run([exe] + REF_EXAMPLES, capture_output=True, text=True)
+    assert r.returncode == 0 and 'The statement is TRUE!' in r.stderr
+    err = io.StringIO()
+    assert cli.main(['evaluate'] + REF_EXAMPLES, err=err) == 0
+    assert err.getvalue() == '\nThe statement is TRUE!\n'
+    # the incorrect statement: cli.rs:557-571 text and a non-zero exit
+    import circuits
+    d = tmp_path / 'bad'
+    d.mkdir()
+    for name, buf in zip(('000_instance.sieve', '001_witness.sieve', '002_relation.sieve'),
+                         circuits.golden_case('arith_101_incorrect')):
+        (d / name).write_bytes(buf)
+    err = io.StringIO()
+    assert cli.main(['evaluate', str(d)], err=err) == 1
+    assert err.getvalue() == ('\nThe statement is NOT TRUE!\nViolations:\n'
+                              '- Wire_9 (may be weighted) should be 0, while it is not\n\n'
+                              'Error: Found 1 violations.\n')
+    r = subprocess.run([exe, str(d)], capture_output=True, text=True)
+    assert r.returncode == 1 and 'Wire_9 (may be weighted) should be 0, while it is not' in r.stderr
