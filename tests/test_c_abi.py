@@ -46,3 +46,18 @@ def test_c_example_and_cli_print_the_reference_verdicts(tmp_path):
                               'Error: Found 1 violations.\n')
     r = subprocess.run([exe, str(d)], capture_output=True, text=True)
     assert r.returncode == 1 and 'Wire_9 (may be weighted) should be 0, while it is not' in r.stderr
+
+
+def test_evaluator_template_runs_as_verifier_with_a_stub_backend(tmp_path):
+    """evaluator.rs:1007-1080: arbitrary backend (Wire = i64, all zeros), no witness message."""
+    import circuits
+    csrc = os.path.join(ROOT, 'zkinterface-ir_amd', 'csrc')
+    exe = str(tmp_path / 'verifier')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-I', csrc, os.path.join(ROOT, 'tests', 'cpp', 'test_evaluator_verifier.cpp'),
+                           os.path.join(csrc, 'sieve', 'reader.cpp'), '-o', exe])
+    inst, wit, rel = circuits.golden_case('arith_101_correct')
+    (tmp_path / 'i.sieve').write_bytes(inst)
+    (tmp_path / 'r.sieve').write_bytes(rel)
+    out = subprocess.check_output([exe, str(tmp_path / 'i.sieve'), str(tmp_path / 'r.sieve')], text=True)
+    # same backend-call count as the plaintext run (277 value calls, 6 asserts); all 6 witnesses absent
+    assert out.strip() == 'calls 277 asserts 6 witnesses_without_value 6 violations 0'

@@ -379,3 +379,16 @@ def test_r1cs_csr_rows_with_coefficients(p):
     ff, counts = ev.r1cs_results(batch)
     assert counts == (0, batch)            # the appended false row fails in every lane
     assert all(int(x) == wl.M + 1 for x in ff)
+
+
+def test_synth_workspace_round_trips_through_files_and_oracle(tmp_path):
+    """`cli.py synth c2`: a benchmark statement written as a real workspace evaluates TRUE through the
+    file Source of both the product and the oracle; the --incorrect variant is FALSE with the same text."""
+    import io
+    from zkinterface_ir_amd import cli
+    for corrupt in (False, True):
+        d = str(tmp_path / ('ws_bad' if corrupt else 'ws'))
+        assert cli.synth('c2', d, lane=3, corrupt=corrupt, err=io.StringIO()) == 0
+        ref = OracleRun(files=[d + '/002_relation.sieve', d + '/000_instance.sieve', d + '/001_witness.sieve'], trace=False)
+        assert zk.evaluate([d]) == ref.violations
+        assert (ref.violations == []) == (not corrupt)

@@ -17,10 +17,52 @@ def print_violations(errors, which_statement='The statement', what='TRUE', err=s
     return None
 
 
+def synth(kind, out_dir, lane=0, corrupt=False, err=sys.stderr):
+    """Write one statement of a benchmark workload as a workspace (000_instance / 001_witness /
+    002_relation .sieve, the naming of producers/sink.rs:84-100) that the original `zki_sieve evaluate`
+    can consume elsewhere -- the external cross-check SURVEY.md 7 H8 asks for.  The expected outputs of
+    the statement come from a GPU replay of the same relation."""
+    import os
+    import numpy as np
+    import zkinterface_ir_amd as zk
+    from zkinterface_ir_amd import workloads
+    from zkinterface_ir_amd.sieve_writer import write_instance, write_witness
+    wl = workloads.ArithLayered() if kind == 'c2' else workloads.BoolLayered()
+    inst, wit = wl.inputs(1, lane)
+    probe = zk.Evaluator()
+    probe.declare_inputs(wl.n_instance0, wl.n_witness)
+    for m in wl.relation_messages(with_epilogue=False, free_last=False):
+        probe.ingest_message(m)
+    probe.finalize()
+    probe.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), 1)
+    probe.replay()
+    probe.synchronize()
+    outs = [probe.get(w, 1)[0] for w in wl.output_wire_ids()]
+    if kind == 'c2':
+        o = np.frombuffer(b''.join(v.to_bytes(wl.width, 'little') for v in outs), dtype=np.uint8).reshape(1, wl.n_out, wl.width)
+    else:
+        o = np.array(outs, dtype=np.uint8).reshape(1, wl.n_out)
+    wl.set_expected_outputs(inst, o, lane_offset=0, corrupt_every=1 if corrupt else 0)
+    os.makedirs(out_dir, exist_ok=True)
+    w = wl.width
+    with open(os.path.join(out_dir, '000_instance.sieve'), 'wb') as f:
+        f.write(write_instance(wl.mod_le, [inst[0, k].tobytes()[:w] for k in range(wl.n_instance)]))
+    with open(os.path.join(out_dir, '001_witness.sieve'), 'wb') as f:
+        f.write(write_witness(wl.mod_le, [wit[0, k].tobytes()[:w] for k in range(wl.n_witness)]))
+    with open(os.path.join(out_dir, '002_relation.sieve'), 'wb') as f:
+        for m in wl.relation_messages():
+            f.write(m)
+    print('wrote %s workspace (lane %d, %s) to %s' % (kind, lane, 'FALSE' if corrupt else 'TRUE', out_dir), file=err)
+    return 0
+
+
 def main(argv=None, err=sys.stderr):
     argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) >= 3 and argv[0] == 'synth' and argv[1] in ('c2', 'c4'):
+        return synth(argv[1], argv[2], lane=int(argv[3]) if len(argv) > 3 else 0, corrupt='--incorrect' in argv, err=err)
     if len(argv) < 2 or argv[0] != 'evaluate':
-        print('usage: cli.py evaluate <workspace dir | file.sieve ...>', file=err)
+        print('usage: cli.py evaluate <workspace dir | file.sieve ...>\n'
+              '       cli.py synth c2|c4 <out dir> [lane] [--incorrect]', file=err)
         return 2
     import zkinterface_ir_amd as zk
     violations = zk.evaluate(argv[1:])
