@@ -392,3 +392,24 @@ def test_synth_workspace_round_trips_through_files_and_oracle(tmp_path):
         ref = OracleRun(files=[d + '/002_relation.sieve', d + '/000_instance.sieve', d + '/001_witness.sieve'], trace=False)
         assert zk.evaluate([d]) == ref.violations
         assert (ref.violations == []) == (not corrupt)
+
+
+def test_trait_level_recording_replays_on_gpu():
+    """a tape recorded call by call through zkgpu_backend_* (what the Rust `impl ZKBackend` does)"""
+    from test_host_tape import _record_through_trait
+    p = circuits.BN254_R
+    ev = zk.Evaluator()
+    handles = _record_through_trait(ev, p)
+    ev.finalize(retain_all=True)
+    lanes = [(5, 9, 28), (5, 9, 29), (0, 0, 3), (1, 0, 5), (p - 1, 1, 4)]
+    inst, wit = batch_arrays([[i0] for _, _, i0 in lanes], [[w0, w1] for w0, w1, _ in lanes], ev.elem_bytes)
+    ev.set_inputs(inst, wit, len(lanes))
+    ev.replay()
+    ev.synchronize()
+    vals = ev.dump_trace_values(len(lanes))
+    for l, (w0, w1, i0) in enumerate(lanes):
+        z = (w0 * w0 + 3 - i0) % p
+        assert vals[l][6] == z and vals[l][9] == (w1 * 7) % p and vals[l][10] == (w1 * 7 * z) % p
+        expect = [] if z == 0 else ['Wire_41 (may be weighted) should be 0, while it is not']
+        assert ev.get_violations(l) == expect
+    assert ev.counts() == (3, 2)

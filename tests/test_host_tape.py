@@ -237,3 +237,51 @@ def test_sparse_wire_ids_and_empty_streams():
         'Did not receive any gate to verify.']
     # a truncated stream ends quietly (read_exact fails -> end of stream, utils.rs:27-41)
     assert zk.Evaluator.from_messages([rel[:-3]]).host_violations() == OracleRun(buffers=[rel[:-3]]).violations
+
+
+def _record_through_trait(ev, p):
+    """z = w0*w0 + 3 - i0 ; assert z == 0 ; also a weighted-style product assert (w1 * z)"""
+    ev.backend_set_field(p.to_bytes(32, 'little'), 1, False)
+    w0 = ev.backend_witness(0)
+    w1 = ev.backend_witness(1)
+    i0 = ev.backend_instance(0)
+    sq = ev.backend_multiply(w0, w0)
+    s3 = ev.backend_add_constant(sq, bytes([3]))
+    neg = ev.backend_mul_constant(i0, (p - 1).to_bytes(32, 'little'))
+    z = ev.backend_add(s3, neg)
+    zc = ev.backend_copy(z)
+    ev.backend_assert_zero(zc, 41)
+    k = ev.backend_constant(bytes([7]))
+    wz = ev.backend_multiply(ev.backend_multiply(w1, k), z)
+    ev.backend_assert_zero(wz, 42)
+    return [w0, w1, i0, sq, s3, neg, z, zc, k, wz]
+
+
+def test_trait_level_entry_points_record_a_tape():
+    p = circuits.BN254_R
+    ev = zk.Evaluator()
+    handles = _record_through_trait(ev, p)
+    kinds, a, b = ev.tape()
+    assert [zk.KIND_NAMES[int(k)] for k in kinds] == ['witness', 'witness', 'instance', 'mul', 'addc', 'mulc', 'add', 'copy',
+                                                     'assert_zero', 'constant', 'mul', 'mul', 'assert_zero']
+    assert list(ev.assert_wires()) == [41, 42]
+    assert ev.n_instance == 1 and ev.n_witness == 2
+    ev.finalize(retain_all=True)
+    for (w0, w1, i0, fails) in [(5, 9, 28, None), (5, 9, 29, 0), (0, 0, 3, None), (1, 0, 5, 0)]:
+        slots, ff, slot_of, info = _sim_lane(ev, p, [i0], [w0, w1])
+        assert ff == fails
+        z = (w0 * w0 + 3 - i0) % p
+        assert program_sim.from_device_form(slots[slot_of[handles[6]]], p, info['words_per_const']) == z
+    # misuse is reported through the status code + zkgpu_last_error, with the reference's strings where they exist
+    ev2 = zk.Evaluator()
+    with pytest.raises(zk.ZkGpuError, match='Modulus is not initiated'):
+        ev2.backend_constant(bytes([1]))
+    with pytest.raises(zk.ZkGpuError, match='Modulus cannot be zero'):
+        ev2.backend_set_field(bytes([0]))
+    with pytest.raises(zk.ZkGpuError, match='Field should be of degree 1'):
+        ev2.backend_set_field(bytes([101]), degree=2)
+    ev2.backend_set_field(bytes([101]))
+    with pytest.raises(zk.ZkGpuError, match='p != 2'):
+        ev2.backend_and(ev2.backend_constant(bytes([1])), ev2.backend_constant(bytes([1])))
+    with pytest.raises(zk.ZkGpuError, match='non-canonical constant'):
+        ev2.backend_constant(bytes([101]))

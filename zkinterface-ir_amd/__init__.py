@@ -178,6 +178,55 @@ class Evaluator:
         s = buf.value.decode('utf-8', 'replace')
         return s.split('\n') if s else []
 
+    # -- ZKBackend trait methods (evaluator.rs:17-76), one C entry point each ------
+    def _wire(self, fn, *args):
+        out = ctypes.c_uint32(0)
+        self._ck(fn(self.h, *args, ctypes.byref(out)))
+        return out.value
+
+    def backend_set_field(self, modulus_le, degree=1, is_boolean=False):
+        m = bytes(modulus_le)
+        self._ck(self.L.zkgpu_backend_set_field(self.h, m, len(m), degree, 1 if is_boolean else 0))
+
+    def backend_copy(self, w):
+        return self._wire(self.L.zkgpu_backend_copy, w)
+
+    def backend_constant(self, value_le):
+        v = bytes(value_le)
+        return self._wire(self.L.zkgpu_backend_constant, v, len(v))
+
+    def backend_assert_zero(self, w, local_wire_id=0):
+        self._ck(self.L.zkgpu_backend_assert_zero(self.h, w, local_wire_id))
+
+    def backend_add(self, a, b):
+        return self._wire(self.L.zkgpu_backend_add, a, b)
+
+    def backend_multiply(self, a, b):
+        return self._wire(self.L.zkgpu_backend_multiply, a, b)
+
+    def backend_add_constant(self, a, c_le):
+        c = bytes(c_le)
+        return self._wire(self.L.zkgpu_backend_add_constant, a, c, len(c))
+
+    def backend_mul_constant(self, a, c_le):
+        c = bytes(c_le)
+        return self._wire(self.L.zkgpu_backend_mul_constant, a, c, len(c))
+
+    def backend_and(self, a, b):
+        return self._wire(self.L.zkgpu_backend_and, a, b)
+
+    def backend_xor(self, a, b):
+        return self._wire(self.L.zkgpu_backend_xor, a, b)
+
+    def backend_not(self, a):
+        return self._wire(self.L.zkgpu_backend_not, a)
+
+    def backend_instance(self, position):
+        return self._wire(self.L.zkgpu_backend_instance, position)
+
+    def backend_witness(self, position):
+        return self._wire(self.L.zkgpu_backend_witness, position)
+
     # -- tape --------------------------------------------------------------------
     def tape(self):
         import numpy as np
