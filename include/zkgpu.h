@@ -101,7 +101,8 @@ uint32_t zkgpu_n_witness(const zkgpu_session* s);
 /* schedule facts: out[0]=levels out[1]=launches out[2]=slots out[3]=widest level out[4]=sequential launches */
 /* ... out[5]=device ops out[6]=constant words out[7]=words per constant */
 int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]);
-/* the device program itself (host-logic tests interpret it without a GPU): ops4 = {dst,a,b,kind} per op,
+/* the device program itself (host-logic tests interpret it without a GPU): ops4 points at 8 words per op
+ * {dst, kind | a_expr << 8 | b_expr << 10, a0, a1, b0, b1, 0, 0} (expr: 0 = the slot, 1 = add(x0,x1), 2 = mul(x0,x1)),
  * launches4 = {first,count,ops_per_wave,sequential} per launch, const_words = constant pool in device form,
  * slot_of[i] = wire-table slot of tape op i (0xFFFFFFFF for asserts).  Any pointer may be NULL. */
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
@@ -117,6 +118,7 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 
 /* options: "max_tape_ops" = N (default 2^30: loops are unrolled, this bounds a corrupt loop bound),
  * "streams" = 1..4 (lane shares replayed concurrently, default 2), "sort_by_operand" = 0|1,
+ * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),
  * "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a
  * 32-witness slice resident in one CU's LDS when the live wires fit in 160 KiB).  Set before zkgpu_set_inputs*. */
 int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value);

@@ -1,5 +1,5 @@
 """Test infrastructure: interprets the *scheduled device program* exported by
-zkgpu_schedule_dump() with Python integers, launch by launch and slot by slot,
+zkgpu_schedule_dump() (8 words per op: dst, kind + operand-expression bits, a0, a1, b0, b1) with Python integers, launch by launch and slot by slot,
 exactly as the HIP kernels would (Montgomery domain for odd p, bits for p=2).
 It lets the CPU-only test tier check the host logic -- tape recording,
 levelisation, slot reuse, constant pool -- against the oracle without a GPU.
@@ -36,11 +36,21 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
         pending = []
         reads = set()
         for i in idx:
-            dst, a, b, kind = (int(x) for x in ops[i])
+            dst, kbits, a, a1, b, b1 = (int(x) for x in ops[i][:6])
+            kind, ea, eb = kbits & 0xFF, (kbits >> 8) & 3, (kbits >> 10) & 3
+
+            def operand(x0, x1, e):  # a slot, or add / mul of two slots evaluated "in registers" (gate fusion)
+                reads.add(x0)
+                v0 = slots[x0]
+                assert v0 is not None, 'read of an unwritten slot'
+                if not e:
+                    return v0
+                reads.add(x1)
+                v1 = slots[x1]
+                assert v1 is not None, 'read of an unwritten slot'
+                return (v0 + v1) % p if e == 1 else v0 * v1 * rinv % p
             if kind in (OP['add'], OP['mul'], OP['and'], OP['xor']):
-                x, y = slots[a], slots[b]
-                reads.update((a, b))
-                assert x is not None and y is not None, 'read of an unwritten slot'
+                x, y = operand(a, a1, ea), operand(b, b1, eb)
                 if kind == OP['add']:
                     r = (x + y) % p
                 elif kind == OP['mul']:

@@ -288,7 +288,7 @@ class Evaluator:
     def schedule_dump(self):
         import numpy as np
         info = self.schedule_info()
-        ops = np.zeros((info['device_ops'], 4), dtype=np.uint32)
+        ops = np.zeros((info['device_ops'], 8), dtype=np.uint32)
         launches = np.zeros((info['launches'], 4), dtype=np.uint32)
         consts = np.zeros(max(info['const_words'], 1), dtype=np.uint32)
         slot_of = np.zeros(max(self.L.zkgpu_tape_len(self.h), 1), dtype=np.uint32)

@@ -21,11 +21,13 @@ struct zkgpu_session {
   std::unique_ptr<Engine> engine;
   Schedule sched;
   bool finalized = false;
+  bool used_evaluator = false;  // messages went through the bundled Evaluator (zkgpu_ingest_* / declare_inputs)
   bool retain_all = false;
   uint32_t declared_inst = 0, declared_wit = 0;
   uint32_t lane_group = 0;
   int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
   bool sort_by_operand = true;
+  bool fuse = true;
   uint32_t n_streams = 2;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
@@ -277,6 +279,7 @@ int zkgpu_backend_witness(zkgpu_session* s, uint32_t position, uint32_t* out) {
 int zkgpu_ingest_messages(zkgpu_session* s, const uint8_t* data, size_t len) {
   return guarded(s, [&] {
     if (s->finalized) throw std::runtime_error("session already finalized");
+    s->used_evaluator = true;
     ingest_stream(s, data, len);
   });
 }
@@ -284,6 +287,7 @@ int zkgpu_ingest_messages(zkgpu_session* s, const uint8_t* data, size_t len) {
 int zkgpu_ingest_paths(zkgpu_session* s, const char* const* paths, size_t n_paths) {
   return guarded(s, [&] {
     if (s->finalized) throw std::runtime_error("session already finalized");
+    s->used_evaluator = true;
     std::vector<std::string> v(paths, paths + n_paths);
     Source src = Source::from_dirs_and_files(v);
     src.print_filenames = false;
@@ -294,6 +298,7 @@ int zkgpu_ingest_paths(zkgpu_session* s, const char* const* paths, size_t n_path
 int zkgpu_declare_inputs(zkgpu_session* s, uint32_t n_instance, uint32_t n_witness) {
   return guarded(s, [&] {
     if (s->finalized) throw std::runtime_error("session already finalized");
+    s->used_evaluator = true;
     for (uint32_t k = 0; k < n_instance; ++k) s->ev.push_instance(TapeBackend::instance_ref(s->declared_inst + k));
     for (uint32_t k = 0; k < n_witness; ++k) s->ev.push_witness(TapeBackend::witness_ref(s->declared_wit + k));
     s->declared_inst += n_instance;
@@ -303,6 +308,9 @@ int zkgpu_declare_inputs(zkgpu_session* s, uint32_t n_instance, uint32_t n_witne
 
 size_t zkgpu_host_violations(zkgpu_session* s, char* buf, size_t cap) {
   if (!s) return 0;
+  // a tape recorded through zkgpu_backend_* belongs to the caller's own Evaluator, which also owns the
+  // "Did not receive any gate to verify." bookkeeping (evaluator.rs:199-203)
+  if (!s->used_evaluator) return copy_out("", buf, cap);
   return copy_out(join_lines(s->ev.get_violations()), buf, cap);
 }
 
@@ -342,6 +350,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     ScheduleOptions opt;
     opt.retain_all = retain_all != 0;
     opt.sort_by_operand = s->sort_by_operand;
+    opt.fuse = s->fuse;
     s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
     s->n_pinned = opt.pinned.size();
     s->sched = build_schedule(s->backend.tape(), s->backend.field(), opt);
@@ -371,7 +380,7 @@ int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]) {
   out[2] = s->sched.n_slots;
   out[3] = s->sched.max_level_width;
   for (const Launch& l : s->sched.launches) out[4] += l.sequential ? 1 : 0;
-  out[5] = s->sched.ops.size();
+  out[5] = s->sched.fused ? s->sched.ops2.size() : s->sched.ops.size();
   out[6] = s->sched.const_words.size();
   out[7] = s->sched.words_per_const;
   return 0;
@@ -381,7 +390,19 @@ int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launch
                         uint32_t* slot_of) {
   if (!s || !s->finalized) return 1;
   const Schedule& sc = s->sched;
-  if (ops4 && !sc.ops.empty()) memcpy(ops4, sc.ops.data(), sc.ops.size() * sizeof(DevOp));
+  // ops8: {dst, kind(+operand-expression bits), a0, a1, b0, b1, 0, 0} per op, fused or not
+  if (ops4) {
+    uint32_t* o = ops4;
+    if (sc.fused) {
+      memcpy(o, sc.ops2.data(), sc.ops2.size() * sizeof(DevOp2));
+    } else {
+      for (size_t i = 0; i < sc.ops.size(); ++i) {
+        const DevOp& d = sc.ops[i];
+        const uint32_t w[8] = {d.dst, d.kind, d.a, 0, d.b, 0, 0, 0};
+        memcpy(o + 8 * i, w, sizeof w);
+      }
+    }
+  }
   if (launches4)
     for (size_t i = 0; i < sc.launches.size(); ++i) {
       launches4[4 * i + 0] = sc.launches[i].first;
@@ -451,6 +472,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "streams") {
       s->n_streams = (uint32_t)std::max(1, std::min(4, atoi(v.c_str())));
       if (s->engine) s->engine->set_streams(s->n_streams);
+    } else if (k == "fuse") {
+      s->fuse = v != "0";
     } else if (k == "sort_by_operand") {
       s->sort_by_operand = v != "0";
     } else {
@@ -523,8 +546,9 @@ size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t 
     fetch_results(s);
     if (lane >= s->first_fail.size()) throw std::runtime_error("lane out of range");
     // evaluator.rs:199-208 for this lane: the first error in execution order wins
-    for (const std::string& m : s->ev.get_violations())
-      if (!s->ev.has_error() || m != s->ev.error()) v.push_back(m);  // "Did not receive any gate to verify."
+    if (s->used_evaluator)
+      for (const std::string& m : s->ev.get_violations())
+        if (!s->ev.has_error() || m != s->ev.error()) v.push_back(m);  // "Did not receive any gate to verify."
     const uint32_t ff = s->first_fail[lane];
     if (s->flags[lane] & ZKGPU_LANE_NONCANONICAL) {
       v.push_back("GPU backend: an instance or witness value is not canonical (>= field characteristic); "

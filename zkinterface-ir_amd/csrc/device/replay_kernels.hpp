@@ -197,6 +197,87 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
   }
 }
 
+// 32-byte program entry of the fused schedule (host: DevOp2, schedule.hpp)
+struct TapeOp2 {
+  u32 dst, kind, a0, a1, b0, b1, pad0, pad1;
+};
+
+struct ReplayArgs2 {
+  const TapeOp2* ops;
+  u32 n_ops;
+  u32 ops_per_wave;
+  uint4* table;
+  u32 n_slots;
+  u32 batch;
+  u32 lb_base;
+  const u32* consts;
+  const uint8_t* inst;
+  const uint8_t* wit;
+  u32 n_inst;
+  u32 n_wit;
+  u32* first_fail;
+  u32* lane_flags;
+};
+
+// Replay of the fused schedule: an Add/Mul operand may be `add(a0,a1)` / `mul(a0,a1)` evaluated in
+// registers -- the absorbed producer's value never goes to the wire table (one 32-B store and one
+// 32-B load less per fused pair).  All gathers of an op are issued before the arithmetic.
+template <int N>
+__global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 args, const FieldParams fp) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 lb = args.lb_base + blockIdx.y;
+  const u32 gw = blockIdx.x * (blockDim.x >> 6) + wave;
+  const u32 begin = gw * args.ops_per_wave;
+  if (begin >= args.n_ops) return;
+  const u32 end = min(args.n_ops, begin + args.ops_per_wave);
+  const u32 lane_g = lb * 64 + lane;
+  const bool lane_valid = lane_g < args.batch;
+  uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
+  constexpr int REC = Layout<N>::kRecord;
+  for (u32 i = begin; i < end; ++i) {
+    const TapeOp2 op = args.ops[i];
+    const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
+    Fp<N> r;
+    bool has_out = true;
+    switch (kind) {
+      case OP_ADD:
+      case OP_MUL: {
+        Fp<N> x0 = wire_load<N>(T + (size_t)op.a0 * REC), x1, y0 = wire_load<N>(T + (size_t)op.b0 * REC), y1;
+        if (ea) x1 = wire_load<N>(T + (size_t)op.a1 * REC);
+        if (eb) y1 = wire_load<N>(T + (size_t)op.b1 * REC);
+        if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp) : fp_mul<N>(x0, x1, fp);
+        if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp) : fp_mul<N>(y0, y1, fp);
+        r = kind == OP_ADD ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
+        break;
+      }
+      case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+      case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+      case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
+      case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
+      case OP_INSTANCE:
+      case OP_WITNESS: {
+        const bool is_inst = kind == OP_INSTANCE;
+        Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0,
+                                  lane_valid);
+        if (fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+        r = fp_to_mont<N>(raw, fp);
+        break;
+      }
+      case OP_ASSERT: {
+        has_out = false;
+        const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC));
+        if (__ballot(nz && lane_valid) != 0ull) {
+          if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b0);
+        }
+        break;
+      }
+      default: has_out = false; break;
+    }
+    if (has_out) wire_store<N>(T + (size_t)op.dst * REC, r);
+  }
+}
+
 // Final verdict reduction: satisfied = lanes with no failing assert and no flag.
 // counts[0] += satisfied, counts[1] += failed (u64 each), one atomic per wave.
 __global__ __launch_bounds__(256) void verdict_kernel(const u32* __restrict__ first_fail,

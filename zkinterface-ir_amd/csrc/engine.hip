@@ -21,6 +21,7 @@ void check(hipError_t e, const char* what) {
 #define HIP_OK(x) check((x), #x)
 
 static_assert(sizeof(DevOp) == sizeof(zkgpu::TapeOp), "DevOp must match the device TapeOp");
+static_assert(sizeof(DevOp2) == sizeof(zkgpu::TapeOp2), "DevOp2 must match the device TapeOp2");
 static_assert(sizeof(R1csRowDev) == sizeof(zkgpu::R1csRow) && sizeof(R1csTermDev) == sizeof(zkgpu::R1csTerm),
               "host and device R1CS records must match");
 static_assert(sizeof(zkgpu::FieldParams) <= 128, "FieldParams must fit Engine::field_params_");
@@ -130,7 +131,10 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   fp.nwords = f.nwords;
   memset(field_params_, 0, sizeof field_params_);
   memcpy(field_params_, &fp, sizeof fp);
-  if (!s.ops.empty()) {
+  if (s.fused) {
+    HIP_OK(hipMalloc(&d_ops_, s.ops2.size() * sizeof(DevOp2)));
+    HIP_OK(hipMemcpy(d_ops_, s.ops2.data(), s.ops2.size() * sizeof(DevOp2), hipMemcpyHostToDevice));
+  } else if (!s.ops.empty()) {
     HIP_OK(hipMalloc(&d_ops_, s.ops.size() * sizeof(DevOp)));
     HIP_OK(hipMemcpy(d_ops_, s.ops.data(), s.ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
   }
@@ -307,6 +311,32 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.packed_wit = (const zkgpu::u64*)d_packed_wit_;
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     zkgpu::bool_replay_kernel<<<grid, 256, 0, st>>>(a);
+    return;
+  }
+  if (sched_.fused) {
+    zkgpu::ReplayArgs2 a;
+    memset(&a, 0, sizeof a);
+    a.ops = (const zkgpu::TapeOp2*)d_ops_ + L.first;
+    a.n_ops = L.count;
+    a.ops_per_wave = L.ops_per_wave;
+    a.table = (uint4*)d_table_;
+    a.n_slots = table_slots_;
+    a.batch = batch_;
+    a.lb_base = lb0;
+    a.consts = (const zkgpu::u32*)d_consts_;
+    a.inst = (const uint8_t*)d_inst_;
+    a.wit = (const uint8_t*)d_wit_;
+    a.n_inst = n_inst_;
+    a.n_wit = n_wit_;
+    a.first_fail = (zkgpu::u32*)d_first_fail_;
+    a.lane_flags = (zkgpu::u32*)d_flags_;
+    switch (nwords_) {
+      case 2: zkgpu::replay_fused_kernel<2><<<grid, 256, 0, st>>>(a, fp); break;
+      case 4: zkgpu::replay_fused_kernel<4><<<grid, 256, 0, st>>>(a, fp); break;
+      case 6: zkgpu::replay_fused_kernel<6><<<grid, 256, 0, st>>>(a, fp); break;
+      case 8: zkgpu::replay_fused_kernel<8><<<grid, 256, 0, st>>>(a, fp); break;
+      default: throw std::runtime_error("Engine: unsupported limb count");
+    }
     return;
   }
   zkgpu::ReplayArgs a;

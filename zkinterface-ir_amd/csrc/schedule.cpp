@@ -87,15 +87,48 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
     if (h < n) last_use[h] = kInf;
   s.n_levels = n_levels;
 
+  // ---- gate fusion ---------------------------------------------------------
+  // An Add/Mul whose value has exactly one reader, itself an Add/Mul, is evaluated inside that reader
+  // (depth 1: an op that absorbs cannot be absorbed, an absorbed op has absorbed nothing).  The value is
+  // then never materialised, so this is only done when nobody can ask for it afterwards.
+  std::vector<uint8_t> absorbed(n, 0);
+  const bool fuse = opt.fuse && !opt.retain_all && !s.boolean_path;
+  if (fuse) {
+    std::vector<uint32_t> reads(n, 0), reader(n, 0);
+    std::vector<uint8_t> has_absorbed(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      const int ni = n_inputs(tape.kind[i]);
+      if (ni >= 1) { ++reads[tape.a[i]]; reader[tape.a[i]] = (uint32_t)i; }
+      if (ni == 2) { ++reads[tape.b[i]]; reader[tape.b[i]] = (uint32_t)i; }
+    }
+    auto arith = [&](size_t i) { return tape.kind[i] == TK_ADD || tape.kind[i] == TK_MUL; };
+    for (size_t i = 0; i < n; ++i) {
+      if (!arith(i) || reads[i] != 1 || last_use[i] == kInf || has_absorbed[i]) continue;
+      const uint32_t c = reader[i];
+      if (!arith(c) || absorbed[c]) continue;
+      absorbed[i] = 1;
+      has_absorbed[c] = 1;
+      ++s.n_absorbed;
+      // the producer's operands are now read at the consumer's level
+      last_use[tape.a[i]] = std::max(last_use[tape.a[i]] == kInf ? kInf : last_use[tape.a[i]], level[c]);
+      last_use[tape.b[i]] = std::max(last_use[tape.b[i]] == kInf ? kInf : last_use[tape.b[i]], level[c]);
+    }
+    s.fused = s.n_absorbed != 0;
+  }
+  auto eff_kind = [&](size_t i) -> uint8_t { return absorbed[i] ? (uint8_t)TK_NOP : tape.kind[i]; };
+
   // ---- order ops by (level, kind): counting sort ------------------------
   constexpr uint32_t kKinds = TK_NOT + 1;
   std::vector<uint64_t> bucket((size_t)n_levels * kKinds + 1, 0);
-  for (size_t i = 0; i < n; ++i) ++bucket[(size_t)level[i] * kKinds + tape.kind[i] + 1];
+  size_t n_live = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (!absorbed[i]) { ++bucket[(size_t)level[i] * kKinds + tape.kind[i] + 1]; ++n_live; }
   for (size_t k = 1; k < bucket.size(); ++k) bucket[k] += bucket[k - 1];
-  std::vector<uint32_t> order(n);
+  std::vector<uint32_t> order(n_live);
   {
     std::vector<uint64_t> cursor(bucket.begin(), bucket.end() - 1);
-    for (size_t i = 0; i < n; ++i) order[cursor[(size_t)level[i] * kKinds + tape.kind[i]]++] = (uint32_t)i;
+    for (size_t i = 0; i < n; ++i)
+      if (!absorbed[i]) order[cursor[(size_t)level[i] * kKinds + tape.kind[i]]++] = (uint32_t)i;
   }
   std::vector<uint64_t> level_start(n_levels + 1);
   for (uint32_t l = 0; l <= n_levels; ++l) level_start[l] = bucket[(size_t)l * kKinds];
@@ -118,7 +151,9 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
         while (e < level_start[l + 1] && tape.kind[order[e]] == kind) ++e;
         if (n_inputs(kind) >= 1 && e - k > 1)
           std::stable_sort(order.begin() + k, order.begin() + e, [&](uint32_t x, uint32_t y) {
-            return s.slot_of[tape.a[x]] < s.slot_of[tape.a[y]];
+            const uint32_t ax = absorbed[tape.a[x]] ? tape.a[tape.a[x]] : tape.a[x];
+            const uint32_t ay = absorbed[tape.a[y]] ? tape.a[tape.a[y]] : tape.a[y];
+            return s.slot_of[ax] < s.slot_of[ay];
           });
         k = e;
       }
@@ -143,8 +178,45 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   s.n_slots = std::max<uint32_t>(n_slots, 1);
 
   // ---- device ops ----------------------------------------------------------
-  s.ops.resize(n);
-  for (size_t k = 0; k < n; ++k) {
+  (void)eff_kind;
+  if (s.fused) {
+    s.ops2.resize(n_live);
+    for (size_t k = 0; k < n_live; ++k) {
+      const uint32_t i = order[k];
+      const uint8_t kind = tape.kind[i];
+      DevOp2 d{0, kind, 0, 0, 0, 0, 0, 0};
+      d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
+      auto operand = [&](uint32_t h, uint32_t* x0, uint32_t* x1, int shift) {
+        if (absorbed[h]) {
+          *x0 = s.slot_of[tape.a[h]];
+          *x1 = s.slot_of[tape.b[h]];
+          d.kind |= (tape.kind[h] == TK_ADD ? 1u : 2u) << shift;
+        } else {
+          *x0 = s.slot_of[h];
+        }
+      };
+      switch (kind) {
+        case TK_ADD: case TK_MUL:
+          operand(tape.a[i], &d.a0, &d.a1, 8);
+          operand(tape.b[i], &d.b0, &d.b1, 10);
+          break;
+        case TK_ADDC: case TK_MULC:
+          d.a0 = s.slot_of[tape.a[i]];
+          d.b0 = tape.b[i];
+          break;
+        case TK_COPY: case TK_NOT: d.a0 = s.slot_of[tape.a[i]]; break;
+        case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a0 = tape.a[i]; break;
+        case TK_ASSERT:
+          d.a0 = s.slot_of[tape.a[i]];
+          d.b0 = tape.b[i];
+          break;
+        default: break;
+      }
+      s.ops2[k] = d;
+    }
+  }
+  s.ops.resize(s.fused ? 0 : n_live);
+  for (size_t k = 0; k < n_live && !s.fused; ++k) {
     const uint32_t i = order[k];
     DevOp d{0, 0, 0, tape.kind[i]};
     const uint8_t kind = tape.kind[i];

@@ -18,6 +18,14 @@ struct DevOp {  // == zkgpu::TapeOp (device/replay_kernels.hpp)
   uint32_t dst, a, b, kind;
 };
 
+// Program entry when gate fusion is on: an Add/Mul operand may itself be an Add/Mul of two slots that is
+// evaluated in registers (the absorbed producer is never written to the wire table).
+//   kind: bits 0-7 main op (TapeKind), bits 8-9 / 10-11: operand a / b is 0 = slot a0 / b0,
+//         1 = add(a0,a1), 2 = mul(a0,a1)
+struct DevOp2 {  // == zkgpu::TapeOp2 (device/replay_kernels.hpp)
+  uint32_t dst, kind, a0, a1, b0, b1, pad0, pad1;
+};
+
 struct Launch {
   uint32_t first = 0;         // index into Schedule::ops
   uint32_t count = 0;
@@ -30,11 +38,15 @@ struct ScheduleOptions {
   bool retain_all = false;          // every value keeps its own slot (wire dumps for parity tests)
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
   bool sort_by_operand = true;      // order a level's ops by first-operand slot (cache locality)
+  bool fuse = true;                 // absorb single-reader Add/Mul producers into their consumer (never with retain_all)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
 };
 
 struct Schedule {
   std::vector<DevOp> ops;
+  std::vector<DevOp2> ops2;         // used instead of `ops` when fused
+  bool fused = false;
+  uint64_t n_absorbed = 0;
   std::vector<Launch> launches;
   std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)
   std::vector<uint32_t> level_of;   // per tape op
