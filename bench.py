@@ -351,6 +351,8 @@ def main():
                        'relation_messages': host['messages'], 'relation_bytes': host['relation_bytes'],
                        'backend_ops_per_witness': int(len(kinds)), 'levels': info['levels'],
                        'launches_per_step': info['launches'], 'wire_table_slots': info['slots'],
+                       'program_entries': info['device_ops'],
+                       'gates_evaluated_inside_their_reader': int(len(kinds)) - info['device_ops'],
                        'wire_table_MB': round(ev.table_bytes / 1e6, 1), 'lane_group': args.lane_group,
                        'parallelism': 'witness lanes sharded over %d GPU(s); one all-reduce of 2 x u64' % world,
                        'satisfied': total[0], 'failed': total[1], 'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')}},

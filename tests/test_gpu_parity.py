@@ -193,6 +193,47 @@ def test_full_size_c2_properties():
         assert ev.get_violations(lane) == ref.violations
 
 
+@pytest.mark.parametrize('seed', range(25, 45))
+def test_random_structured_relations_on_gpu_compact_schedule(seed):
+    """same fuzz through the production schedule (slot reuse, operand ordering, gate fusion, two
+    streams): violation strings, counts and the surviving top-level wires against the oracle."""
+    from random_circuits import Gen
+    from test_fuzz_host import FIELDS
+    p, boolean = FIELDS[seed % len(FIELDS)]
+    g = Gen(seed, p, boolean)
+    rel, mod_le = g.relation(n_top=14)
+    lanes = 130
+    rows_i, rows_w = g.lane_inputs(lanes, seed + 1000)
+    ev = zk.Evaluator()
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    ev.ingest_message(rel)
+    ev.finalize(retain_all=False)
+    inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+    ev.set_inputs(inst if g.n_inst else None, wit if g.n_wit else None, lanes)
+    ev.replay()
+    ev.synchronize()
+    n_ok = 0
+    for lane in range(0, lanes, 3):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32, trace=False)
+        assert ev.get_violations(lane) == ref.violations, (seed, lane)
+    first, _ = ev.lane_results(lanes)
+    for lane in range(lanes):
+        n_ok += int(first[lane]) == zk.NO_FAIL
+    assert ev.counts() == (n_ok, lanes - n_ok)
+    # Evaluator::get on wires still alive at the end (pinned: never fused away, never overwritten)
+    ref = oracle_lane(mod_le, rows_i[0], rows_w[0], [rel], 32, trace=False)
+    if not ref.violations:
+        checked = 0
+        for wid in range(0, 60):
+            want = ref.get(wid)
+            got = ev.get(wid, lanes)
+            assert (want is None) == (got is None), (seed, wid)
+            if want is not None:
+                assert got[0] == want, (seed, wid)
+                checked += 1
+        assert checked > 0
+
+
 @pytest.mark.parametrize('seed', range(25))
 def test_random_structured_relations_on_gpu(seed):
     """functions / for / switch / nested switch / frees: every lane's wire values and violation
