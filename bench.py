@@ -45,7 +45,7 @@ def pmc_traffic(width, batch, nwords_bytes):
         d = json.load(open(PMC_TRAFFIC_JSON))
     except (OSError, ValueError):
         return None, None
-    if d.get('grid_size_filter') != width * batch:
+    if d.get('workload') != 'c2' or (width, batch) != (4096, 1024):
         return None, None
     return d['traffic_bytes_per_launch'], os.path.relpath(PMC_TRAFFIC_JSON, ROOT)
 
@@ -335,7 +335,7 @@ def main():
             dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
             wl_name = ('BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
                        'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
-            kernel = 'replay_kernel<8,false>'
+            kernel = 'replay_fused_kernel<8>' if info['device_ops'] < len(kinds) else 'replay_kernel<8,false>'
         else:
             metric = 'gate-ops/sec (whole node), GF(2), 10M-gate And/Xor/Not relation, bit-packed batched witnesses'
             dtype = 'u1 (GF(2), %d witnesses per word)' % (32 if lds else 64)

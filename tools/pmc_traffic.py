@@ -4,20 +4,23 @@ dominant kernel, applying the gfx950 corrections of MI355X_MICROARCH.md (HBM sec
 are in KiB; FETCH_SIZE reports half of the bytes of wide coalesced streaming reads -> doubled;
 WRITE_SIZE is exact for 16-B-per-lane stores.
 
-  tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [grid_size]
+  tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> \
+                       [min_grid_size] [kernel name substring] [workload tag]
+Launches of the kernel with at least min_grid_size threads are averaged (the level launches of the
+workload; the few tiny launches are left out).
 """
 import csv
 import json
 import sys
 
 
-def collect(path, counter, kernel_substr, grid_size):
+def collect(path, counter, kernel_substr, min_grid):
     vals, durs = [], []
     with open(path) as f:
         for row in csv.DictReader(f):
             if row['Counter_Name'] != counter or kernel_substr not in row['Kernel_Name']:
                 continue
-            if grid_size and int(row['Grid_Size']) != grid_size:
+            if min_grid and int(row['Grid_Size']) < min_grid:
                 continue
             vals.append(float(row['Counter_Value']))
             durs.append(int(row['End_Timestamp']) - int(row['Start_Timestamp']))
@@ -27,13 +30,14 @@ def collect(path, counter, kernel_substr, grid_size):
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
     grid = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-    kern = 'replay_kernel<8, false>'
+    kern = sys.argv[5] if len(sys.argv) > 5 else 'replay_fused_kernel<8>'
+    tag = sys.argv[6] if len(sys.argv) > 6 else 'c2'
     fv, fd = collect(fetch_csv, 'FETCH_SIZE', kern, grid)
     wv, wd = collect(write_csv, 'WRITE_SIZE', kern, grid)
     fetch_kib = sum(fv) / len(fv)
     write_kib = sum(wv) / len(wv)
     res = {
-        'kernel': kern, 'grid_size_filter': grid, 'launches_fetch_pass': len(fv), 'launches_write_pass': len(wv),
+        'kernel': kern, 'min_grid_size': grid, 'workload': tag, 'launches_fetch_pass': len(fv), 'launches_write_pass': len(wv),
         'FETCH_SIZE_KiB_avg': fetch_kib, 'WRITE_SIZE_KiB_avg': write_kib,
         'fetch_bytes_corrected': 2 * fetch_kib * 1024, 'write_bytes': write_kib * 1024,
         'traffic_bytes_per_launch': 2 * fetch_kib * 1024 + write_kib * 1024,
