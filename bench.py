@@ -106,7 +106,7 @@ def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, stream
     return ev, inst, wit, n_bad, msgs, host
 
 
-def cpu_baseline(wl, msgs, inst, wit, gates):
+def cpu_baseline(wl, msgs, inst, wit, gates, ev=None):
     """The oracle (literal restatement of the reference Evaluator + PlaintextBackend) on this
     box's host cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -120,7 +120,18 @@ def cpu_baseline(wl, msgs, inst, wit, gates):
     lanes = int(min(inst.shape[0], max(threads, min(4 * threads, (15.0 / per_lane) * threads))))
     ok, secs, ops = oracle_lib.eval_batch(rel, wl.mod_le, inst[:lanes].tobytes(), wl.n_instance,
                                           wit[:lanes].tobytes(), wl.n_witness, wl.width, lanes, threads)
-    return {'value': gates * lanes / secs, 'unit': 'gate-ops/s', 'cores': threads, 'kind': 'port',
+    extra = {}
+    if wl.p != 2 and ev is not None:
+        # BASELINE.md section 3 `cpu_opt`: flat array + 64-bit Montgomery on the recorded tape, same threads
+        kinds, a, b = ev.tape()
+        opt_lanes = int(min(inst.shape[0], 16 * threads))
+        _, osecs, _ = oracle_lib.opt_eval(kinds, a, b, ev.constants(), wl.mod_le, inst[:opt_lanes].tobytes(),
+                                          wl.n_instance, wit[:opt_lanes].tobytes(), wl.n_witness, wl.width, opt_lanes,
+                                          threads)
+        extra = {'cpu_opt': {'value': gates * opt_lanes / osecs, 'unit': 'gate-ops/s', 'cores': threads,
+                             'what': 'optimised CPU evaluator (flat wire array, 4x64 Montgomery, flattened tape), '
+                                     '%d witnesses in %.1f s' % (opt_lanes, osecs)}}
+    return {**extra, 'value': gates * lanes / secs, 'unit': 'gate-ops/s', 'cores': threads, 'kind': 'port',
             'sample': '%d witnesses of the same %d-gate relation, one reference-style Evaluator run per witness, '
                       '%d threads, %.1f s wall (single witness: %.2f s)' % (lanes, gates, threads, secs, per_lane),
             'satisfied_in_sample': int(sum(ok))}
@@ -367,7 +378,7 @@ def main():
                          'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates)
+            out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates, ev)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

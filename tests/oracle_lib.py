@@ -49,7 +49,33 @@ def load():
                                    ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32,
                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p,
                                    ctypes.POINTER(ctypes.c_uint64)]
+    lib.zko_opt_eval.restype = ctypes.c_double
+    lib.zko_opt_eval.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p,
+                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p,
+                                 ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                 ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
     return lib
+
+
+def opt_eval(kinds, a, b, constants, modulus_le, inst, n_inst, wit, n_wit, width, batch, threads, dump_lane=None):
+    """`cpu_opt`: flat-array Montgomery evaluation of a recorded tape (oracle/cpu_opt.cpp).
+    Returns (first_fail uint32[batch], seconds, values of dump_lane or None)."""
+    import numpy as np
+    lib = load()
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    cw = max([len(c) for c in constants] + [1])
+    cbytes = b''.join(bytes(c) + bytes(cw - len(c)) for c in constants) or b'\x00'
+    ff = np.zeros(batch, dtype=np.uint32)
+    vals = np.zeros((len(kinds), 32), dtype=np.uint8) if dump_lane is not None else None
+    secs = lib.zko_opt_eval(kinds.ctypes.data, a.ctypes.data, b.ctypes.data, len(kinds), cbytes, cw, len(constants),
+                            modulus_le, len(modulus_le), inst, n_inst, wit, n_wit, width, batch, threads,
+                            ff.ctypes.data, vals.ctypes.data if vals is not None else None, dump_lane or 0)
+    out = None
+    if vals is not None:
+        out = [int.from_bytes(vals[i].tobytes(), 'little') for i in range(len(kinds)) if kinds[i] != 9]
+    return ff, secs, out
 
 
 class OracleRun:

@@ -184,6 +184,12 @@ def test_full_size_c2_properties():
     ev.synchronize()
     grouped = ev.lane_results(batch)
     assert np.array_equal(first[0], grouped[0])
+    # every lane against the optimised CPU evaluator (oracle/cpu_opt.cpp; itself pinned to the literal oracle)
+    from oracle_lib import opt_eval
+    kinds, ta, tb = ev.tape()
+    ff_cpu, _, _ = opt_eval(kinds, ta, tb, ev.constants(), wl.mod_le, inst.tobytes(), wl.n_instance, wit.tobytes(),
+                            wl.n_witness, wl.width, batch, 16)
+    assert np.array_equal(ff_cpu, first[0])
     # two sampled lanes of the full relation against the oracle (a good and a corrupted one)
     msgs = wl.relation_messages()
     for lane in (5, 97):

@@ -68,3 +68,27 @@ def test_missing_inputs():
     assert OracleRun(buffers=[wit, rel]).violations == ['Not enough instance to consume']
     run = OracleRun(buffers=[inst, rel])  # PlaintextBackend panics on a missing witness (evaluator.rs:944-946)
     assert run.panicked and 'Missing witness value' in run.violations[0]
+
+
+def test_cpu_opt_agrees_with_the_literal_oracle():
+    """oracle/cpu_opt.cpp (flat array + 64-bit Montgomery on the recorded tape) against the literal
+    restatement: every value and the first failing assert, arithmetic goldens over two fields."""
+    import zkinterface_ir_amd as zk
+    from helpers import le_values
+    from oracle_lib import opt_eval
+    for name, p, inst, wit in [('arith_bn254_correct', circuits.BN254_R, [25, 0, 1], [3, 4, 0, 17711]),
+                               ('arith_101_correct', 101, [25, 0, 1], [3, 4, 0, 36]),
+                               ('arith_101_incorrect', 101, [25, 0, 1], [3, 5, 1, 40])]:
+        bufs = golden_buffers(name)
+        ev = zk.Evaluator.from_messages(bufs)
+        kinds, a, b = ev.tape()
+        mod_le = p.to_bytes(32, 'little')
+        ff, _, vals = opt_eval(kinds, a, b, ev.constants(), mod_le, le_values(inst, 32), len(inst), le_values(wit, 32),
+                               len(wit), 32, 1, 1, dump_lane=0)
+        ref = OracleRun(buffers=bufs)
+        rv = ref.trace_values()
+        assert vals[:len(rv)] == rv
+        if ref.violations:
+            assert ref.violations == ['Wire_%d (may be weighted) should be 0, while it is not' % int(ev.assert_wires()[int(ff[0])])]
+        else:
+            assert int(ff[0]) == 0xFFFFFFFF
