@@ -118,9 +118,6 @@ def lib():
     return L
 
 
-EXPORTED_SYMBOLS = None  # filled lazily by exported_symbols()
-
-
 def exported_symbols():
     return sorted(lib()._signatures.keys())
 

@@ -34,13 +34,11 @@ void dfree(T*& p) {
   }
 }
 
+// The scheduler always emits ops_per_wave = 1 for a level (measured fastest) and one wave per lane block
+// for sequential segments; neither wants the in-wave operand prefetch variant (PIPE, kept for tools/kbench).
 template <int N>
-void launch_arith(const zkgpu::ReplayArgs& a, const zkgpu::FieldParams& fp, bool sequential, dim3 grid,
-                  hipStream_t st) {
-  if (sequential || a.ops_per_wave == 1)
-    zkgpu::replay_kernel<N, false><<<grid, 256, 0, st>>>(a, fp);
-  else
-    zkgpu::replay_kernel<N, true><<<grid, 256, 0, st>>>(a, fp);
+void launch_arith(const zkgpu::ReplayArgs& a, const zkgpu::FieldParams& fp, bool, dim3 grid, hipStream_t st) {
+  zkgpu::replay_kernel<N, false><<<grid, 256, 0, st>>>(a, fp);
 }
 
 }  // namespace

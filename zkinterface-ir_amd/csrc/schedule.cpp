@@ -115,7 +115,6 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
     }
     s.fused = s.n_absorbed != 0;
   }
-  auto eff_kind = [&](size_t i) -> uint8_t { return absorbed[i] ? (uint8_t)TK_NOP : tape.kind[i]; };
 
   // ---- order ops by (level, kind): counting sort ------------------------
   constexpr uint32_t kKinds = TK_NOT + 1;
@@ -178,7 +177,6 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   s.n_slots = std::max<uint32_t>(n_slots, 1);
 
   // ---- device ops ----------------------------------------------------------
-  (void)eff_kind;
   if (s.fused) {
     s.ops2.resize(n_live);
     for (size_t k = 0; k < n_live; ++k) {

@@ -443,11 +443,10 @@ std::string file_name(const std::string& path) {
 
 uint16_t parse_gate_set(const std::string& gateset) {
   uint16_t ret = 0;
-  bool done = false;
   for_each_token(gateset, [&](const std::string& raw) {
     const std::string s = without_spaces(raw);
-    if (s == "arithmetic") { ret = mask::ARITH; done = true; return true; }
-    if (s == "boolean") { ret = mask::BOOL; done = true; return true; }
+    if (s == "arithmetic") { ret = mask::ARITH; return true; }  // short-circuits (relation.rs:149)
+    if (s == "boolean") { ret = mask::BOOL; return true; }
     if (s == "@add") ret |= mask::ADD;
     else if (s == "@addc") ret |= mask::ADDC;
     else if (s == "@mul") ret |= mask::MUL;
@@ -458,7 +457,6 @@ uint16_t parse_gate_set(const std::string& gateset) {
     else if (!s.empty()) throw Error("Unable to parse the following gateset: " + gateset);
     return false;
   });
-  (void)done;
   return ret;
 }
 
