@@ -63,7 +63,8 @@ def _batched_example(modulus, lanes):
     return rows_i, rows_w
 
 
-@pytest.mark.parametrize('modulus', [101, circuits.BN254_R, 2 ** 61 - 1, 2 ** 127 - 1])
+@pytest.mark.parametrize('modulus', [101, circuits.BN254_R, 2 ** 61 - 1, 2 ** 127 - 1, circuits.P320,
+                                     circuits.BLS12_381_Q])
 def test_batched_example_matches_oracle_per_lane(modulus):
     """One relation, many (instance, witness) pairs: lane i == i-th reference run."""
     lanes = 70  # spans two 64-lane blocks, ragged tail
@@ -90,6 +91,7 @@ def test_batched_example_matches_oracle_per_lane(modulus):
         n_ok += not ref.violations
     assert ev.counts() == (n_ok, lanes - n_ok)
     assert 0 < n_ok < lanes
+    assert w == 8 * ((modulus.bit_length() + 63) // 64)
 
 
 def test_noncanonical_inputs_are_flagged_not_guessed():

@@ -76,6 +76,28 @@ def test_scheduled_program_matches_oracle(name, retain):
         assert info['slots'] < ev.n_value_ops  # liveness actually reuses slots
 
 
+@pytest.mark.parametrize('p', [circuits.P320, circuits.BLS12_381_Q])
+def test_fields_wider_than_256_bits(p):
+    """five- and six-limb fields (up to 384 bits) through recording, scheduling and the interpreter"""
+    inst, wit, rel = circuits.arith_example(p)
+    bufs = [inst, wit, rel]
+    ref = OracleRun(buffers=bufs, width=48)
+    assert ref.violations == []
+    for retain in (True, False):
+        ev = zk.Evaluator.from_messages(bufs)
+        assert ev.host_violations() == [] and ev.elem_bytes == 8 * ((p.bit_length() + 63) // 64)
+        ev.finalize(retain_all=retain)
+        slots, ff, slot_of, info = _sim_lane(ev, p, [25, 0, 1], [3, 4, 0, 17711])
+        assert ff is None and info['words_per_const'] == ev.elem_bytes // 4
+        if retain:
+            kinds, _, _ = ev.tape()
+            vals = [program_sim.from_device_form(slots[slot_of[i]], p, info['words_per_const'])
+                    for i in range(len(kinds)) if kinds[i] != 9]
+            assert vals == ref.trace_values()
+    too_wide = circuits.arith_example(2 ** 400 + 1)[2]
+    assert any('wider than 384 bits' in m for m in zk.Evaluator.from_messages([too_wide]).host_violations())
+
+
 def test_reader_file_ordering_and_framing(tmp_path):
     # Source::from_filenames ordering (source.rs:69-89): name sort, then instance < witness < relation
     ev = zk.Evaluator()

@@ -158,10 +158,10 @@ CoefMap device_coefs(const std::vector<Value>& coefs, const FieldHost& f) {
   CoefMap m;
   m.index.resize(coefs.size());
   for (size_t i = 0; i < coefs.size(); ++i) {
-    uint32_t r[8], mont[8];
+    uint32_t r[kFieldWords], mont[kFieldWords];
     f.reduce(coefs[i], r);
     bool zero = true, one = r[0] == 1;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kFieldWords; ++k) {
       zero &= r[k] == 0;
       if (k) one &= r[k] == 0;
     }
@@ -597,8 +597,8 @@ int zkgpu_r1cs_from_tape(zkgpu_session* s, int use_correction) {
     if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
     if (s->backend.field().is_two) throw std::runtime_error("R1CS conversion on the GPU path needs an odd field characteristic");
     const Tape& t = s->backend.tape();
-    Value modulus(32, 0);
-    for (int i = 0; i < 32; ++i) modulus[i] = (uint8_t)(s->backend.field().p[i / 4] >> (8 * (i % 4)));
+    Value modulus(4 * kFieldWords, 0);
+    for (int i = 0; i < 4 * kFieldWords; ++i) modulus[i] = (uint8_t)(s->backend.field().p[i / 4] >> (8 * (i % 4)));
     s->r1cs = r1cs_from_tape(t, s->backend.field(), modulus, use_correction != 0);
     s->r1cs_ready = true;
     s->r1cs_loaded_csr = false;

@@ -8,7 +8,7 @@
 // 32x32 (v_mad_u64_u32).  All results are canonical (< p), which is what makes
 // from_mont(x) bit-identical to the reference's reduced BigUint.
 //
-// Requirements: p odd, p < 2^(32*N).  p = 2 is handled by the Boolean path.
+// Requirements: p odd, p < 2^(32*N), N <= 12 (384 bits).  p = 2 is handled by the Boolean path.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,7 +18,7 @@ namespace zkgpu {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-constexpr int kMaxWords = 8;  // 256-bit fields
+constexpr int kMaxWords = 12;  // fields up to 384 bits
 
 // Per-field constants, passed by value in the kernarg segment (wave-uniform:
 // the compiler keeps them in SGPRs).
@@ -27,7 +27,7 @@ struct FieldParams {
   u32 r2[kMaxWords];   // R^2 mod p   (to_mont multiplier)
   u32 one[kMaxWords];  // R mod p     (Montgomery form of 1)
   u32 n0inv;           // -p^{-1} mod 2^32
-  u32 nwords;          // N actually used (2, 4, 6 or 8)
+  u32 nwords;          // N actually used (2, 4, ..., 12)
 };
 
 template <int N>

@@ -24,7 +24,7 @@ static_assert(sizeof(DevOp) == sizeof(zkgpu::TapeOp), "DevOp must match the devi
 static_assert(sizeof(DevOp2) == sizeof(zkgpu::TapeOp2), "DevOp2 must match the device TapeOp2");
 static_assert(sizeof(R1csRowDev) == sizeof(zkgpu::R1csRow) && sizeof(R1csTermDev) == sizeof(zkgpu::R1csTerm),
               "host and device R1CS records must match");
-static_assert(sizeof(zkgpu::FieldParams) <= 128, "FieldParams must fit Engine::field_params_");
+static_assert(sizeof(zkgpu::FieldParams) <= 192, "FieldParams must fit Engine::field_params_");
 
 template <typename T>
 void dfree(T*& p) {
@@ -86,6 +86,10 @@ Engine::~Engine() {
   for (void* e : launch_events_) (void)hipEventDestroy((hipEvent_t)e);
   if (ev_begin_) (void)hipEventDestroy((hipEvent_t)ev_begin_);
   if (ev_end_) (void)hipEventDestroy((hipEvent_t)ev_end_);
+  for (int k = 0; k < 2; ++k) {
+    if (h_stage_[k]) (void)hipHostFree(h_stage_[k]);
+    if (ev_stage_[k]) (void)hipEventDestroy((hipEvent_t)ev_stage_[k]);
+  }
   if (ev_fork_) (void)hipEventDestroy((hipEvent_t)ev_fork_);
   for (int k = 0; k < 3; ++k) {
     if (ev_join_[k]) (void)hipEventDestroy((hipEvent_t)ev_join_[k]);
@@ -273,10 +277,39 @@ void Engine::upload_inputs(const uint8_t* inst, const uint8_t* wit) {
   if (wb && !wit) throw std::runtime_error("Engine: witness values missing");
   if (!d_inst_own_) HIP_OK(hipMalloc(&d_inst_own_, std::max<size_t>(ib, 64)));
   if (!d_wit_own_) HIP_OK(hipMalloc(&d_wit_own_, std::max<size_t>(wb, 64)));
-  if (ib) HIP_OK(hipMemcpy(d_inst_own_, inst, ib, hipMemcpyHostToDevice));
-  if (wb) HIP_OK(hipMemcpy(d_wit_own_, wit, wb, hipMemcpyHostToDevice));
+  if (ib) staged_upload(d_inst_own_, inst, ib);
+  if (wb) staged_upload(d_wit_own_, wit, wb);
   d_inst_ = d_inst_own_;
   d_wit_ = d_wit_own_;
+}
+
+// Host -> HBM through two pinned staging buffers: the CPU copy of chunk k overlaps the DMA of chunk k-1.
+// (A plain hipMemcpy from pageable memory measured ~4 GB/s here.)
+void Engine::staged_upload(void* dst, const uint8_t* src, size_t bytes) {
+  constexpr size_t kChunk = 16u << 20;
+  hipStream_t st = (hipStream_t)stream_;
+  for (int k = 0; k < 2; ++k) {
+    if (!h_stage_[k]) HIP_OK(hipHostMalloc(&h_stage_[k], kChunk, hipHostMallocDefault));
+    if (!ev_stage_[k]) {
+      hipEvent_t e;
+      HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev_stage_[k] = e;
+    }
+  }
+  size_t done = 0;
+  int k = 0;
+  bool used[2] = {false, false};
+  while (done < bytes) {
+    const size_t n = std::min(kChunk, bytes - done);
+    if (used[k]) HIP_OK(hipEventSynchronize((hipEvent_t)ev_stage_[k]));  // buffer k free again
+    memcpy(h_stage_[k], src + done, n);
+    HIP_OK(hipMemcpyAsync((uint8_t*)dst + done, h_stage_[k], n, hipMemcpyHostToDevice, st));
+    HIP_OK(hipEventRecord((hipEvent_t)ev_stage_[k], st));
+    used[k] = true;
+    done += n;
+    k ^= 1;
+  }
+  HIP_OK(hipStreamSynchronize(st));
 }
 
 void Engine::use_device_inputs(const void* d_inst, const void* d_wit) {
@@ -333,6 +366,8 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
       case 4: zkgpu::replay_fused_kernel<4><<<grid, 256, 0, st>>>(a, fp); break;
       case 6: zkgpu::replay_fused_kernel<6><<<grid, 256, 0, st>>>(a, fp); break;
       case 8: zkgpu::replay_fused_kernel<8><<<grid, 256, 0, st>>>(a, fp); break;
+      case 10: zkgpu::replay_fused_kernel<10><<<grid, 256, 0, st>>>(a, fp); break;
+      case 12: zkgpu::replay_fused_kernel<12><<<grid, 256, 0, st>>>(a, fp); break;
       default: throw std::runtime_error("Engine: unsupported limb count");
     }
     return;
@@ -358,6 +393,8 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     case 4: launch_arith<4>(a, fp, L.sequential, grid, st); break;
     case 6: launch_arith<6>(a, fp, L.sequential, grid, st); break;
     case 8: launch_arith<8>(a, fp, L.sequential, grid, st); break;
+    case 10: launch_arith<10>(a, fp, L.sequential, grid, st); break;
+    case 12: launch_arith<12>(a, fp, L.sequential, grid, st); break;
     default: throw std::runtime_error("Engine: unsupported limb count");
   }
 }
@@ -517,7 +554,7 @@ void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
     else zkgpu::r1cs_row_kernel<N, false><<<grid, 256, 0, st>>>(a, fp);                \
     break;
   switch (nwords_) {
-    ZK_R1CS(2) ZK_R1CS(4) ZK_R1CS(6) ZK_R1CS(8)
+    ZK_R1CS(2) ZK_R1CS(4) ZK_R1CS(6) ZK_R1CS(8) ZK_R1CS(10) ZK_R1CS(12)
     default: throw std::runtime_error("Engine: unsupported limb count");
   }
 #undef ZK_R1CS
@@ -588,6 +625,8 @@ void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>
       case 4: zkgpu::dump_slots_kernel<4><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
       case 6: zkgpu::dump_slots_kernel<6><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
       case 8: zkgpu::dump_slots_kernel<8><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 10: zkgpu::dump_slots_kernel<10><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
+      case 12: zkgpu::dump_slots_kernel<12><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
       default: break;
     }
   }

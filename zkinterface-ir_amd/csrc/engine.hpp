@@ -76,6 +76,7 @@ class Engine {
   void free_batch();
   void launch_range(uint32_t lb0, uint32_t lbs, bool time_each);
   void launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream);
+  void staged_upload(void* dst, const uint8_t* src, size_t bytes);
 
   Schedule sched_;  // host copy (launch list)
   bool loaded_ = false;
@@ -107,6 +108,8 @@ class Engine {
   const void* d_wit_ = nullptr;
   void* d_packed_inst_ = nullptr;  // GF(2) path
   void* d_packed_wit_ = nullptr;
+  void* h_stage_[2] = {nullptr, nullptr};  // pinned staging for host -> HBM input uploads
+  void* ev_stage_[2] = {nullptr, nullptr};
   void* d_r1cs_rows_ = nullptr;
   void* d_r1cs_terms_ = nullptr;
   void* d_r1cs_coefs_ = nullptr;
@@ -128,7 +131,7 @@ class Engine {
   // pinned wires (Evaluator::get) need the LDS-resident values written back to HBM
   void set_writeback(bool on) { force_writeback_ = on; }
  private:
-  unsigned char field_params_[128];  // zkgpu::FieldParams, opaque here
+  unsigned char field_params_[192];  // zkgpu::FieldParams, opaque here
 };
 
 }  // namespace zki

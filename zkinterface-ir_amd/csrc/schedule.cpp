@@ -46,7 +46,7 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
     s.words_per_const = field.nwords;
     s.const_words.assign((size_t)n_consts * field.nwords, 0);
     for (uint32_t i = 0; i < n_consts; ++i) {
-      uint32_t r[8], m[8];
+      uint32_t r[kFieldWords], m[kFieldWords];
       field.reduce(tape.consts[i], r);
       field.to_mont(r, m);
       memcpy(&s.const_words[(size_t)i * field.nwords], m, 4 * field.nwords);

@@ -12,14 +12,15 @@ const char* tape_kind_name(uint8_t k) {
 
 // ---------------------------------------------------------------- FieldHost
 namespace {
+constexpr int W = kFieldWords;
 bool geq8(const uint32_t* a, const uint32_t* b) {
-  for (int i = 7; i >= 0; --i)
+  for (int i = W - 1; i >= 0; --i)
     if (a[i] != b[i]) return a[i] > b[i];
   return true;
 }
 void sub8(uint32_t* a, const uint32_t* b) {
   uint64_t borrow = 0;
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < W; ++i) {
     const uint64_t d = (uint64_t)a[i] - b[i] - borrow;
     a[i] = (uint32_t)d;
     borrow = (d >> 63) & 1;
@@ -32,10 +33,10 @@ size_t significant_bytes(const Value& v) {
 }
 }  // namespace
 
-void FieldHost::add(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) const {
-  uint32_t r[8];
+void FieldHost::add(const uint32_t a[W], const uint32_t b[W], uint32_t out[W]) const {
+  uint32_t r[W];
   uint64_t c = 0;
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < W; ++i) {
     c += (uint64_t)a[i] + b[i];
     r[i] = (uint32_t)c;
     c >>= 32;
@@ -48,9 +49,9 @@ void FieldHost::init(const Value& modulus_le) {
   *this = FieldHost();
   const size_t n = significant_bytes(modulus_le);
   if (n == 0) throw Error("Modulus cannot be zero.");  // evaluator.rs:868-869
-  if (n > 32) throw Error("GPU backend: field characteristic wider than 256 bits is not supported");
+  if (n > 4 * (size_t)W) throw Error("GPU backend: field characteristic wider than 384 bits is not supported");
   for (size_t i = 0; i < n; ++i) p[i / 4] |= (uint32_t)modulus_le[i] << (8 * (i % 4));
-  for (int i = 7; i >= 0 && bits == 0; --i)
+  for (int i = W - 1; i >= 0 && bits == 0; --i)
     if (p[i]) bits = 32 * i + (32 - __builtin_clz(p[i]));
   if (bits == 2 && p[0] == 2) {
     is_two = true;
@@ -61,7 +62,7 @@ void FieldHost::init(const Value& modulus_le) {
   if (bits < 2) throw Error("GPU backend: field characteristic 1 is not supported");
   nwords = 2 * ((bits + 63) / 64);
   // R = 2^(32*nwords).  one = R mod p by doubling; r2 = R^2 mod p the same way.
-  uint32_t x[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t x[W] = {1};
   for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
   memcpy(one, x, sizeof x);
   for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
@@ -73,15 +74,15 @@ void FieldHost::init(const Value& modulus_le) {
 
 bool FieldHost::is_canonical(const Value& v) const {
   const size_t n = significant_bytes(v);
-  if (n > 32) return false;
-  uint32_t w[8] = {0};
+  if (n > 4 * (size_t)W) return false;
+  uint32_t w[W] = {0};
   for (size_t i = 0; i < n; ++i) w[i / 4] |= (uint32_t)v[i] << (8 * (i % 4));
   return !geq8(w, p);
 }
 
-void FieldHost::reduce(const Value& v, uint32_t out[8]) const {
-  uint32_t r[8] = {0};
-  const uint32_t one_[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+void FieldHost::reduce(const Value& v, uint32_t out[W]) const {
+  uint32_t r[W] = {0};
+  const uint32_t one_[W] = {1};
   const size_t n = significant_bytes(v);
   for (size_t bit = n * 8; bit-- > 0;) {
     add(r, r, r);
@@ -90,8 +91,8 @@ void FieldHost::reduce(const Value& v, uint32_t out[8]) const {
   memcpy(out, r, sizeof r);
 }
 
-void FieldHost::to_mont(const uint32_t in[8], uint32_t out[8]) const {
-  uint32_t x[8];
+void FieldHost::to_mont(const uint32_t in[W], uint32_t out[W]) const {
+  uint32_t x[W];
   memcpy(x, in, sizeof x);
   for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
   memcpy(out, x, sizeof x);

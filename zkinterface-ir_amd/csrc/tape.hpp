@@ -22,21 +22,23 @@ const char* tape_kind_name(uint8_t k);  // names of SURVEY.md Appendix A ("copy"
 
 constexpr uint32_t kNoWire = 0xFFFFFFFFu;
 
-// Host-side description of GF(p), p < 2^256: limbs and Montgomery constants
+constexpr int kFieldWords = 12;  // 32-bit words of the widest supported field (384 bits)
+
+// Host-side description of GF(p), p < 2^384: limbs and Montgomery constants
 // for the device (device/fp_mont.hpp FieldParams), plus canonicalisation of
 // arbitrary-length little-endian Values.
 struct FieldHost {
-  uint32_t nwords = 0;          // 32-bit words in use: 2, 4, 6 or 8 (64-bit limb granularity)
+  uint32_t nwords = 0;          // 32-bit words in use: 2, 4, ..., 12 (64-bit limb granularity)
   uint32_t bits = 0;
   bool is_two = false;          // p == 2: Boolean/bit-packed path, no Montgomery form
-  uint32_t p[8] = {0}, r2[8] = {0}, one[8] = {0};
+  uint32_t p[kFieldWords] = {0}, r2[kFieldWords] = {0}, one[kFieldWords] = {0};
   uint32_t n0inv = 0;
 
   void init(const Value& modulus_le);                         // throws zki::Error if unsupported
   bool is_canonical(const Value& v) const;                    // v < p as integers
-  void reduce(const Value& v, uint32_t out[8]) const;         // v mod p
-  void to_mont(const uint32_t in[8], uint32_t out[8]) const;  // in * R mod p
-  void add(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) const;
+  void reduce(const Value& v, uint32_t out[kFieldWords]) const;         // v mod p
+  void to_mont(const uint32_t in[kFieldWords], uint32_t out[kFieldWords]) const;  // in * R mod p
+  void add(const uint32_t a[kFieldWords], const uint32_t b[kFieldWords], uint32_t out[kFieldWords]) const;
 };
 
 struct Tape {
