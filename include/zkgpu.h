@@ -119,6 +119,7 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 /* options: "max_tape_ops" = N (default 2^30: loops are unrolled, this bounds a corrupt loop bound),
  * "streams" = 1..4 (lane shares replayed concurrently, default 2), "sort_by_operand" = 0|1,
  * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),
+ * "propagate_copies" = 0|1 (readers use a copy's source, unobserved copies are not materialised; never with retain_all),
  * "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a
  * 32-witness slice resident in one CU's LDS when the live wires fit in 160 KiB).  Set before zkgpu_set_inputs*. */
 int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value);

@@ -28,6 +28,7 @@ struct zkgpu_session {
   int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
   bool sort_by_operand = true;
   bool fuse = true;
+  bool propagate_copies = true;
   uint32_t n_streams = 2;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
@@ -351,6 +352,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     opt.retain_all = retain_all != 0;
     opt.sort_by_operand = s->sort_by_operand;
     opt.fuse = s->fuse;
+    opt.propagate_copies = s->propagate_copies;
     s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
     s->n_pinned = opt.pinned.size();
     s->sched = build_schedule(s->backend.tape(), s->backend.field(), opt);
@@ -472,6 +474,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "streams") {
       s->n_streams = (uint32_t)std::max(1, std::min(4, atoi(v.c_str())));
       if (s->engine) s->engine->set_streams(s->n_streams);
+    } else if (k == "propagate_copies") {
+      s->propagate_copies = v != "0";
     } else if (k == "fuse") {
       s->fuse = v != "0";
     } else if (k == "sort_by_operand") {

@@ -53,6 +53,35 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
     }
   }
 
+  // ---- copy propagation ------------------------------------------------------
+  // The reference's scoping (ingest_subcircuit, evaluator.rs:698-746) copies every input into and every
+  // output out of a call / loop body / switch branch: about half of the backend calls of a structured
+  // relation are copies.  A copy has the value of its source, so readers are pointed at the source and a
+  // copy nobody can observe any more is not materialised.  Copies that must stay
+  // readable (retain_all dumps, wires alive at the end) are kept.
+  std::vector<uint32_t> opa(tape.a), opb(tape.b);
+  std::vector<uint8_t> absorbed(n, 0);  // 1 = evaluated inside its reader (fusion), 2 = elided copy
+  const bool propagate = opt.propagate_copies && !opt.retain_all;
+  if (propagate) {
+    std::vector<uint8_t> is_pinned(n, 0);
+    for (uint32_t h : opt.pinned)
+      if (h < n) is_pinned[h] = 1;
+    std::vector<uint32_t> root(n);
+    for (size_t i = 0; i < n; ++i) {
+      root[i] = (uint32_t)i;
+      if (tape.kind[i] == TK_COPY) root[i] = root[tape.a[i]];  // source of the whole copy chain
+    }
+    for (size_t i = 0; i < n; ++i) {
+      const int ni = n_inputs(tape.kind[i]);
+      if (ni >= 1) opa[i] = root[tape.a[i]];
+      if (ni == 2) opb[i] = root[tape.b[i]];
+      if (tape.kind[i] == TK_COPY && !is_pinned[i]) {
+        absorbed[i] = 2;
+        ++s.n_copies_elided;
+      }
+    }
+  }
+
   // ---- dependency levels (ASAP for ops with inputs) ----------------------
   std::vector<uint32_t>& level = s.level_of;
   std::vector<uint32_t> first_use(n, kInf), last_use(n, 0);
@@ -60,25 +89,27 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   for (size_t i = 0; i < n; ++i) {
     const int ni = n_inputs(tape.kind[i]);
     uint32_t lv = 0;
-    if (ni >= 1) lv = level[tape.a[i]] + 1;
-    if (ni == 2) lv = std::max(lv, level[tape.b[i]] + 1);
+    if (ni >= 1) lv = level[opa[i]] + 1;
+    if (ni == 2) lv = std::max(lv, level[opb[i]] + 1);
     level[i] = lv;
   }
   // sources (constant / instance / witness) are produced as late as possible:
   // one level before their first reader, so they do not occupy a slot early.
   for (size_t i = 0; i < n; ++i) {
+    if (absorbed[i]) continue;  // an elided copy reads nothing
     const int ni = n_inputs(tape.kind[i]);
-    if (ni >= 1) first_use[tape.a[i]] = std::min(first_use[tape.a[i]], level[i]);
-    if (ni == 2) first_use[tape.b[i]] = std::min(first_use[tape.b[i]], level[i]);
+    if (ni >= 1) first_use[opa[i]] = std::min(first_use[opa[i]], level[i]);
+    if (ni == 2) first_use[opb[i]] = std::min(first_use[opb[i]], level[i]);
   }
   for (size_t i = 0; i < n; ++i)
     if (n_inputs(tape.kind[i]) == 0 && tape.kind[i] != TK_NOP)
       level[i] = first_use[i] == kInf ? 0 : first_use[i] - 1;
   uint32_t n_levels = 0;
   for (size_t i = 0; i < n; ++i) {
+    if (absorbed[i]) continue;
     const int ni = n_inputs(tape.kind[i]);
-    if (ni >= 1) { last_use[tape.a[i]] = std::max(last_use[tape.a[i]], level[i]); used[tape.a[i]] = 1; }
-    if (ni == 2) { last_use[tape.b[i]] = std::max(last_use[tape.b[i]], level[i]); used[tape.b[i]] = 1; }
+    if (ni >= 1) { last_use[opa[i]] = std::max(last_use[opa[i]], level[i]); used[opa[i]] = 1; }
+    if (ni == 2) { last_use[opb[i]] = std::max(last_use[opb[i]], level[i]); used[opb[i]] = 1; }
     n_levels = std::max(n_levels, level[i] + 1);
   }
   for (size_t i = 0; i < n; ++i)
@@ -91,27 +122,27 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   // An Add/Mul whose value has exactly one reader, itself an Add/Mul, is evaluated inside that reader
   // (depth 1: an op that absorbs cannot be absorbed, an absorbed op has absorbed nothing).  The value is
   // then never materialised, so this is only done when nobody can ask for it afterwards.
-  std::vector<uint8_t> absorbed(n, 0);
   const bool fuse = opt.fuse && !opt.retain_all && !s.boolean_path;
   if (fuse) {
     std::vector<uint32_t> reads(n, 0), reader(n, 0);
     std::vector<uint8_t> has_absorbed(n, 0);
     for (size_t i = 0; i < n; ++i) {
+      if (absorbed[i]) continue;
       const int ni = n_inputs(tape.kind[i]);
-      if (ni >= 1) { ++reads[tape.a[i]]; reader[tape.a[i]] = (uint32_t)i; }
-      if (ni == 2) { ++reads[tape.b[i]]; reader[tape.b[i]] = (uint32_t)i; }
+      if (ni >= 1) { ++reads[opa[i]]; reader[opa[i]] = (uint32_t)i; }
+      if (ni == 2) { ++reads[opb[i]]; reader[opb[i]] = (uint32_t)i; }
     }
     auto arith = [&](size_t i) { return tape.kind[i] == TK_ADD || tape.kind[i] == TK_MUL; };
     for (size_t i = 0; i < n; ++i) {
-      if (!arith(i) || reads[i] != 1 || last_use[i] == kInf || has_absorbed[i]) continue;
+      if (absorbed[i] || !arith(i) || reads[i] != 1 || last_use[i] == kInf || has_absorbed[i]) continue;
       const uint32_t c = reader[i];
       if (!arith(c) || absorbed[c]) continue;
       absorbed[i] = 1;
       has_absorbed[c] = 1;
       ++s.n_absorbed;
       // the producer's operands are now read at the consumer's level
-      last_use[tape.a[i]] = std::max(last_use[tape.a[i]] == kInf ? kInf : last_use[tape.a[i]], level[c]);
-      last_use[tape.b[i]] = std::max(last_use[tape.b[i]] == kInf ? kInf : last_use[tape.b[i]], level[c]);
+      last_use[opa[i]] = std::max(last_use[opa[i]] == kInf ? kInf : last_use[opa[i]], level[c]);
+      last_use[opb[i]] = std::max(last_use[opb[i]] == kInf ? kInf : last_use[opb[i]], level[c]);
     }
     s.fused = s.n_absorbed != 0;
   }
@@ -150,8 +181,8 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
         while (e < level_start[l + 1] && tape.kind[order[e]] == kind) ++e;
         if (n_inputs(kind) >= 1 && e - k > 1)
           std::stable_sort(order.begin() + k, order.begin() + e, [&](uint32_t x, uint32_t y) {
-            const uint32_t ax = absorbed[tape.a[x]] ? tape.a[tape.a[x]] : tape.a[x];
-            const uint32_t ay = absorbed[tape.a[y]] ? tape.a[tape.a[y]] : tape.a[y];
+            const uint32_t ax = absorbed[opa[x]] ? opa[opa[x]] : opa[x];
+            const uint32_t ay = absorbed[opa[y]] ? opa[opa[y]] : opa[y];
             return s.slot_of[ax] < s.slot_of[ay];
           });
         k = e;
@@ -186,8 +217,8 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
       d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
       auto operand = [&](uint32_t h, uint32_t* x0, uint32_t* x1, int shift) {
         if (absorbed[h]) {
-          *x0 = s.slot_of[tape.a[h]];
-          *x1 = s.slot_of[tape.b[h]];
+          *x0 = s.slot_of[opa[h]];
+          *x1 = s.slot_of[opb[h]];
           d.kind |= (tape.kind[h] == TK_ADD ? 1u : 2u) << shift;
         } else {
           *x0 = s.slot_of[h];
@@ -195,18 +226,18 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
       };
       switch (kind) {
         case TK_ADD: case TK_MUL:
-          operand(tape.a[i], &d.a0, &d.a1, 8);
-          operand(tape.b[i], &d.b0, &d.b1, 10);
+          operand(opa[i], &d.a0, &d.a1, 8);
+          operand(opb[i], &d.b0, &d.b1, 10);
           break;
         case TK_ADDC: case TK_MULC:
-          d.a0 = s.slot_of[tape.a[i]];
-          d.b0 = tape.b[i];
+          d.a0 = s.slot_of[opa[i]];
+          d.b0 = opb[i];
           break;
-        case TK_COPY: case TK_NOT: d.a0 = s.slot_of[tape.a[i]]; break;
-        case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a0 = tape.a[i]; break;
+        case TK_COPY: case TK_NOT: d.a0 = s.slot_of[opa[i]]; break;
+        case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a0 = opa[i]; break;
         case TK_ASSERT:
-          d.a0 = s.slot_of[tape.a[i]];
-          d.b0 = tape.b[i];
+          d.a0 = s.slot_of[opa[i]];
+          d.b0 = opb[i];
           break;
         default: break;
       }
@@ -221,27 +252,27 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
     d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
     switch (kind) {
       case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR:
-        d.a = s.slot_of[tape.a[i]];
-        d.b = s.slot_of[tape.b[i]];
+        d.a = s.slot_of[opa[i]];
+        d.b = s.slot_of[opb[i]];
         break;
       case TK_ADDC: case TK_MULC:
-        d.a = s.slot_of[tape.a[i]];
-        d.b = tape.b[i];
+        d.a = s.slot_of[opa[i]];
+        d.b = opb[i];
         break;
-      case TK_COPY: case TK_NOT: d.a = s.slot_of[tape.a[i]]; break;
-      case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a = tape.a[i]; break;
+      case TK_COPY: case TK_NOT: d.a = s.slot_of[opa[i]]; break;
+      case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a = opa[i]; break;
       case TK_ASSERT:
-        d.a = s.slot_of[tape.a[i]];
-        d.b = tape.b[i];
+        d.a = s.slot_of[opa[i]];
+        d.b = opb[i];
         break;
       default: break;
     }
     if (s.boolean_path) {  // arithmetic mod 2 on {0,1}: (a+b)%2 = xor, (a*b)%2 = and
       if (kind == TK_ADD) d.kind = TK_XOR;
       else if (kind == TK_MUL) d.kind = TK_AND;
-      else if (kind == TK_ADDC) d.kind = const_odd[tape.b[i]] ? TK_NOT : TK_COPY;
+      else if (kind == TK_ADDC) d.kind = const_odd[opb[i]] ? TK_NOT : TK_COPY;
       else if (kind == TK_MULC) {
-        if (const_odd[tape.b[i]]) d.kind = TK_COPY;
+        if (const_odd[opb[i]]) d.kind = TK_COPY;
         else { d.kind = TK_CONST; d.a = bool_zero_const; }
       }
     }

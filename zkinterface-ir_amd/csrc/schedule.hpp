@@ -39,6 +39,7 @@ struct ScheduleOptions {
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
   bool sort_by_operand = true;      // order a level's ops by first-operand slot (cache locality)
   bool fuse = true;                 // absorb single-reader Add/Mul producers into their consumer (never with retain_all)
+  bool propagate_copies = true;     // readers use a copy's source; unobserved copies are not materialised (never with retain_all)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
 };
 
@@ -47,6 +48,7 @@ struct Schedule {
   std::vector<DevOp2> ops2;         // used instead of `ops` when fused
   bool fused = false;
   uint64_t n_absorbed = 0;
+  uint64_t n_copies_elided = 0;
   std::vector<Launch> launches;
   std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)
   std::vector<uint32_t> level_of;   // per tape op
