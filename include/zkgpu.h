@@ -121,8 +121,25 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),
  * "propagate_copies" = 0|1 (readers use a copy's source, unobserved copies are not materialised; never with retain_all),
  * "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a
- * 32-witness slice resident in one CU's LDS when the live wires fit in 160 KiB).  Set before zkgpu_set_inputs*. */
+ * 32-witness slice resident in one CU's LDS when the live wires fit in 160 KiB).  Set before zkgpu_set_inputs*.
+ * "validate" = "prover" | "verifier" | "off" and "metrics" = 0|1 switch on the other two consumers of
+ * `valid-eval-metrics`; set them before the first zkgpu_ingest_* call ("validator_max_steps" = N bounds the
+ * wire-by-wire walk of Free/For ranges, default 2^40). */
 int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value);
+
+/* ---- Validator and Stats beside the Evaluator: `zki_sieve valid-eval-metrics` (rust/src/cli.rs:333-363) ----
+ * With "validate" / "metrics" enabled every message given to zkgpu_ingest_* is also fed to a Validator
+ * (rust/src/consumers/validator.rs:64-861) and a Stats (rust/src/consumers/stats.rs:44-287), in the
+ * order the reference feeds them; a message that does not parse makes zkgpu_ingest_* fail (cli.rs:345-346).
+ * zkgpu_validator_violations = Validator::get_violations() joined with '\n' (same strings, same order);
+ * zkgpu_validator_live_wires = 1 when the reference would print "WARNING: few variables were not freed.";
+ * zkgpu_stats_json = serde_json::to_writer_pretty(&stats); zkgpu_stats_warnings = its stderr lines.
+ * String getters return the full length and write at most cap-1 bytes + NUL. */
+size_t zkgpu_validator_violations(zkgpu_session* s, char* buf, size_t cap);
+int zkgpu_validator_count(zkgpu_session* s);        /* -1 when the validator is off */
+int zkgpu_validator_live_wires(zkgpu_session* s);
+size_t zkgpu_stats_json(zkgpu_session* s, char* buf, size_t cap);
+size_t zkgpu_stats_warnings(zkgpu_session* s, char* buf, size_t cap);
 int zkgpu_uses_lds_path(zkgpu_session* s);           /* 1 / 0, -1 on error (touches the GPU) */
 int zkgpu_replay(zkgpu_session* s);                  /* asynchronous */
 int zkgpu_replay_timed(zkgpu_session* s);            /* per-launch HIP events, synchronous */

@@ -17,15 +17,29 @@ def lit32(v):
     return v.to_bytes(4, 'little')
 
 
+def emit_spec(spec):
+    kw = dict(degree=spec.get('degree', 1), version=spec.get('version', '1.0.0'))
+    if spec['type'] == 'instance':
+        return write_instance(spec['mod'], spec['values'], **kw)
+    if spec['type'] == 'witness':
+        return write_witness(spec['mod'], spec['values'], **kw)
+    return write_relation(spec['mod'], spec['gateset'], spec['features'], spec['functions'], spec['gates'], **kw)
+
+
 def arith_example(modulus=101, incorrect=False):
     """Pythagorean + Fibonacci example; returns (instance, witness, relation) buffers."""
+    return tuple(emit_spec(s) for s in arith_example_specs(modulus, incorrect))
+
+
+def arith_example_specs(modulus=101, incorrect=False):
+    """The same statement as message specs (tests/validator_ref.py): data, emitted by emit_spec()."""
     mod_le = lit32(modulus) if modulus < 2 ** 32 else int_to_le(modulus)
     neg_one = bytes([mod_le[0] - 1]) + mod_le[1:]  # examples.rs:236-241 encode_negative_one
-    inst = write_instance(mod_le, [lit32(25), lit32(0), lit32(1)])
+    inst = {'type': 'instance', 'mod': mod_le, 'values': [lit32(25), lit32(0), lit32(1)]}
     if incorrect:
-        wit = write_witness(mod_le, [lit32(3), lit32(5), lit32(1), lit32(40)])
+        wit = {'type': 'witness', 'mod': mod_le, 'values': [lit32(3), lit32(5), lit32(1), lit32(40)]}
     else:
-        wit = write_witness(mod_le, [lit32(3), lit32(4), lit32(0), int_to_le(17711 % modulus)])
+        wit = {'type': 'witness', 'mod': mod_le, 'values': [lit32(3), lit32(4), lit32(0), int_to_le(17711 % modulus)]}
     mul = 'com.example::mul'
     functions = [(mul, 1, 2, 0, 0, [('mul', 0, 1, 2)])]
     gates = [
@@ -74,15 +88,20 @@ def arith_example(modulus=101, incorrect=False):
           [('sub', ('name', 'i'), ('const', 1)), ('sub', ('name', 'i'), ('const', 2))])),
         ('free', 8, 50),
     ]
-    rel = write_relation(mod_le, '@add,@mul,@mulc,', '@for,@switch,@function,', functions, gates)
-    return inst, wit, rel
+    rel = {'type': 'relation', 'mod': mod_le, 'gateset': '@add,@mul,@mulc,', 'features': '@for,@switch,@function,',
+           'functions': functions, 'gates': gates}
+    return [inst, wit, rel]
 
 
 def bool_example(incorrect=False):
+    return tuple(emit_spec(s) for s in bool_example_specs(incorrect))
+
+
+def bool_example_specs(incorrect=False):
     mod_le = bytes([2])
-    inst = write_instance(mod_le, [bytes([v]) for v in (0, 0, 0, 0, 0, 1, 0, 1)])
+    inst = {'type': 'instance', 'mod': mod_le, 'values': [bytes([v]) for v in (0, 0, 0, 0, 0, 1, 0, 1)]}
     wvals = (1, 1, 1, 0, 0) if incorrect else (1, 0, 1, 0, 0)
-    wit = write_witness(mod_le, [bytes([v]) for v in wvals])
+    wit = {'type': 'witness', 'mod': mod_le, 'values': [bytes([v]) for v in wvals]}
     adder = 'two_bit_adder'
     functions = [(adder, 3, 4, 0, 0, [
         ('xor', 2, 4, 6), ('and', 7, 4, 6), ('xor', 8, 3, 5), ('xor', 1, 7, 8), ('and', 9, 3, 5),
@@ -110,8 +129,9 @@ def bool_example(incorrect=False):
         ('assert_zero', 27),
         ('free', 24, 27),
     ]
-    rel = write_relation(mod_le, '@xor,@and,@not,', '@for,@switch,@function,', functions, gates)
-    return inst, wit, rel
+    rel = {'type': 'relation', 'mod': mod_le, 'gateset': '@xor,@and,@not,', 'features': '@for,@switch,@function,',
+           'functions': functions, 'gates': gates}
+    return [inst, wit, rel]
 
 
 # (n_ops, sha256 of the backend-op trace, violations)

@@ -240,6 +240,8 @@ class Gen:
         self.n_inst, self.n_wit = counters
         mod_le = sw.int_to_le(self.p)
         gateset = 'boolean' if self.boolean else 'arithmetic'
+        self.spec = {'type': 'relation', 'mod': mod_le, 'gateset': gateset, 'features': '@function,@for,@switch',
+                     'functions': self.functions, 'gates': gates}
         return sw.write_relation(mod_le, gateset, '@function,@for,@switch', self.functions, gates), mod_le
 
     def lane_inputs(self, lanes, seed):

@@ -49,6 +49,43 @@ def test_evaluate_helper_prints_reference_verdicts():
     assert zk.evaluate([inst, wit]) == ['Did not receive any gate to verify.']
 
 
+def test_valid_eval_metrics_three_part_report(tmp_path):
+    """`zki_sieve valid-eval-metrics` (cli.rs:333-363; run on both examples by cli.rs:574-627): validator
+    verdict, evaluator verdict (GPU replay) and the Stats JSON, from one pass over the messages."""
+    import io
+    import json
+    from zkinterface_ir_amd import cli
+    from validator_ref import StatsRef
+    for name, specs, verdict in (('arith', circuits.arith_example_specs(), None),
+                                 ('bool', circuits.bool_example_specs(), None),
+                                 ('arith_bad', circuits.arith_example_specs(incorrect=True),
+                                  'Wire_9 (may be weighted) should be 0, while it is not'),
+                                 ('bool_bad', circuits.bool_example_specs(incorrect=True),
+                                  'Wire_22 (may be weighted) should be 0, while it is not')):
+        d = tmp_path / name
+        d.mkdir()
+        for k, s in enumerate(specs):
+            (d / ('%03d_%s.sieve' % (k, s['type']))).write_bytes(circuits.emit_spec(s))
+        want_stats = StatsRef()
+        for s in specs:
+            want_stats.ingest(s)
+        valid, evald, stats = zk.valid_eval_metrics([str(d)])
+        assert valid == []
+        assert evald == ([verdict] if verdict else [])
+        assert json.loads(stats) == want_stats.as_dict()
+        err, out = io.StringIO(), io.StringIO()
+        rc = cli.main(['valid-eval-metrics', str(d)], err=err, out=out)
+        assert json.loads(out.getvalue()) == want_stats.as_dict()
+        if verdict:
+            assert rc == 1
+            assert err.getvalue() == ('\nThe statement is COMPLIANT with the specification!\n'
+                                      '\nThe statement is NOT TRUE!\nViolations:\n- %s\n\nError: Found 1 violations.\n' % verdict)
+        else:
+            assert rc == 0
+            assert err.getvalue() == ('\nThe statement is COMPLIANT with the specification!\n'
+                                      '\nThe statement is TRUE!\n')
+
+
 def _batched_example(modulus, lanes):
     """Lane inputs for the arithmetic example relation (examples.rs:72-212): the switch condition
     (witness 0) stays 3 so the pythagorean branch is live; it checks instance0 == 3^2 + witness1^2

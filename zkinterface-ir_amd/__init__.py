@@ -84,6 +84,11 @@ def lib():
         'zkgpu_set_inputs_from_messages': (ci, [vp]),
         'zkgpu_set_lane_group': (ci, [vp, u32]),
         'zkgpu_set_option': (ci, [vp, ctypes.c_char_p, ctypes.c_char_p]),
+        'zkgpu_validator_violations': (sz, [vp, ctypes.c_char_p, sz]),
+        'zkgpu_validator_count': (ci, [vp]),
+        'zkgpu_validator_live_wires': (ci, [vp]),
+        'zkgpu_stats_json': (sz, [vp, ctypes.c_char_p, sz]),
+        'zkgpu_stats_warnings': (sz, [vp, ctypes.c_char_p, sz]),
         'zkgpu_uses_lds_path': (ci, [vp]),
         'zkgpu_replay': (ci, [vp]),
         'zkgpu_replay_timed': (ci, [vp]),
@@ -168,11 +173,38 @@ class Evaluator:
     def declare_inputs(self, n_instance, n_witness):
         self._ck(self.L.zkgpu_declare_inputs(self.h, n_instance, n_witness))
 
-    def host_violations(self):
-        n = self.L.zkgpu_host_violations(self.h, None, 0)
+    def _text(self, fn, *args):
+        n = fn(self.h, *args, None, 0)
         buf = ctypes.create_string_buffer(n + 1)
-        self.L.zkgpu_host_violations(self.h, buf, n + 1)
-        s = buf.value.decode('utf-8', 'replace')
+        fn(self.h, *args, buf, n + 1)
+        return buf.value.decode('utf-8', 'replace')
+
+    def host_violations(self):
+        s = self._text(self.L.zkgpu_host_violations)
+        return s.split('\n') if s else []
+
+    # -- the other two consumers of `valid-eval-metrics` (cli.rs:333-363) -------
+    def validator_violations(self):
+        """Validator::get_violations() (validator.rs:135-142); needs set_option('validate', 'prover'|'verifier')
+        before the first message."""
+        if self.L.zkgpu_validator_count(self.h) < 0:
+            raise ZkGpuError('the validator is not enabled (set_option("validate", "prover") before ingesting)')
+        s = self._text(self.L.zkgpu_validator_violations)
+        return s.split('\n') if s else []
+
+    def validator_has_live_wires(self):
+        return self.L.zkgpu_validator_live_wires(self.h) == 1
+
+    def stats_json(self):
+        """serde_json::to_writer_pretty(&Stats) (stats.rs:44-53, cli.rs:353); needs set_option('metrics', '1')."""
+        return self._text(self.L.zkgpu_stats_json)
+
+    def stats(self):
+        import json
+        return json.loads(self.stats_json())
+
+    def stats_warnings(self):
+        s = self._text(self.L.zkgpu_stats_warnings)
         return s.split('\n') if s else []
 
     # -- ZKBackend trait methods (evaluator.rs:17-76), one C entry point each ------
@@ -455,15 +487,50 @@ class Evaluator:
         return self.L.zkgpu_table_bytes(self.h)
 
 
-def evaluate(paths_or_buffers):
-    """`zki_sieve evaluate` (cli.rs:315-320) for one statement: returns the violation list
-    (empty list = "The statement is TRUE!")."""
-    ev = Evaluator()
+def _ingest_any(ev, paths_or_buffers):
     if paths_or_buffers and isinstance(paths_or_buffers[0], str):
         ev.ingest_paths(list(paths_or_buffers))
     else:
         for b in paths_or_buffers:
             ev.ingest_message(b)
+
+
+def validate(paths_or_buffers, as_prover=True):
+    """`zki_sieve validate` (cli.rs:302-313): the Validator's violation list, no GPU involved."""
+    ev = Evaluator()
+    ev.set_option('validate', 'prover' if as_prover else 'verifier')
+    _ingest_any(ev, paths_or_buffers)
+    return ev.validator_violations()
+
+
+def metrics(paths_or_buffers):
+    """`zki_sieve metrics` (cli.rs:322-330): the Stats JSON text, no GPU involved."""
+    ev = Evaluator()
+    ev.set_option('metrics', '1')
+    _ingest_any(ev, paths_or_buffers)
+    return ev.stats_json()
+
+
+def valid_eval_metrics(paths_or_buffers):
+    """`zki_sieve valid-eval-metrics` (cli.rs:333-363): every message is read once and fed to the Validator
+    (as prover), the Evaluator and the Stats; returns (validator violations, evaluator violations, stats JSON).
+    The evaluation itself is the GPU replay of `evaluate`."""
+    ev = Evaluator()
+    ev.set_option('validate', 'prover')
+    ev.set_option('metrics', '1')
+    _ingest_any(ev, paths_or_buffers)
+    return ev.validator_violations(), _finish_evaluate(ev), ev.stats_json()
+
+
+def evaluate(paths_or_buffers):
+    """`zki_sieve evaluate` (cli.rs:315-320) for one statement: returns the violation list
+    (empty list = "The statement is TRUE!")."""
+    ev = Evaluator()
+    _ingest_any(ev, paths_or_buffers)
+    return _finish_evaluate(ev)
+
+
+def _finish_evaluate(ev):
     try:
         ev.finalize()
     except ZkGpuError:

@@ -1,7 +1,8 @@
-"""`zki_sieve evaluate <paths...>` on the GPU path (rust/src/cli.rs:130,315-320,557-571): same file
-discovery and ordering, same verdict text on stderr, non-zero exit on violations.
+"""`zki_sieve evaluate | validate | metrics | valid-eval-metrics <paths...>` on the GPU path
+(rust/src/cli.rs:130,302-363,557-571): same file discovery and ordering, same verdict text on stderr,
+Stats JSON on stdout, non-zero exit on violations.
 
-  python -m zkinterface_ir_amd.cli evaluate <workspace dir or .sieve files ...>
+  python -m zkinterface_ir_amd.cli valid-eval-metrics <workspace dir or .sieve files ...>
 (run through `python zkinterface-ir_amd/cli.py ...` or after __graft_entry__.load_package())."""
 import sys
 
@@ -56,20 +57,36 @@ def synth(kind, out_dir, lane=0, corrupt=False, err=sys.stderr):
     return 0
 
 
-def main(argv=None, err=sys.stderr):
+def main(argv=None, err=sys.stderr, out=sys.stdout):
     argv = list(sys.argv[1:] if argv is None else argv)
     if len(argv) >= 3 and argv[0] == 'synth' and argv[1] in ('c2', 'c4'):
         return synth(argv[1], argv[2], lane=int(argv[3]) if len(argv) > 3 else 0, corrupt='--incorrect' in argv, err=err)
-    if len(argv) < 2 or argv[0] != 'evaluate':
-        print('usage: cli.py evaluate <workspace dir | file.sieve ...>\n'
+    tools = ('evaluate', 'validate', 'metrics', 'valid-eval-metrics')
+    if len(argv) < 2 or argv[0] not in tools:
+        print('usage: cli.py evaluate|validate|metrics|valid-eval-metrics <workspace dir | file.sieve ...>\n'
               '       cli.py synth c2|c4 <out dir> [lane] [--incorrect]', file=err)
         return 2
     import zkinterface_ir_amd as zk
-    violations = zk.evaluate(argv[1:])
-    msg = print_violations(violations, err=err)
-    if msg:
-        print('Error: %s' % msg, file=err)
-        return 1
+    tool, paths = argv[0], argv[1:]
+    failures = []
+    try:
+        if tool == 'evaluate':
+            failures.append(print_violations(zk.evaluate(paths), err=err))
+        elif tool == 'validate':  # cli.rs:302-313
+            failures.append(print_violations(zk.validate(paths), what='COMPLIANT with the specification', err=err))
+        elif tool == 'metrics':   # cli.rs:322-330
+            print(zk.metrics(paths), file=out)
+        else:                     # cli.rs:333-363: three reports, then the first failure decides the exit
+            valid, evald, stats = zk.valid_eval_metrics(paths)
+            failures.append(print_violations(valid, what='COMPLIANT with the specification', err=err))
+            failures.append(print_violations(evald, err=err))
+            print(stats, file=out)
+    except zk.ZkGpuError as e:
+        failures.append(str(e))
+    for msg in failures:
+        if msg:
+            print('Error: %s' % msg, file=err)
+            return 1
     return 0
 
 

@@ -11,7 +11,9 @@
 #include "evaluator.hpp"
 #include "r1cs.hpp"
 #include "schedule.hpp"
+#include "stats.hpp"
 #include "tape.hpp"
+#include "validator.hpp"
 
 using namespace zki;
 
@@ -37,6 +39,9 @@ struct zkgpu_session {
   std::vector<R1csTermDev> r1cs_terms_dev;
   std::vector<uint32_t> r1cs_coef_words;
   uint32_t r1cs_extra_vars = 0;
+  // the other two consumers of `valid-eval-metrics` (cli.rs:333-363), fed the same messages when enabled
+  std::unique_ptr<Validator> validator;
+  std::unique_ptr<Stats> stats;
   std::string last_error;
   std::vector<uint32_t> first_fail, flags;
   std::vector<uint32_t> value_op_index;  // k-th value-returning call -> tape index
@@ -83,17 +88,23 @@ void need_engine(zkgpu_session* s) {
 }
 
 void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
+  const bool side_consumers = s->validator || s->stats;
   for (const auto& m : split_messages(data, len)) {
-    if (s->ev.has_error()) return;
+    if (s->ev.has_error() && !side_consumers) return;
     // peek the message type: Instance / Witness messages become lane 0's streams
     Message msg;
     try {
       msg = read_message(data + m.first, m.second);
     } catch (const std::exception& e) {
+      // `let msg = msg?;` ends valid-eval-metrics before any report (cli.rs:345-346)
+      if (side_consumers) throw;
       // Evaluator::from_messages unwraps (evaluator.rs:193): route through the latch
       s->ev.ingest_buffer(data + m.first, m.second, s->backend);
       continue;
     }
+    if (s->validator) s->validator->ingest_message(msg);
+    if (s->stats) s->stats->ingest_message(msg);
+    if (s->ev.has_error()) continue;  // first error latches (evaluator.rs:213-222)
     if (msg.kind == Message::IsInstance) {
       s->ev.set_modulus(msg.instance.header.field_characteristic);
       for (const Value& v : msg.instance.common_inputs) s->ev.push_instance(s->backend.import_instance(v));
@@ -480,10 +491,42 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->fuse = v != "0";
     } else if (k == "sort_by_operand") {
       s->sort_by_operand = v != "0";
+    } else if (k == "validate") {
+      if (v == "prover") s->validator.reset(new Validator(Validator::new_as_prover()));
+      else if (v == "verifier") s->validator.reset(new Validator(Validator::new_as_verifier()));
+      else if (v == "off") s->validator.reset();
+      else throw std::runtime_error("validate must be prover, verifier or off");
+    } else if (k == "validator_max_steps") {
+      if (!s->validator) throw std::runtime_error("validator_max_steps: the validator is not enabled");
+      s->validator->set_max_steps(strtoull(v.c_str(), nullptr, 10));
+    } else if (k == "metrics") {
+      if (v != "0") s->stats.reset(new Stats());
+      else s->stats.reset();
     } else {
       throw std::runtime_error("unknown option " + k);
     }
   });
+}
+
+size_t zkgpu_validator_violations(zkgpu_session* s, char* buf, size_t cap) {
+  if (!s || !s->validator) return copy_out("", buf, cap);
+  return copy_out(join_lines(s->validator->get_violations()), buf, cap);
+}
+int zkgpu_validator_count(zkgpu_session* s) {
+  if (!s || !s->validator) return -1;
+  return (int)s->validator->get_violations().size();
+}
+int zkgpu_validator_live_wires(zkgpu_session* s) {
+  if (!s || !s->validator) return -1;
+  return s->validator->has_live_wires() ? 1 : 0;
+}
+size_t zkgpu_stats_json(zkgpu_session* s, char* buf, size_t cap) {
+  if (!s || !s->stats) return copy_out("", buf, cap);
+  return copy_out(s->stats->to_json_pretty(), buf, cap);
+}
+size_t zkgpu_stats_warnings(zkgpu_session* s, char* buf, size_t cap) {
+  if (!s || !s->stats) return copy_out("", buf, cap);
+  return copy_out(join_lines(s->stats->warnings), buf, cap);
 }
 
 int zkgpu_uses_lds_path(zkgpu_session* s) {

@@ -267,26 +267,26 @@ def int_to_le(v, width=None):
     return v.to_bytes(n, 'little')
 
 
-def write_instance(modulus, values, degree=1):
+def write_instance(modulus, values, degree=1, version='1.0.0'):
     """values: list of bytes (little-endian Values)."""
     b = Builder()
     vec = b.offset_vector([_value(b, v) for v in values])
-    h = _header(b, modulus, degree)
+    h = _header(b, modulus, degree, version)
     inst = b.table([(4, 'off', h), (6, 'off', vec)])
     root = b.table([(4, 'u8', 2), (6, 'off', inst)])
     return b.finish_size_prefixed(root)
 
 
-def write_witness(modulus, values, degree=1):
+def write_witness(modulus, values, degree=1, version='1.0.0'):
     b = Builder()
     vec = b.offset_vector([_value(b, v) for v in values])
-    h = _header(b, modulus, degree)
+    h = _header(b, modulus, degree, version)
     wit = b.table([(4, 'off', h), (6, 'off', vec)])
     root = b.table([(4, 'u8', 3), (6, 'off', wit)])
     return b.finish_size_prefixed(root)
 
 
-def write_relation(modulus, gateset, features, functions, gates, degree=1):
+def write_relation(modulus, gateset, features, functions, gates, degree=1, version='1.0.0'):
     """functions: list of (name, output_count, input_count, instance_count, witness_count, [gates])."""
     b = Builder()
     gv = _gates_vector(b, gates)
@@ -299,7 +299,7 @@ def write_relation(modulus, gateset, features, functions, gates, degree=1):
     fv = b.offset_vector(fts) if functions is not None else None
     feat = b.string(features)
     gs = b.string(gateset)
-    h = _header(b, modulus, degree)
+    h = _header(b, modulus, degree, version)
     rel = b.table([(4, 'off', h), (6, 'off', gs), (8, 'off', feat), (10, 'off', fv), (12, 'off', gv)])
     root = b.table([(4, 'u8', 1), (6, 'off', rel)])
     return b.finish_size_prefixed(root)
