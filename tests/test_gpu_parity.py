@@ -499,3 +499,111 @@ def test_trait_level_recording_replays_on_gpu():
         expect = [] if z == 0 else ['Wire_41 (may be weighted) should be 0, while it is not']
         assert ev.get_violations(l) == expect
     assert ev.counts() == (3, 2)
+
+
+@pytest.mark.parametrize('name', ['with_function', 'with_several_functions', 'switch_builder', 'switch_nested_in_function'])
+def test_builder_circuits_replay_true(name):
+    """rust/src/producers/builder.rs:727-1175: the four GateBuilder circuits evaluate with zero violations."""
+    from builder_circuits import BUILDER_CIRCUITS
+    bufs = BUILDER_CIRCUITS[name]().buffers()
+    assert zk.evaluate(bufs) == []
+    ref = OracleRun(buffers=bufs)
+    ev = zk.Evaluator.from_messages(bufs)
+    ev.finalize(retain_all=True)
+    ev.set_inputs_from_messages()
+    ev.replay()
+    ev.synchronize()
+    assert ev.dump_trace_values(1)[0] == ref.trace_values()
+
+
+def test_r1cs_example_converted_to_ir_replays_with_reference_wire_values(tmp_path):
+    """rust/src/producers/from_r1cs.rs:176-217: wires 0..6 hold 1, 100, 3, 4, 25, 9, 16 and nothing is violated;
+    through a FilesSink workspace as `zkif-to-ir` would write it (cli.rs:365-440)."""
+    from builder_circuits import R1CS_EXAMPLE_WIRES, r1cs_example
+    from zkinterface_ir_amd.builder import FilesSink
+    sink = r1cs_example(FilesSink.new_clean(str(tmp_path / 'ws')))
+    sink.close()
+    ev = zk.Evaluator()
+    ev.ingest_paths(sink.paths())
+    ev.finalize(retain_all=True)
+    ev.set_inputs_from_messages()
+    ev.replay()
+    ev.synchronize()
+    assert ev.get_violations(0) == []
+    assert [ev.get(w, 1)[0] for w in range(7)] == R1CS_EXAMPLE_WIRES
+    assert zk.evaluate(r1cs_example(zz=26).buffers()) == ['Wire_35 (may be weighted) should be 0, while it is not']
+
+
+@pytest.mark.parametrize('p', [101, circuits.BN254_R])
+def test_r1cs_rows_and_their_ir_expansion_agree_per_lane(p):
+    """One constraint system, two device paths: the row-check kernel over the CSR (C5) and the replay of the
+    FromR1CSConverter expansion of the same rows (C2 path).  Every lane must get the same verdict, and the first
+    failing row must be the first failing assert."""
+    from zkinterface_ir_amd.builder import MemorySink
+    from zkinterface_ir_amd.from_r1cs import FromR1CSConverter
+    rng = np.random.default_rng(1234)
+    n_base, M, batch = 12, 120, 70
+    width = 8 * ((p.bit_length() + 63) // 64)
+    le = lambda x: int(x).to_bytes(width, 'little')
+    rows = []   # (A, B, C) with terms (var id, coef int); ids: 0 = one, 1..n_base base, n_base+1+i = z_i
+    for i in range(M):
+        hi = n_base + 1 + i
+        lc = lambda k: [(int(rng.integers(0, hi)), int(rng.integers(0, 2 ** 62)) % p) for _ in range(k)]
+        rows.append((lc(int(rng.integers(1, 4))), lc(int(rng.integers(0, 4))), [(hi, 1)]))
+    # per-lane assignments; some lanes get one wrong z
+    vals = np.zeros((batch, n_base + 1 + M), dtype=object)
+    bad_row = {}
+    for lane in range(batch):
+        vals[lane, 0] = 1
+        for k in range(1, n_base + 1):
+            vals[lane, k] = int(rng.integers(0, 2 ** 62)) % p
+        wrong = int(rng.integers(0, M)) if lane % 5 == 2 else None
+        for i, (a, b, _c) in enumerate(rows):
+            z = sum(c * vals[lane, v] for v, c in a) % p * (sum(c * vals[lane, v] for v, c in b) % p) % p
+            if wrong == i:
+                z = (z + 1) % p
+                bad_row[lane] = i
+            vals[lane, n_base + 1 + i] = z
+    n_wit = n_base + M
+    wit = np.frombuffer(b''.join(le(vals[lane, k]) for lane in range(batch) for k in range(1, n_wit + 1)),
+                        dtype=np.uint8).reshape(batch, n_wit, width)
+
+    # path 1: CSR rows through the R1CS kernel; variable id k (>= 1) is witness k - 1, id 0 is the constant one
+    cb = [le(1)]
+    tv, tc, row_ptr = [], [], [0]
+    for a, b, c in rows:
+        for lcomb in (a, b, c):
+            for var, coef in lcomb:
+                tv.append(2 ** 64 - 1 if var == 0 else var - 1)
+                cb.append(le(coef))
+                tc.append(len(cb) - 1)
+            row_ptr.append(len(tv))
+    ev = zk.Evaluator()
+    ev.declare_inputs(0, n_wit)
+    ev.ingest_message(sw.write_relation(sw.int_to_le(p), 'arithmetic', 'simple', [], [('witness', k) for k in range(n_wit)]))
+    ev.finalize(retain_all=True)
+    ev.r1cs_load_csr(np.array(row_ptr, dtype=np.uint32), np.array(tv, dtype=np.uint64), np.array(tc, dtype=np.uint32),
+                     np.frombuffer(b''.join(cb), dtype=np.uint8).reshape(len(cb), width), width, 0)
+    ev.set_inputs(None, wit.tobytes(), batch)
+    ev.replay()
+    ev.r1cs_check()
+    ff_rows, counts_rows = ev.r1cs_results(batch)
+
+    # path 2: the same rows expanded to gates, replayed for the same lanes
+    conv = FromR1CSConverter(MemorySink(), p - 1, [(0, le(1))], list(range(1, n_wit + 1)))
+    conv.ingest_constraints([tuple([(var, le(c)) for var, c in lcomb] for lcomb in row) for row in rows])
+    rel = conv.finish().buffers()[2]
+    ev2 = zk.Evaluator()
+    ev2.declare_inputs(0, n_wit)
+    ev2.ingest_message(rel)
+    ev2.finalize()
+    ev2.set_inputs(None, wit.tobytes(), batch)
+    ev2.replay()
+    ev2.synchronize()
+    ff_gates, flags = ev2.lane_results(batch)
+    assert ev2.counts() == counts_rows == (batch - len(bad_row), len(bad_row))
+    for lane in range(batch):
+        if lane in bad_row:
+            assert int(ff_rows[lane]) == bad_row[lane] and int(ff_gates[lane]) == bad_row[lane]
+        else:
+            assert int(ff_rows[lane]) == 0xFFFFFFFF and int(ff_gates[lane]) == 0xFFFFFFFF
