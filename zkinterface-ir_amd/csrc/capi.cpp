@@ -28,10 +28,11 @@ struct zkgpu_session {
   uint32_t declared_inst = 0, declared_wit = 0;
   uint32_t lane_group = 0;
   int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
-  bool sort_by_operand = true;
+  int sort_by_operand = 2;
   bool fuse = true;
   bool propagate_copies = true;
   uint32_t n_streams = 2;
+  bool xcd_map = true;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
   bool r1cs_ready = false, r1cs_on_device = false, r1cs_loaded_csr = false;
@@ -82,6 +83,7 @@ void need_engine(zkgpu_session* s) {
     e->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
     e->set_lane_group(s->lane_group);
     e->set_streams(s->n_streams);
+    e->set_xcd_map(s->xcd_map);
     if (s->r1cs_extra_vars) e->reserve_extra_slots(s->r1cs_extra_vars);
     s->engine = std::move(e);
   }
@@ -485,12 +487,15 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "streams") {
       s->n_streams = (uint32_t)std::max(1, std::min(4, atoi(v.c_str())));
       if (s->engine) s->engine->set_streams(s->n_streams);
+    } else if (k == "xcd_map") {
+      s->xcd_map = v != "0";
+      if (s->engine) s->engine->set_xcd_map(s->xcd_map);
     } else if (k == "propagate_copies") {
       s->propagate_copies = v != "0";
     } else if (k == "fuse") {
       s->fuse = v != "0";
     } else if (k == "sort_by_operand") {
-      s->sort_by_operand = v != "0";
+      s->sort_by_operand = std::max(0, std::min(2, atoi(v.c_str())));
     } else if (k == "validate") {
       if (v == "prover") s->validator.reset(new Validator(Validator::new_as_prover()));
       else if (v == "verifier") s->validator.reset(new Validator(Validator::new_as_verifier()));

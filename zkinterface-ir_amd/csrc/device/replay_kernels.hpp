@@ -55,7 +55,26 @@ struct ReplayArgs {
   u32 n_wit;
   u32* first_fail;        // [lane] min assert sequence number that failed
   u32* lane_flags;        // [lane] sticky flags (non-canonical input ...)
+  u32 xcd_chunks;         // != 0: XCD-aware 1-D grid, see block_coords()
 };
+
+// Workgroup -> (chunk of ops, lane block).  Legacy grid: x = chunk, y = lane block; consecutive
+// chunks of one lane block then land on different XCDs (workgroups are dealt round-robin over the 8
+// XCDs) and a wire read by two gates of the level is fetched into two L2s.  XCD-aware grid (the launch
+// covers a multiple of 8 lane blocks): block b runs on XCD b % 8 and is given lane block
+// 8 * group + (b % 8), so each XCD sweeps whole levels of its own lane blocks and the second reader of
+// a wire finds it in that XCD's L2.
+__device__ __forceinline__ void block_coords(u32 xcd_chunks, u32& chunk, u32& lb_rel) {
+  if (xcd_chunks == 0) {
+    chunk = blockIdx.x;
+    lb_rel = blockIdx.y;
+  } else {
+    const u32 j = blockIdx.x >> 3;
+    const u32 g = j / xcd_chunks;
+    chunk = j - g * xcd_chunks;
+    lb_rel = g * 8 + (blockIdx.x & 7);
+  }
+}
 
 template <int N>
 struct Layout {
@@ -121,8 +140,10 @@ template <int N, bool PIPE>
 __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, const FieldParams fp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
-  const u32 lb = args.lb_base + blockIdx.y;
-  const u32 gw = blockIdx.x * (blockDim.x >> 6) + wave;
+  u32 chunk, lb_rel;
+  block_coords(args.xcd_chunks, chunk, lb_rel);
+  const u32 lb = args.lb_base + lb_rel;
+  const u32 gw = chunk * (blockDim.x >> 6) + wave;
   const u32 begin = gw * args.ops_per_wave;
   if (begin >= args.n_ops) return;
   const u32 end = min(args.n_ops, begin + args.ops_per_wave);
@@ -217,6 +238,7 @@ struct ReplayArgs2 {
   u32 n_wit;
   u32* first_fail;
   u32* lane_flags;
+  u32 xcd_chunks;
 };
 
 // Replay of the fused schedule: an Add/Mul operand may be `add(a0,a1)` / `mul(a0,a1)` evaluated in
@@ -226,8 +248,10 @@ template <int N>
 __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 args, const FieldParams fp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
-  const u32 lb = args.lb_base + blockIdx.y;
-  const u32 gw = blockIdx.x * (blockDim.x >> 6) + wave;
+  u32 chunk, lb_rel;
+  block_coords(args.xcd_chunks, chunk, lb_rel);
+  const u32 lb = args.lb_base + lb_rel;
+  const u32 gw = chunk * (blockDim.x >> 6) + wave;
   const u32 begin = gw * args.ops_per_wave;
   if (begin >= args.n_ops) return;
   const u32 end = min(args.n_ops, begin + args.ops_per_wave);

@@ -325,7 +325,11 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   memcpy(&fp, field_params_, sizeof fp);
   const Launch& L = sched_.launches[li];
   const uint32_t waves = (L.count + L.ops_per_wave - 1) / L.ops_per_wave;
-  const dim3 grid((waves + 3) / 4, lbs);
+  const uint32_t chunks = (waves + 3) / 4;
+  dim3 grid(chunks, lbs);
+  // XCD-aware grid (device/replay_kernels.hpp block_coords): each XCD sweeps whole levels of its own lane blocks
+  const uint32_t xcd_chunks = (!boolean_ && xcd_map_ && !L.sequential && lbs % 8 == 0 && chunks >= 8) ? chunks : 0;
+  if (xcd_chunks) grid = dim3(chunks * lbs);
   if (boolean_) {
     zkgpu::BoolReplayArgs a;
     memset(&a, 0, sizeof a);
@@ -361,6 +365,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.n_wit = n_wit_;
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.lane_flags = (zkgpu::u32*)d_flags_;
+    a.xcd_chunks = xcd_chunks;
     switch (nwords_) {
       case 2: zkgpu::replay_fused_kernel<2><<<grid, 256, 0, st>>>(a, fp); break;
       case 4: zkgpu::replay_fused_kernel<4><<<grid, 256, 0, st>>>(a, fp); break;
@@ -388,6 +393,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   a.n_wit = n_wit_;
   a.first_fail = (zkgpu::u32*)d_first_fail_;
   a.lane_flags = (zkgpu::u32*)d_flags_;
+  a.xcd_chunks = xcd_chunks;
   switch (nwords_) {
     case 2: launch_arith<2>(a, fp, L.sequential, grid, st); break;
     case 4: launch_arith<4>(a, fp, L.sequential, grid, st); break;

@@ -39,6 +39,7 @@ class Engine {
   void set_lane_group(uint32_t lanes) { lane_group_ = lanes; }
   // Replay the lane blocks as `n` interleaved halves on `n` HIP streams (1..4): the levels of one
   // half fill the kernel-boundary bubbles and wave tails of the other.
+  void set_xcd_map(bool on) { xcd_map_ = on; }
   void set_streams(uint32_t n) { n_streams_ = n < 1 ? 1 : (n > kMaxStreams ? kMaxStreams : n); }
   static constexpr uint32_t kMaxStreams = 4;
   // GF(2): 0 = pick automatically, 1 = force the HBM-table kernel, 2 = require the LDS-resident kernel
@@ -93,6 +94,7 @@ class Engine {
   void* ev_fork_ = nullptr;
   void* ev_join_[3] = {nullptr, nullptr, nullptr};
   uint32_t n_streams_ = 2;
+  bool xcd_map_ = true;
   void* ev_begin_ = nullptr;
   void* ev_end_ = nullptr;
   std::vector<void*> launch_events_;

@@ -19,6 +19,66 @@ constexpr uint32_t kInf = 0xFFFFFFFFu;
 
 }  // namespace
 
+namespace {
+
+// Depth-first walk of the "reads the same wire" graph of one level: ops become neighbours of an op they
+// share an operand with, so the second reader of a wire runs while the first reader's fetch is still in
+// the XCD's L2 (device/replay_kernels.hpp block_coords keeps the ops of a lane block on one XCD).  On the
+// random wiring of the C2 workload this takes the distinct-line fetches of a level from 1.6 to 1.07 per op.
+template <class Gathered>
+void locality_order(uint32_t* ops, size_t cnt, Gathered&& gathered) {
+  struct Edge {
+    uint32_t wire, pos;
+  };
+  std::vector<Edge> edges;
+  edges.reserve(cnt * 2);
+  std::vector<uint32_t> first_edge(cnt + 1, 0);
+  for (size_t p = 0; p < cnt; ++p) {
+    uint32_t w[4];
+    const int k = gathered(ops[p], w);
+    for (int j = 0; j < k; ++j) edges.push_back({w[j], (uint32_t)p});
+  }
+  std::sort(edges.begin(), edges.end(), [](const Edge& x, const Edge& y) { return x.wire != y.wire ? x.wire < y.wire : x.pos < y.pos; });
+  // wire rank -> [begin, end) in `edges`; per op the ranks of its wires
+  std::vector<uint32_t> wire_begin;
+  std::vector<uint32_t> op_wires(cnt * 4, 0xFFFFFFFFu);
+  std::vector<uint8_t> op_nw(cnt, 0);
+  for (size_t e = 0; e < edges.size(); ++e) {
+    if (e == 0 || edges[e].wire != edges[e - 1].wire) wire_begin.push_back((uint32_t)e);
+    const uint32_t rank = (uint32_t)wire_begin.size() - 1, p = edges[e].pos;
+    if (op_nw[p] < 4 && (op_nw[p] == 0 || op_wires[4 * p + op_nw[p] - 1] != rank)) op_wires[4 * p + op_nw[p]++] = rank;
+  }
+  wire_begin.push_back((uint32_t)edges.size());
+  std::vector<uint8_t> visited(cnt, 0), expanded(wire_begin.size(), 0);
+  std::vector<uint32_t> out, stack;
+  out.reserve(cnt);
+  for (size_t root = 0; root < cnt; ++root) {
+    if (visited[root]) continue;
+    stack.push_back((uint32_t)root);
+    while (!stack.empty()) {
+      const uint32_t p = stack.back();
+      stack.pop_back();
+      if (visited[p]) continue;
+      visited[p] = 1;
+      out.push_back(ops[p]);
+      for (int j = op_nw[p] - 1; j >= 0; --j) {
+        const uint32_t r = op_wires[4 * p + j];
+        const uint32_t b = wire_begin[r], e = wire_begin[r + 1];
+        // a wire with many readers is expanded once; re-pushing its readers at every visit would be quadratic
+        if (e - b > 8) {
+          if (expanded[r]) continue;
+          expanded[r] = 1;
+        }
+        for (uint32_t q = e; q-- > b;)
+          if (!visited[edges[q].pos]) stack.push_back(edges[q].pos);
+      }
+    }
+  }
+  for (size_t p = 0; p < cnt; ++p) ops[p] = out[p];
+}
+
+}  // namespace
+
 Schedule build_schedule(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt) {
   Schedule s;
   const size_t n = tape.size();
@@ -163,6 +223,23 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   std::vector<uint64_t> level_start(n_levels + 1);
   for (uint32_t l = 0; l <= n_levels; ++l) level_start[l] = bucket[(size_t)l * kKinds];
 
+  // wires an op gathers from the table (resolved through elided copies and fused producers)
+  auto gathered = [&](uint32_t i, uint32_t out[4]) {
+    int k = 0;
+    const int ni = n_inputs(tape.kind[i]);
+    auto push = [&](uint32_t p) {
+      if (absorbed[p] == 1) {
+        out[k++] = opa[p];
+        out[k++] = opb[p];
+      } else {
+        out[k++] = p;
+      }
+    };
+    if (ni >= 1) push(opa[i]);
+    if (ni == 2) push(opb[i]);
+    return k;
+  };
+
   // ---- slots: liveness-based reuse, level by level ----------------------
   std::vector<uint32_t> free_slots;
   std::vector<uint32_t> expire_head(n_levels + 1, kInf), expire_next(n, kInf);  // intrusive lists per last_use level
@@ -188,6 +265,8 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
         k = e;
       }
     }
+    if (opt.sort_by_operand >= 2 && !s.boolean_path && level_start[l + 1] - level_start[l] > 8)
+      locality_order(order.data() + level_start[l], level_start[l + 1] - level_start[l], gathered);
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
       const uint32_t i = order[k];
       if (tape.kind[i] == TK_ASSERT || tape.kind[i] == TK_NOP) continue;

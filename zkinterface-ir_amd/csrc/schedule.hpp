@@ -37,7 +37,7 @@ struct Launch {
 struct ScheduleOptions {
   bool retain_all = false;          // every value keeps its own slot (wire dumps for parity tests)
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
-  bool sort_by_operand = true;      // order a level's ops by first-operand slot (cache locality)
+  int sort_by_operand = 2;          // order of a level's ops: 0 tape order, 1 by first-operand slot, 2 shared-operand walk
   bool fuse = true;                 // absorb single-reader Add/Mul producers into their consumer (never with retain_all)
   bool propagate_copies = true;     // readers use a copy's source; unobserved copies are not materialised (never with retain_all)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
