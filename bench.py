@@ -277,7 +277,8 @@ def main():
     if args.workload == 'c5':
         return bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev)
     if args.workload == 'c2':
-        wl = workloads.ArithLayered(W=args.width or 4096, D=args.depth or 256)
+        mp = os.environ.get('ZKI_C2_MUL_PERCENT')  # developer sensitivity runs only; the metric is quoted on the default mix
+        wl = workloads.ArithLayered(W=args.width or 4096, D=args.depth or 256, mul_percent=int(mp) if mp else None)
         batch = args.batch_per_gpu or 1024
         bytes_table, bool_path = BYTES_PER_OP, None
     else:

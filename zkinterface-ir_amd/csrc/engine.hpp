@@ -42,6 +42,7 @@ class Engine {
   void set_xcd_map(bool on) { xcd_map_ = on; }
   void set_streams(uint32_t n) { n_streams_ = n < 1 ? 1 : (n > kMaxStreams ? kMaxStreams : n); }
   static constexpr uint32_t kMaxStreams = 4;
+  static constexpr uint64_t kInfinityCacheBudget = 288ull << 20;  // wire-table bytes kept in flight per lane group
   // GF(2): 0 = pick automatically, 1 = force the HBM-table kernel, 2 = require the LDS-resident kernel
   void set_bool_path(int mode) { bool_path_ = mode; }
   bool uses_lds_path() const { return lds_path_; }
