@@ -238,6 +238,45 @@ def test_full_size_c2_properties():
         assert ev.get_violations(lane) == ref.violations
 
 
+@pytest.mark.parametrize('batch', [1100, 2560])
+def test_grid_mappings_and_op_orders_agree(batch):
+    """Every launch geometry gives the same per-lane answer as the CPU evaluator of the same tape: XCD-aware grid
+    (2560 lanes = 40 lane blocks: shares of 16 + 24, two and three groups per XCD) and the plain grid (1100
+    lanes = 18 lane blocks, not a multiple of 8), two ops per wave on 4096-wide levels, the three op orders,
+    one to three streams, explicit lane groups."""
+    from oracle_lib import opt_eval
+    wl = workloads.ArithLayered(W=4096, D=5, n_instance0=64, n_out=16)
+    ev, inst, wit, n_bad = _layered_session(wl, batch)
+    ev.replay()
+    ev.synchronize()
+    base = ev.lane_results(batch)
+    assert ev.counts() == (batch - n_bad, n_bad)
+    kinds, ta, tb = ev.tape()
+    ff_cpu, _, _ = opt_eval(kinds, ta, tb, ev.constants(), wl.mod_le, inst.tobytes(), wl.n_instance, wit.tobytes(),
+                            wl.n_witness, wl.width, batch, 8)
+    assert np.array_equal(ff_cpu, base[0])
+    for opts in ({'xcd_map': 0}, {'streams': 1}, {'streams': 3}, {'xcd_map': 1, 'streams': 2}):
+        for k, v in opts.items():
+            ev.set_option(k, str(v))
+        for group in (0, 512, 1024):
+            ev.set_lane_group(group)
+            ev.replay()
+            ev.synchronize()
+            got = ev.lane_results(batch)
+            assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), (opts, group)
+    for order in (0, 1):
+        other = zk.Evaluator()
+        other.set_option('sort_by_operand', str(order))
+        other.declare_inputs(wl.n_instance, wl.n_witness)
+        for m in wl.relation_messages():
+            other.ingest_message(m)
+        other.finalize()
+        other.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+        other.replay()
+        other.synchronize()
+        assert np.array_equal(other.lane_results(batch)[0], base[0]), order
+
+
 @pytest.mark.parametrize('seed', range(25, 45))
 def test_random_structured_relations_on_gpu_compact_schedule(seed):
     """same fuzz through the production schedule (slot reuse, operand ordering, gate fusion, two
