@@ -139,6 +139,13 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value);
  * zkgpu_stats_json = serde_json::to_writer_pretty(&stats); zkgpu_stats_warnings = its stderr lines.
  * String getters return the full length and write at most cap-1 bytes + NUL. */
 size_t zkgpu_validator_violations(zkgpu_session* s, char* buf, size_t cap);
+/* values of the ingested Instance (witness = 0) / Witness (witness = 1) messages, in stream order: what
+ * `Evaluator::ingest_instance/ingest_witness` queued (rust/src/consumers/evaluator.rs:239-257).  _values = how
+ * many; _value copies up to cap bytes of value `index` (little-endian, as sent) and returns its length. */
+uint32_t zkgpu_message_values(const zkgpu_session* s, int witness);
+/* the field characteristic the backend was given (`set_field`), little-endian as sent; 0 = no field yet */
+size_t zkgpu_modulus(const zkgpu_session* s, uint8_t* buf, size_t cap);
+size_t zkgpu_message_value(const zkgpu_session* s, int witness, uint32_t index, uint8_t* buf, size_t cap);
 int zkgpu_validator_count(zkgpu_session* s);        /* -1 when the validator is off */
 int zkgpu_validator_live_wires(zkgpu_session* s);
 size_t zkgpu_stats_json(zkgpu_session* s, char* buf, size_t cap);

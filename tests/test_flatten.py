@@ -47,3 +47,28 @@ def test_flattened_relation_re_evaluates_like_the_original(name):
     ev2 = zk.Evaluator.from_messages([fi, fw, rel])
     assert ev2.host_violations() == []
     assert ev2.n_asserts == ev.n_asserts and ev2.n_value_ops == ev.n_value_ops + ev.n_asserts
+
+
+def test_flatten_tool_writes_an_equisatisfiable_workspace(tmp_path):
+    """`flatten <workspace> --out <dir>` (cli.rs:442-472) through the file sink."""
+    import io
+    from zkinterface_ir_amd import cli
+    for name, sat in (('arith_101_correct', True), ('arith_101_incorrect', False), ('bool_correct', True)):
+        src, dst = tmp_path / (name + '_src'), tmp_path / (name + '_flat')
+        src.mkdir()
+        for k, b in enumerate(golden_buffers(name)):
+            (src / ('%03d.sieve' % k)).write_bytes(b)
+        err = io.StringIO()
+        assert cli.main(['flatten', str(src), '--out', str(dst)], err=err) == 0, err.getvalue()
+        assert sorted(p.name for p in dst.iterdir()) == ['000_instance.sieve', '001_witness.sieve', '002_relation.sieve']
+        flat = OracleRun(files=[str(dst / n) for n in ('000_instance.sieve', '001_witness.sieve', '002_relation.sieve')])
+        assert (flat.violations == []) == sat
+        # only simple gates, and the validator accepts the result
+        ev = zk.Evaluator()
+        ev.set_option('validate', 'prover')
+        ev.set_option('metrics', '1')
+        ev.ingest_paths([str(dst)])
+        assert ev.validator_violations() == []
+        gs = ev.stats()['gate_stats']
+        assert gs['functions_called'] == gs['switches'] == gs['for_loops'] == 0
+    assert cli.main(['flatten', str(src), '--out', str(tmp_path / 'x.sieve')], err=io.StringIO()) == 1

@@ -84,6 +84,9 @@ def lib():
         'zkgpu_set_inputs_from_messages': (ci, [vp]),
         'zkgpu_set_lane_group': (ci, [vp, u32]),
         'zkgpu_set_option': (ci, [vp, ctypes.c_char_p, ctypes.c_char_p]),
+        'zkgpu_modulus': (sz, [vp, ctypes.c_char_p, sz]),
+        'zkgpu_message_values': (u32, [vp, ci]),
+        'zkgpu_message_value': (sz, [vp, ci, u32, ctypes.c_char_p, sz]),
         'zkgpu_validator_violations': (sz, [vp, ctypes.c_char_p, sz]),
         'zkgpu_validator_count': (ci, [vp]),
         'zkgpu_validator_live_wires': (ci, [vp]),
@@ -182,6 +185,22 @@ class Evaluator:
     def host_violations(self):
         s = self._text(self.L.zkgpu_host_violations)
         return s.split('\n') if s else []
+
+    def modulus_le(self):
+        n = self.L.zkgpu_modulus(self.h, None, 0)
+        buf = ctypes.create_string_buffer(max(n, 1))
+        self.L.zkgpu_modulus(self.h, buf, n)
+        return buf.raw[:n]
+
+    def message_values(self, witness=False):
+        """Values of the ingested Instance / Witness messages in stream order (little-endian bytes as sent)."""
+        out = []
+        for k in range(self.L.zkgpu_message_values(self.h, int(witness))):
+            n = self.L.zkgpu_message_value(self.h, int(witness), k, None, 0)
+            buf = ctypes.create_string_buffer(max(n, 1))
+            self.L.zkgpu_message_value(self.h, int(witness), k, buf, n)
+            out.append(buf.raw[:n])
+        return out
 
     # -- the other two consumers of `valid-eval-metrics` (cli.rs:333-363) -------
     def validator_violations(self):

@@ -513,6 +513,24 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
   });
 }
 
+size_t zkgpu_modulus(const zkgpu_session* s, uint8_t* buf, size_t cap) {
+  if (!s || !s->backend.field_set()) return 0;
+  const Value& m = s->backend.modulus();
+  if (buf && cap) memcpy(buf, m.data(), std::min(cap, m.size()));
+  return m.size();
+}
+uint32_t zkgpu_message_values(const zkgpu_session* s, int witness) {
+  if (!s) return 0;
+  return (uint32_t)(witness ? s->backend.lane0_witnesses().size() : s->backend.lane0_instances().size());
+}
+size_t zkgpu_message_value(const zkgpu_session* s, int witness, uint32_t index, uint8_t* buf, size_t cap) {
+  if (!s) return 0;
+  const auto& v = witness ? s->backend.lane0_witnesses() : s->backend.lane0_instances();
+  if (index >= v.size()) return 0;
+  if (buf && cap) memcpy(buf, v[index].data(), std::min(cap, v[index].size()));
+  return v[index].size();
+}
+
 size_t zkgpu_validator_violations(zkgpu_session* s, char* buf, size_t cap) {
   if (!s || !s->validator) return copy_out("", buf, cap);
   return copy_out(join_lines(s->validator->get_violations()), buf, cap);

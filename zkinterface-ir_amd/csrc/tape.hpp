@@ -104,6 +104,7 @@ class TapeBackend {
   // Loops are unrolled into the tape; a limit keeps a corrupt or hostile bound from exhausting the host.
   void set_max_ops(uint64_t n) { max_ops_ = n; }
   const FieldHost& field() const { return field_; }
+  const Value& modulus() const { return modulus_; }  // bytes given to set_field
   bool field_set() const { return field_set_; }
   bool is_boolean() const { return is_boolean_; }
   const std::vector<Value>& lane0_instances() const { return lane0_instances_; }

@@ -56,3 +56,26 @@ def flattened_inputs(modulus_le, instance_values, witness_values, positions):
     (values = lists of little-endian byte strings of the original statement)."""
     return (write_instance(modulus_le, [instance_values[p] for p in positions['instance']]),
             write_witness(modulus_le, [witness_values[p] for p in positions['witness']]))
+
+
+def flatten_workspace(paths, out_dir):
+    """`zki_sieve flatten <paths> --out <dir>` (cli.rs:442-472): record the statement, write the flattened
+    relation and its own instance / witness streams through a FilesSink (000_instance / 001_witness /
+    002_relation .sieve).  Returns the Evaluator that recorded it."""
+    from . import Evaluator
+    from .builder import FilesSink
+    ev = Evaluator()
+    ev.ingest_paths(list(paths))
+    v = ev.host_violations()
+    if v:
+        raise ValueError('; '.join(v))
+    boolean = ev.elem_bytes == 1 if ev.n_value_ops else False
+    mod_le = ev.modulus_le()
+    rel, positions = flatten(ev, mod_le, boolean=boolean)
+    fi, fw = flattened_inputs(mod_le, ev.message_values(False), ev.message_values(True), positions)
+    sink = FilesSink.new_clean(out_dir)
+    sink.push_instance_message(fi)
+    sink.push_witness_message(fw)
+    sink.push_relation_message(rel)
+    sink.close()
+    return ev
