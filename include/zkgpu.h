@@ -121,6 +121,8 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "sort_by_operand" = 0|1|2 (order of the ops inside a level: tape order, by first operand, or a depth-first
  * walk over shared operands so that the readers of a wire run back to back; default 2),
  * "xcd_map" = 0|1 (launches over a multiple of 8 lane blocks give each XCD its own lane blocks; default 1),
+ * "level_ops_per_wave" = 1..8 (program entries of a wide level walked by one wave, interleaved over the 4 waves
+ * of a workgroup; default 2),
  * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),
  * "propagate_copies" = 0|1 (readers use a copy's source, unobserved copies are not materialised; never with retain_all),
  * "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a

@@ -239,6 +239,7 @@ struct ReplayArgs2 {
   u32* first_fail;
   u32* lane_flags;
   u32 xcd_chunks;
+  u32 op_stride;          // 1 or 4, see the kernel
 };
 
 // Replay of the fused schedule: an Add/Mul operand may be `add(a0,a1)` / `mul(a0,a1)` evaluated in
@@ -251,15 +252,18 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
   u32 chunk, lb_rel;
   block_coords(args.xcd_chunks, chunk, lb_rel);
   const u32 lb = args.lb_base + lb_rel;
-  const u32 gw = chunk * (blockDim.x >> 6) + wave;
-  const u32 begin = gw * args.ops_per_wave;
+  // Ops of a workgroup: consecutive per wave (op_stride 1: sequential segments must keep their order), or
+  // interleaved over its 4 waves (op_stride 4, levels): the neighbours of the shared-operand order then run
+  // at the same time in neighbouring waves, not one after the other in one wave.
+  const u32 stride = args.op_stride;
+  const u32 begin = stride == 1 ? (chunk * 4 + wave) * args.ops_per_wave : chunk * 4 * args.ops_per_wave + wave;
   if (begin >= args.n_ops) return;
-  const u32 end = min(args.n_ops, begin + args.ops_per_wave);
+  const u32 end = min(args.n_ops, begin + args.ops_per_wave * stride);
   const u32 lane_g = lb * 64 + lane;
   const bool lane_valid = lane_g < args.batch;
   uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
   constexpr int REC = Layout<N>::kRecord;
-  for (u32 i = begin; i < end; ++i) {
+  for (u32 i = begin; i < end; i += stride) {
     const TapeOp2 op = args.ops[i];
     const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
     Fp<N> r;

@@ -326,7 +326,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   const Launch& L = sched_.launches[li];
   // Wide levels of the fused program walk two ops per wave: half as many waves to dispatch, same registers
   // (measured on C2: 9.83 -> 9.48 ms; three or more per wave lose again to the shorter grid).
-  const uint32_t opw = (sched_.fused && !boolean_ && !L.sequential && L.count >= 2048) ? 2 : L.ops_per_wave;
+  const uint32_t opw = (sched_.fused && !boolean_ && !L.sequential && L.count >= 1024 * level_ops_per_wave_) ? level_ops_per_wave_ : L.ops_per_wave;
   const uint32_t waves = (L.count + opw - 1) / opw;
   const uint32_t chunks = (waves + 3) / 4;
   dim3 grid(chunks, lbs);
@@ -369,6 +369,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.lane_flags = (zkgpu::u32*)d_flags_;
     a.xcd_chunks = xcd_chunks;
+    a.op_stride = (L.sequential || opw == 1) ? 1 : 4;
     switch (nwords_) {
       case 2: zkgpu::replay_fused_kernel<2><<<grid, 256, 0, st>>>(a, fp); break;
       case 4: zkgpu::replay_fused_kernel<4><<<grid, 256, 0, st>>>(a, fp); break;

@@ -40,6 +40,7 @@ class Engine {
   // Replay the lane blocks as `n` interleaved halves on `n` HIP streams (1..4): the levels of one
   // half fill the kernel-boundary bubbles and wave tails of the other.
   void set_xcd_map(bool on) { xcd_map_ = on; }
+  void set_level_ops_per_wave(uint32_t n) { level_ops_per_wave_ = n < 1 ? 1 : (n > 8 ? 8 : n); }
   void set_streams(uint32_t n) { n_streams_ = n < 1 ? 1 : (n > kMaxStreams ? kMaxStreams : n); }
   static constexpr uint32_t kMaxStreams = 4;
   static constexpr uint64_t kInfinityCacheBudget = 288ull << 20;  // wire-table bytes kept in flight per lane group
@@ -96,6 +97,7 @@ class Engine {
   void* ev_join_[3] = {nullptr, nullptr, nullptr};
   uint32_t n_streams_ = 2;
   bool xcd_map_ = true;
+  uint32_t level_ops_per_wave_ = 2;
   void* ev_begin_ = nullptr;
   void* ev_end_ = nullptr;
   std::vector<void*> launch_events_;
