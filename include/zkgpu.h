@@ -102,7 +102,8 @@ uint32_t zkgpu_n_witness(const zkgpu_session* s);
 /* ... out[5]=device ops out[6]=constant words out[7]=words per constant */
 int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]);
 /* the device program itself (host-logic tests interpret it without a GPU): ops4 points at 8 words per op
- * {dst, kind | a_expr << 8 | b_expr << 10, a0, a1, b0, b1, 0, 0} (expr: 0 = the slot, 1 = add(x0,x1), 2 = mul(x0,x1)),
+ * {dst, kind | a_expr << 8 | b_expr << 10 | second << 12, a0, a1, b0, b1, dst2, c0} (expr: 0 = the slot,
+ * 1 = add(x0,x1), 2 = mul(x0,x1); second != 0: pair entry, also dst2 = add (1) / mul (2) of operand a and slot c0),
  * launches4 = {first,count,ops_per_wave,sequential} per launch, const_words = constant pool in device form,
  * slot_of[i] = wire-table slot of tape op i (0xFFFFFFFF for asserts).  Any pointer may be NULL. */
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
@@ -124,6 +125,8 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "level_ops_per_wave" = 1..8 (program entries of a wide level walked by one wave, interleaved over the 4 waves
  * of a workgroup; default 2),
  * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),
+ * "pair" = 0|1 (an Add/Mul read by exactly two Add/Mul gates of one level is evaluated once inside a pair entry
+ * that produces both readers' values; part of "fuse", never with retain_all),
  * "propagate_copies" = 0|1 (readers use a copy's source, unobserved copies are not materialised; never with retain_all),
  * "bool_path" = "auto" | "hbm" | "lds"  (GF(2): HBM wire table, or the whole wire table of a
  * 32-witness slice resident in one CU's LDS when the live wires fit in 160 KiB).  Set before zkgpu_set_inputs*.

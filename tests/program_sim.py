@@ -1,5 +1,5 @@
 """Test infrastructure: interprets the *scheduled device program* exported by
-zkgpu_schedule_dump() (8 words per op: dst, kind + operand-expression bits, a0, a1, b0, b1) with Python integers, launch by launch and slot by slot,
+zkgpu_schedule_dump() (8 words per op: dst, kind + operand-expression bits, a0, a1, b0, b1, dst2, c0) with Python integers, launch by launch and slot by slot,
 exactly as the HIP kernels would (Montgomery domain for odd p, bits for p=2).
 It lets the CPU-only test tier check the host logic -- tape recording,
 levelisation, slot reuse, constant pool -- against the oracle without a GPU.
@@ -36,8 +36,8 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
         pending = []
         reads = set()
         for i in idx:
-            dst, kbits, a, a1, b, b1 = (int(x) for x in ops[i][:6])
-            kind, ea, eb = kbits & 0xFF, (kbits >> 8) & 3, (kbits >> 10) & 3
+            dst, kbits, a, a1, b, b1, dst2, c0 = (int(x) for x in ops[i][:8])
+            kind, ea, eb, second = kbits & 0xFF, (kbits >> 8) & 3, (kbits >> 10) & 3, (kbits >> 12) & 3
 
             def operand(x0, x1, e):  # a slot, or add / mul of two slots evaluated "in registers" (gate fusion)
                 reads.add(x0)
@@ -59,6 +59,17 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                     r = x & y
                 else:
                     r = x ^ y
+                if second:  # pair entry: a second gate of the level shares operand a
+                    assert kind in (OP['add'], OP['mul'])
+                    reads.add(c0)
+                    z = slots[c0]
+                    assert z is not None, 'read of an unwritten slot'
+                    r2 = (x + z) % p if second == 1 else x * z * rinv % p
+                    if sequential:
+                        assert dst2 != dst
+                        slots[dst2] = r2
+                    else:
+                        pending.append((dst2, r2))
             elif kind in (OP['addc'], OP['mulc']):
                 x = slots[a]
                 reads.add(a)

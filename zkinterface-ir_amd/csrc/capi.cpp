@@ -31,6 +31,7 @@ struct zkgpu_session {
   int sort_by_operand = 2;
   bool fuse = true;
   bool propagate_copies = true;
+  bool pair = true;
   uint32_t n_streams = 2;
   bool xcd_map = true;
   uint32_t level_ops_per_wave = 2;
@@ -366,6 +367,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     ScheduleOptions opt;
     opt.retain_all = retain_all != 0;
     opt.sort_by_operand = s->sort_by_operand;
+    opt.pair = s->pair;
     opt.fuse = s->fuse;
     opt.propagate_copies = s->propagate_copies;
     s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
@@ -377,6 +379,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     for (size_t i = 0; i < t.size(); ++i)
       if (t.kind[i] != TK_ASSERT) s->value_op_index.push_back((uint32_t)i);
     s->engine.reset();
+    Engine::validate_program(s->sched, lane_inputs(s, true), lane_inputs(s, false));  // host check of every index the kernels use
     s->finalized = true;
     s->results_fresh = false;
   });
@@ -495,6 +498,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "xcd_map") {
       s->xcd_map = v != "0";
       if (s->engine) s->engine->set_xcd_map(s->xcd_map);
+    } else if (k == "pair") {
+      s->pair = v != "0";
     } else if (k == "propagate_copies") {
       s->propagate_copies = v != "0";
     } else if (k == "fuse") {

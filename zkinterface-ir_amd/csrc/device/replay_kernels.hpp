@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
     const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
     Fp<N> r;
     bool has_out = true;
+    u32 dst_slot = op.dst;
     switch (kind) {
       case OP_ADD:
       case OP_MUL: {
@@ -296,6 +297,15 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
         if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp) : fp_mul<N>(x0, x1, fp);
         if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp) : fp_mul<N>(y0, y1, fp);
         r = kind == OP_ADD ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
+        const u32 pair = (op.kind >> 12) & 3;
+        if (pair) {
+          // a second gate of the same level fed by the shared producer X: store the first result, fetch the second
+          // gate's other operand into registers the first no longer needs, and let the common store write it
+          wire_store<N>(T + (size_t)dst_slot * REC, r);
+          y0 = wire_load<N>(T + (size_t)op.pad1 * REC);
+          r = pair == 1 ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
+          dst_slot = op.pad0;
+        }
         break;
       }
       case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
       }
       default: has_out = false; break;
     }
-    if (has_out) wire_store<N>(T + (size_t)op.dst * REC, r);
+    if (has_out) wire_store<N>(T + (size_t)dst_slot * REC, r);
   }
 }
 

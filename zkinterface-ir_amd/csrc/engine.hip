@@ -111,6 +111,57 @@ void Engine::free_batch() {
   batch_ = 0;
 }
 
+// Every index a kernel will dereference is checked on the host before the program is uploaded: a slot, constant
+// or input position out of range must be an exception here, never a memory fault on the GPU.
+void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness) {
+  const uint32_t wpc = s.words_per_const ? s.words_per_const : 1;
+  const uint64_t n_consts = s.const_words.size() / wpc;
+  auto fail = [](size_t i, const char* what) {
+    throw std::runtime_error("Engine: program entry " + std::to_string(i) + " has " + what + " out of range");
+  };
+  auto slot = [&](size_t i, uint32_t v) {
+    if (v >= s.n_slots) fail(i, ("a wire-table slot (" + std::to_string(v) + " of " + std::to_string(s.n_slots) + ")").c_str());
+  };
+  auto check = [&](size_t i, uint32_t kind, uint32_t dst, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t ea,
+                   uint32_t eb, uint32_t second, uint32_t dst2, uint32_t c0) {
+    switch (kind) {
+      case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR:
+        slot(i, dst); slot(i, a0); slot(i, b0);
+        if (ea) slot(i, a1);
+        if (eb) slot(i, b1);
+        if (second) { slot(i, dst2); slot(i, c0); }
+        break;
+      case TK_ADDC: case TK_MULC:
+        slot(i, dst); slot(i, a0);
+        if (b0 >= n_consts) fail(i, "a constant");
+        break;
+      case TK_COPY: case TK_NOT: slot(i, dst); slot(i, a0); break;
+      case TK_CONST:
+        slot(i, dst);
+        if (a0 >= n_consts) fail(i, "a constant");
+        break;
+      case TK_INSTANCE: slot(i, dst); if (a0 >= n_instance) fail(i, "an instance position"); break;
+      case TK_WITNESS: slot(i, dst); if (a0 >= n_witness) fail(i, "a witness position"); break;
+      case TK_ASSERT: slot(i, a0); break;
+      case TK_NOP: break;
+      default: fail(i, "an unknown kind");
+    }
+  };
+  for (size_t i = 0; i < s.ops2.size() && s.fused; ++i) {
+    const DevOp2& d = s.ops2[i];
+    const uint32_t kind = d.kind & 0xFF, ea = (d.kind >> 8) & 3, eb = (d.kind >> 10) & 3, second = (d.kind >> 12) & 3;
+    if ((d.kind >> 14) != 0 || ((ea || eb || second) && kind != TK_ADD && kind != TK_MUL)) fail(i, "its kind word");
+    check(i, kind, d.dst, d.a0, d.a1, d.b0, d.b1, ea, eb, second, d.pad0, d.pad1);
+  }
+  for (size_t i = 0; i < s.ops.size() && !s.fused; ++i) {
+    const DevOp& d = s.ops[i];
+    check(i, d.kind, d.dst, d.a, 0, d.b, 0, 0, 0, 0, 0, 0);
+  }
+  size_t n_ops = s.fused ? s.ops2.size() : s.ops.size();
+  for (const Launch& L : s.launches)
+    if ((uint64_t)L.first + L.count > n_ops) throw std::runtime_error("Engine: a launch reaches past the program");
+}
+
 void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness) {
   free_batch();
   dfree(d_ops_);
@@ -133,6 +184,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   fp.nwords = f.nwords;
   memset(field_params_, 0, sizeof field_params_);
   memcpy(field_params_, &fp, sizeof fp);
+  validate_program(s, n_instance, n_witness);
   if (s.fused) {
     HIP_OK(hipMalloc(&d_ops_, s.ops2.size() * sizeof(DevOp2)));
     HIP_OK(hipMemcpy(d_ops_, s.ops2.data(), s.ops2.size() * sizeof(DevOp2), hipMemcpyHostToDevice));

@@ -26,6 +26,7 @@ class Engine {
   Engine& operator=(const Engine&) = delete;
 
   // Upload the program.  n_instance / n_witness = values per witness stream.
+  static void validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness);
   void load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness);
   // Bytes per input value the batch buffers must use: 4*nwords (arithmetic) or 1 (GF(2)).
   uint32_t elem_bytes() const { return elem_bytes_; }

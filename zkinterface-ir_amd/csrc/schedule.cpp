@@ -183,14 +183,19 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   // (depth 1: an op that absorbs cannot be absorbed, an absorbed op has absorbed nothing).  The value is
   // then never materialised, so this is only done when nobody can ask for it afterwards.
   const bool fuse = opt.fuse && !opt.retain_all && !s.boolean_path;
+  std::vector<uint32_t> pair_second;  // first gate of a pair entry -> second gate (allocated when pairing runs)
   if (fuse) {
-    std::vector<uint32_t> reads(n, 0), reader(n, 0);
+    std::vector<uint32_t> reads(n, 0), reader(n, 0), reader0(n, 0);
     std::vector<uint8_t> has_absorbed(n, 0);
+    auto note_read = [&](uint32_t p, size_t i) {
+      if (reads[p]++ == 0) reader0[p] = (uint32_t)i;
+      reader[p] = (uint32_t)i;
+    };
     for (size_t i = 0; i < n; ++i) {
       if (absorbed[i]) continue;
       const int ni = n_inputs(tape.kind[i]);
-      if (ni >= 1) { ++reads[opa[i]]; reader[opa[i]] = (uint32_t)i; }
-      if (ni == 2) { ++reads[opb[i]]; reader[opb[i]] = (uint32_t)i; }
+      if (ni >= 1) note_read(opa[i], i);
+      if (ni == 2) note_read(opb[i], i);
     }
     auto arith = [&](size_t i) { return tape.kind[i] == TK_ADD || tape.kind[i] == TK_MUL; };
     for (size_t i = 0; i < n; ++i) {
@@ -203,6 +208,31 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
       // the producer's operands are now read at the consumer's level
       last_use[opa[i]] = std::max(last_use[opa[i]] == kInf ? kInf : last_use[opa[i]], level[c]);
       last_use[opb[i]] = std::max(last_use[opb[i]] == kInf ? kInf : last_use[opb[i]], level[c]);
+    }
+    // Shared producers: an Add/Mul read by exactly two Add/Mul gates of one level is evaluated once inside a
+    // *pair entry* that produces both readers' values (X = producer; r1 = X o Y -> dst, r2 = X o Z -> dst2).
+    // X is never materialised: one store and two loads less.  Y may itself be a fused producer, Z is a plain wire.
+    if (opt.pair) {
+      pair_second.assign(n, kInf);
+      std::vector<uint8_t> in_pair(n, 0);
+      for (size_t i = 0; i < n; ++i) {
+        if (absorbed[i] || !arith(i) || reads[i] != 2 || last_use[i] == kInf || has_absorbed[i] || in_pair[i]) continue;
+        uint32_t c1 = reader0[i], c2 = reader[i];
+        if (c1 == c2 || !arith(c1) || !arith(c2) || absorbed[c1] || absorbed[c2] || in_pair[c1] || in_pair[c2] ||
+            level[c1] != level[c2])
+          continue;
+        if (has_absorbed[c2]) std::swap(c1, c2);  // the second gate's other operand must be a plain wire
+        if (has_absorbed[c2]) continue;
+        absorbed[i] = 3;
+        absorbed[c2] = 4;
+        pair_second[c1] = c2;
+        has_absorbed[c1] = 1;
+        in_pair[c1] = in_pair[c2] = 1;
+        ++s.n_absorbed;
+        ++s.n_paired;
+        last_use[opa[i]] = std::max(last_use[opa[i]] == kInf ? kInf : last_use[opa[i]], level[c1]);
+        last_use[opb[i]] = std::max(last_use[opb[i]] == kInf ? kInf : last_use[opb[i]], level[c1]);
+      }
     }
     s.fused = s.n_absorbed != 0;
   }
@@ -228,16 +258,18 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
     int k = 0;
     const int ni = n_inputs(tape.kind[i]);
     auto push = [&](uint32_t p) {
-      if (absorbed[p] == 1) {
-        out[k++] = opa[p];
-        out[k++] = opb[p];
-      } else {
+      if (absorbed[p] == 1 || absorbed[p] == 3) {
+        if (k + 2 <= 4) {
+          out[k++] = opa[p];
+          out[k++] = opb[p];
+        }
+      } else if (k < 4) {
         out[k++] = p;
       }
     };
     if (ni >= 1) push(opa[i]);
     if (ni == 2) push(opb[i]);
-    return k;
+    return k;  // (a pair entry's fifth wire, the second gate's own operand, is left out of the locality graph)
   };
 
   // ---- slots: liveness-based reuse, level by level ----------------------
@@ -258,8 +290,9 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
         while (e < level_start[l + 1] && tape.kind[order[e]] == kind) ++e;
         if (n_inputs(kind) >= 1 && e - k > 1)
           std::stable_sort(order.begin() + k, order.begin() + e, [&](uint32_t x, uint32_t y) {
-            const uint32_t ax = absorbed[opa[x]] ? opa[opa[x]] : opa[x];
-            const uint32_t ay = absorbed[opa[y]] ? opa[opa[y]] : opa[y];
+            auto inner = [&](uint32_t h) { return absorbed[h] == 1 || absorbed[h] == 3; };
+            const uint32_t ax = inner(opa[x]) ? opa[opa[x]] : opa[x];
+            const uint32_t ay = inner(opa[y]) ? opa[opa[y]] : opa[y];
             return s.slot_of[ax] < s.slot_of[ay];
           });
         k = e;
@@ -282,6 +315,20 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
         expire_next[i] = expire_head[last_use[i]];
         expire_head[last_use[i]] = i;
       }
+      if (!pair_second.empty() && pair_second[i] != kInf) {  // the second value of a pair entry needs a slot too
+        const uint32_t j = pair_second[i];
+        if (!free_slots.empty()) {
+          slot = free_slots.back();
+          free_slots.pop_back();
+        } else {
+          slot = n_slots++;
+        }
+        s.slot_of[j] = slot;
+        if (last_use[j] != kInf) {
+          expire_next[j] = expire_head[last_use[j]];
+          expire_head[last_use[j]] = j;
+        }
+      }
     }
   }
   s.n_slots = std::max<uint32_t>(n_slots, 1);
@@ -295,7 +342,7 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
       DevOp2 d{0, kind, 0, 0, 0, 0, 0, 0};
       d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
       auto operand = [&](uint32_t h, uint32_t* x0, uint32_t* x1, int shift) {
-        if (absorbed[h]) {
+        if (absorbed[h] == 1 || absorbed[h] == 3) {  // evaluated inside this entry (4 = second value of a pair entry: has a slot)
           *x0 = s.slot_of[opa[h]];
           *x1 = s.slot_of[opb[h]];
           d.kind |= (tape.kind[h] == TK_ADD ? 1u : 2u) << shift;
@@ -305,8 +352,21 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
       };
       switch (kind) {
         case TK_ADD: case TK_MUL:
-          operand(opa[i], &d.a0, &d.a1, 8);
-          operand(opb[i], &d.b0, &d.b1, 10);
+          if (!pair_second.empty() && pair_second[i] != kInf) {
+            // pair entry: the shared producer goes first (Add/Mul commute), then the second gate's result slot
+            // and its own operand
+            const uint32_t j = pair_second[i];
+            const uint32_t x = absorbed[opa[i]] == 3 ? opa[i] : opb[i];
+            const uint32_t y = absorbed[opa[i]] == 3 ? opb[i] : opa[i];
+            operand(x, &d.a0, &d.a1, 8);
+            operand(y, &d.b0, &d.b1, 10);
+            d.kind |= (tape.kind[j] == TK_ADD ? 1u : 2u) << 12;
+            d.pad0 = s.slot_of[j];
+            d.pad1 = s.slot_of[opa[j] == x ? opb[j] : opa[j]];
+          } else {
+            operand(opa[i], &d.a0, &d.a1, 8);
+            operand(opb[i], &d.b0, &d.b1, 10);
+          }
           break;
         case TK_ADDC: case TK_MULC:
           d.a0 = s.slot_of[opa[i]];
