@@ -238,6 +238,34 @@ def test_full_size_c2_properties():
         assert ev.get_violations(lane) == ref.violations
 
 
+def test_full_size_c2_outputs_match_the_committed_oracle_digests():
+    """tests/golden/c2_digests.json: SHA-256 of the 64 output wires of six lanes of the BASELINE configs[1] relation as
+    the oracle computes them (fixture committed with its generator).  The production schedule (fusion, pair entries,
+    XCD-aware grid) must reproduce them bit for bit."""
+    import hashlib
+    import json
+    import os
+    from helpers import ROOT
+    fx = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'c2_digests.json')))
+    wl = workloads.ArithLayered()
+    batch = 1024
+    inst, wit = wl.inputs(batch)
+    ev = zk.Evaluator()
+    ev.declare_inputs(wl.n_instance0, wl.n_witness)
+    for m in wl.relation_messages(with_epilogue=False, free_last=False):
+        ev.ingest_message(m)
+    ev.finalize()
+    assert ev.schedule_info()['device_ops'] < 700000   # the compact program, not the retain_all one
+    ev.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), batch)
+    ev.replay()
+    ev.synchronize()
+    cols = [ev.get(w, batch) for w in wl.output_wire_ids()]
+    for lane, want in fx['lanes'].items():
+        vals = [col[int(lane)] for col in cols]
+        assert hashlib.sha256('\n'.join(str(v) for v in vals).encode()).hexdigest() == want['sha256'], lane
+        assert str(vals[0]) == want['first_output']
+
+
 @pytest.mark.parametrize('batch', [1100, 2560])
 def test_grid_mappings_and_op_orders_agree(batch):
     """Every launch geometry gives the same per-lane answer as the CPU evaluator of the same tape: XCD-aware grid

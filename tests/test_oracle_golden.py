@@ -92,3 +92,23 @@ def test_cpu_opt_agrees_with_the_literal_oracle():
             assert ref.violations == ['Wire_%d (may be weighted) should be 0, while it is not' % int(ev.assert_wires()[int(ff[0])])]
         else:
             assert int(ff[0]) == 0xFFFFFFFF
+
+
+def test_c2_full_size_digest_fixture_matches_the_oracle():
+    """tests/golden/c2_digests.json (made by tests/golden/make_c2_digests.py) is what the oracle computes for the
+    BASELINE configs[1] relation: one lane is recomputed here, the GPU tier compares all of them."""
+    import hashlib
+    import json
+    import os
+    from helpers import ROOT, oracle_lane
+    from zkinterface_ir_amd import workloads
+    fx = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'c2_digests.json')))
+    wl = workloads.ArithLayered()
+    inst, wit = wl.inputs(98)
+    lane = 97
+    iv = [int.from_bytes(inst[lane, k].tobytes(), 'little') for k in range(wl.n_instance0)]
+    wv = [int.from_bytes(wit[lane, k].tobytes(), 'little') for k in range(wl.n_witness)]
+    run = oracle_lane(wl.mod_le, iv, wv, wl.relation_messages(with_epilogue=False, free_last=False), wl.width, trace=False)
+    vals = [run.get(w) for w in wl.output_wire_ids()]
+    assert hashlib.sha256('\n'.join(str(v) for v in vals).encode()).hexdigest() == fx['lanes'][str(lane)]['sha256']
+    assert str(vals[0]) == fx['lanes'][str(lane)]['first_output']
