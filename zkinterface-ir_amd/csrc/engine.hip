@@ -579,6 +579,19 @@ void Engine::reserve_extra_slots(uint32_t n) {
 void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<R1csTermDev>& terms,
                          const std::vector<uint32_t>& coef_words) {
   if (boolean_) throw std::runtime_error("Engine: the R1CS row kernel needs an arithmetic field");
+  // host check of every index the row kernel dereferences (same rule as validate_program)
+  const uint64_t n_coefs = nwords_ ? coef_words.size() / nwords_ : 0;
+  const uint32_t n_table_slots = sched_.n_slots + extra_slots_;
+  for (size_t r = 0; r < rows.size(); ++r) {
+    const uint32_t n = (rows[r].counts & 0xFF) + ((rows[r].counts >> 8) & 0xFF) + ((rows[r].counts >> 16) & 0xFF);
+    if ((uint64_t)rows[r].first + n > terms.size()) throw std::runtime_error("Engine: R1CS row " + std::to_string(r) + " reaches past the term list");
+  }
+  for (size_t t = 0; t < terms.size(); ++t) {
+    if (terms[t].slot != 0xFFFFFFFFu && terms[t].slot >= n_table_slots)
+      throw std::runtime_error("Engine: R1CS term " + std::to_string(t) + " names a wire-table slot out of range");
+    if (terms[t].coef != 0xFFFFFFFFu && terms[t].coef >= n_coefs)
+      throw std::runtime_error("Engine: R1CS term " + std::to_string(t) + " names a coefficient out of range");
+  }
   dfree(d_r1cs_rows_);
   dfree(d_r1cs_terms_);
   dfree(d_r1cs_coefs_);
