@@ -1,6 +1,7 @@
 #include "stats.hpp"
 
 #include <algorithm>
+#include <array>
 
 namespace zki {
 
@@ -11,24 +12,17 @@ const char* const kNames[GateStats::kFields] = {
     "functions_defined", "functions_called", "switches", "branches", "for_loops", "instance_messages",
     "witness_messages", "relation_messages"};
 
-// ingest_call_stats (stats.rs:268-286): gate and structure counts of a callee are added to the
-// caller; variables, definitions and message counts are not.
+// The counters ingest_call_stats (stats.rs:268-286) carries from a callee to its caller: gate and structure
+// counts; variables, definitions and message counts are not carried.
+std::array<uint64_t*, 15> call_fields(GateStats& g) {
+  return {&g.constants_gates, &g.assert_zero_gates, &g.copy_gates, &g.add_gates, &g.mul_gates, &g.add_constant_gates,
+          &g.mul_constant_gates, &g.and_gates, &g.xor_gates, &g.not_gates, &g.variables_freed, &g.switches,
+          &g.branches, &g.for_loops, &g.functions_called};
+}
 void add_call_stats(GateStats& a, const GateStats& o) {
-  a.constants_gates += o.constants_gates;
-  a.assert_zero_gates += o.assert_zero_gates;
-  a.copy_gates += o.copy_gates;
-  a.add_gates += o.add_gates;
-  a.mul_gates += o.mul_gates;
-  a.add_constant_gates += o.add_constant_gates;
-  a.mul_constant_gates += o.mul_constant_gates;
-  a.and_gates += o.and_gates;
-  a.xor_gates += o.xor_gates;
-  a.not_gates += o.not_gates;
-  a.variables_freed += o.variables_freed;
-  a.switches += o.switches;
-  a.branches += o.branches;
-  a.for_loops += o.for_loops;
-  a.functions_called += o.functions_called;
+  GateStats from = o;
+  const auto dst = call_fields(a), src = call_fields(from);
+  for (size_t k = 0; k < dst.size(); ++k) *dst[k] += *src[k];
 }
 
 std::string json_string(const std::string& s) {
@@ -204,18 +198,8 @@ void Stats::ingest_gate(GateStats& s, const Gate& g) {
         wit = body.witness_count;
       }
       const uint64_t n = x.last - x.first + 1;
-      GateStats scaled;
-      // scale by n: add_call_stats covers the gate/structure counters
-      const uint64_t* src[] = {&once.constants_gates, &once.assert_zero_gates, &once.copy_gates, &once.add_gates,
-                               &once.mul_gates, &once.add_constant_gates, &once.mul_constant_gates, &once.and_gates,
-                               &once.xor_gates, &once.not_gates, &once.variables_freed, &once.switches, &once.branches,
-                               &once.for_loops, &once.functions_called};
-      uint64_t* dst[] = {&scaled.constants_gates, &scaled.assert_zero_gates, &scaled.copy_gates, &scaled.add_gates,
-                         &scaled.mul_gates, &scaled.add_constant_gates, &scaled.mul_constant_gates, &scaled.and_gates,
-                         &scaled.xor_gates, &scaled.not_gates, &scaled.variables_freed, &scaled.switches, &scaled.branches,
-                         &scaled.for_loops, &scaled.functions_called};
-      for (size_t k = 0; k < sizeof(src) / sizeof(src[0]); ++k) *dst[k] = *src[k] * n;
-      add_call_stats(s, scaled);
+      for (uint64_t* f : call_fields(once)) *f *= n;
+      add_call_stats(s, once);
       s.instance_variables += ins * n;
       s.witness_variables += wit * n;
       break;
