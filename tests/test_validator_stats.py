@@ -94,6 +94,14 @@ def test_committed_workspace_is_compliant_and_counted():
     assert not ev.validator_has_live_wires()
 
 
+def test_live_wire_warning_flag():
+    """`WARNING: few variables were not freed.` (validator.rs:138-140) is exposed as a flag."""
+    assert run(RULE_CASES['too_many_inputs'], metrics=False).validator_has_live_wires()
+    assert not run(arith_example_specs(), metrics=False).validator_has_live_wires()
+    with pytest.raises(zk.ZkGpuError, match='not enabled'):
+        zk.Evaluator().validator_violations()
+
+
 def test_boolean_example():  # cli.rs:602-624 runs valid-eval-metrics on it
     ev = run(bool_example_specs())
     assert ev.validator_violations() == []
