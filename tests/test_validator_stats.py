@@ -123,6 +123,20 @@ def test_primality():  # value.rs:57-64 + the moduli this repo uses
         [{'type': 'instance', 'mod': bytes([1]), 'values': []}]).validator_violations()
 
 
+def test_bignum_unit(tmp_path):
+    """tests/cpp/test_bignum.cpp: the strong Lucas half of the primality test passes every odd prime below 60000 and,
+    among the composites, exactly the published strong Lucas pseudoprimes; is_probably_prime agrees with a sieve."""
+    import os
+    import subprocess
+    from helpers import ROOT
+    csrc = os.path.join(ROOT, 'zkinterface-ir_amd', 'csrc')
+    exe = str(tmp_path / 'test_bignum')
+    subprocess.check_call(['g++', '-std=c++17', '-O2', '-I', csrc, os.path.join(ROOT, 'tests', 'cpp', 'test_bignum.cpp'),
+                           os.path.join(csrc, 'sieve', 'bignum.cpp'), '-o', exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and 'bad=0' in r.stdout, r.stdout[-2000:]
+
+
 # ---- one case per rule, checked against the restatement ------------------------------------------------------
 
 def relation(gates, gateset='arithmetic', features='@function,@for,@switch', functions=(), mod=lit32(101), **kw):

@@ -180,6 +180,99 @@ std::string BigNat::to_decimal() const {
   return out;
 }
 
+namespace {
+
+uint64_t gcd_free_jacobi_u64(uint64_t a, uint64_t n, int* t) {  // Jacobi (a/n), n odd; returns 0 when gcd != 1
+  a %= n;
+  while (a != 0) {
+    while ((a & 1) == 0) {
+      a >>= 1;
+      const uint64_t r = n & 7;
+      if (r == 3 || r == 5) *t = -*t;
+    }
+    std::swap(a, n);
+    if ((a & 3) == 3 && (n & 3) == 3) *t = -*t;
+    a %= n;
+  }
+  return n == 1 ? 1 : 0;
+}
+
+// Jacobi symbol (a/n) for a small signed a and an odd n > 1.
+int jacobi_small(int64_t a, const BigNat& n) {
+  int t = 1;
+  const uint32_t n8 = n.mod_small(8);
+  uint64_t A = a < 0 ? (uint64_t)(-a) : (uint64_t)a;
+  if (a < 0 && (n8 & 3) == 3) t = -t;
+  if (A == 0) return 0;
+  while ((A & 1) == 0) {
+    A >>= 1;
+    if (n8 == 3 || n8 == 5) t = -t;
+  }
+  if (A == 1) return t;
+  if ((A & 3) == 3 && (n8 & 3) == 3) t = -t;
+  const uint64_t N = n.mod_small((uint32_t)A);  // callers keep |a| below 2^31
+  return gcd_free_jacobi_u64(N, A, &t) ? t : 0;
+}
+
+bool is_perfect_square(const BigNat& n) {
+  // integer square root by bisection: lo^2 <= n < hi^2 throughout
+  BigNat lo, hi(1);
+  for (size_t i = 0; i < n.bits() / 2 + 1; ++i) hi = hi.add(hi);
+  while (BigNat(1) < hi.sub(lo)) {
+    const BigNat mid = lo.add(hi).shr(1);
+    if (n < mid.mul(mid)) hi = mid;
+    else lo = mid;
+  }
+  return lo.mul(lo) == n;
+}
+
+}  // namespace
+
+// Strong Lucas probable-prime test with Selfridge's parameters (the second half of Baillie-PSW).
+bool strong_lucas_selfridge(const BigNat& n) {  // n odd, > 2
+  if (is_perfect_square(n)) return false;
+  int64_t D = 5;
+  for (int tries = 0;; ++tries) {
+    const int j = jacobi_small(D, n);
+    if (j == -1) break;
+    if (j == 0 && BigNat((uint64_t)(D < 0 ? -D : D)) < n) return false;  // a small factor
+    if (tries > 200) return true;  // no suitable D found: leave the verdict to Miller-Rabin
+    D = D > 0 ? -(D + 2) : -(D - 2);
+  }
+  const BigNat one(1), two(2);
+  auto addm = [&](const BigNat& a, const BigNat& b) { BigNat r = a.add(b); return r >= n ? r.sub(n) : r; };
+  auto subm = [&](const BigNat& a, const BigNat& b) { return a >= b ? a.sub(b) : a.add(n).sub(b); };
+  auto mulm = [&](const BigNat& a, const BigNat& b) { return a.mul(b).mod(n); };
+  auto half = [&](const BigNat& a) { return a.is_even() ? a.shr(1) : a.add(n).shr(1); };
+  auto from_signed = [&](int64_t v) { return v >= 0 ? BigNat((uint64_t)v).mod(n) : subm(BigNat(), BigNat((uint64_t)(-v)).mod(n)); };
+  const BigNat Dm = from_signed(D), Q = from_signed((1 - D) / 4);
+  const BigNat n1 = n.add(one);
+  size_t s = 0;
+  while (n1.shr(s).is_even()) ++s;
+  const BigNat d = n1.shr(s);
+  // U_1 = 1, V_1 = P = 1, Q^1 = Q; walk the bits of d below the top one
+  BigNat U = one, V = one, Qk = Q;
+  for (size_t b = d.bits() - 1; b-- > 0;) {
+    U = mulm(U, V);
+    V = subm(mulm(V, V), addm(Qk, Qk));
+    Qk = mulm(Qk, Qk);
+    if (!d.shr(b).is_even()) {
+      const BigNat U2 = half(addm(U, V));            // (P U + V) / 2, P = 1
+      const BigNat V2 = half(addm(mulm(Dm, U), V));  // (D U + P V) / 2
+      U = U2;
+      V = V2;
+      Qk = mulm(Qk, Q);
+    }
+  }
+  if (U.is_zero() || V.is_zero()) return true;
+  for (size_t r = 1; r < s; ++r) {
+    V = subm(mulm(V, V), addm(Qk, Qk));
+    Qk = mulm(Qk, Qk);
+    if (V.is_zero()) return true;
+  }
+  return false;
+}
+
 bool is_probably_prime(const Value& v) {
   const BigNat n = BigNat::from_bytes_le(v);
   if (n < BigNat(2)) return false;
@@ -210,7 +303,7 @@ bool is_probably_prime(const Value& v) {
     }
     if (witness) return false;
   }
-  return true;
+  return strong_lucas_selfridge(n);
 }
 
 }  // namespace zki

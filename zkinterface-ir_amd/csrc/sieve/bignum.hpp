@@ -43,9 +43,12 @@ class BigNat {
 };
 
 // is_probably_prime (structs/value.rs:52-55 -> num_bigint_dig::prime::probably_prime(n, 10)).
-// Both are probabilistic tests; this one is trial division by the primes below 1000 followed by
-// Miller-Rabin to 24 fixed prime bases, which is exact below 3.3e24 and agrees with the reference
-// on every modulus that was not constructed to defeat one of the two tests.
+// Both are probabilistic tests; this one is trial division by the primes below 1000, Miller-Rabin to 24 fixed
+// prime bases (exact below 3.3e24) and a strong Lucas test with Selfridge's parameters (so it contains
+// Baillie-PSW, for which no pseudoprime is known); it agrees with the reference on every modulus that was not
+// constructed to defeat one of the two tests.
 bool is_probably_prime(const Value& v);
+// the Lucas half on its own (n odd and > 2), exposed for its unit test
+bool strong_lucas_selfridge(const BigNat& n);
 
 }  // namespace zki
