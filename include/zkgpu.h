@@ -125,6 +125,8 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "level_ops_per_wave" = 1..8 (program entries of a wide level walked by one wave, interleaved over the 4 waves
  * of a workgroup; default 2),
  * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),
+ * "fermat" = 0|1 (the exponent ladder x^(p-1) of a Switch weight becomes one `x != 0` entry when the characteristic
+ * passes the primality test; never with retain_all; default 1),
  * "pair" = 0|1 (an Add/Mul read by exactly two Add/Mul gates of one level is evaluated once inside a pair entry
  * that produces both readers' values; part of "fuse", never with retain_all),
  * "propagate_copies" = 0|1 (readers use a copy's source, unobserved copies are not materialised; never with retain_all),

@@ -6,7 +6,7 @@ levelisation, slot reuse, constant pool -- against the oracle without a GPU.
 It is not a product path and is never imported outside tests/."""
 
 OP = {'nop': 0, 'add': 1, 'mul': 2, 'addc': 3, 'mulc': 4, 'copy': 5, 'const': 6, 'instance': 7, 'witness': 8,
-      'assert': 9, 'and': 10, 'xor': 11, 'not': 12}
+      'assert': 9, 'and': 10, 'xor': 11, 'not': 12, 'nz': 13}
 
 
 def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None):
@@ -79,6 +79,10 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                 r = slots[a]
                 reads.add(a)
                 assert r is not None
+            elif kind == OP['nz']:   # x^(p-1) of a prime field: 1 (device form) unless x is 0
+                assert slots[a] is not None and not boolean
+                reads.add(a)
+                r = 0 if slots[a] == 0 else R % p
             elif kind == OP['not']:
                 assert slots[a] is not None
                 reads.add(a)

@@ -131,6 +131,47 @@ def test_batched_example_matches_oracle_per_lane(modulus):
     assert w == 8 * ((modulus.bit_length() + 63) // 64)
 
 
+@pytest.mark.parametrize('modulus', [101, circuits.BN254_R, 2 ** 61 - 1, circuits.P320])
+def test_switch_weights_in_the_production_schedule(modulus):
+    """The compact schedule (exponent ladder of every Switch weight replaced by one `x != 0` entry, copies
+    propagated, gates fused) against one oracle run per lane; the lanes take the first branch, the second branch
+    or none (condition 3, 5, anything else)."""
+    lanes = 96
+    _, _, rel = circuits.arith_example(modulus)
+    rows_i, rows_w = _batched_example(modulus, lanes)
+    for lane in range(lanes):
+        if lane % 4 == 1:
+            rows_w[lane][0] = 5
+        elif lane % 4 == 2:
+            rows_w[lane][0] = (7 + lane) % modulus
+    ev = zk.Evaluator()
+    ev.declare_inputs(3, 4)
+    ev.ingest_message(rel)
+    ev.finalize()
+    assert ev.schedule_info()['device_ops'] < 130
+    w = ev.elem_bytes
+    inst, wit = batch_arrays(rows_i, rows_w, w)
+    ev.set_inputs(inst, wit, lanes)
+    ev.replay()
+    ev.synchronize()
+    mod_le = sw.int_to_le(modulus) if modulus >= 2 ** 32 else modulus.to_bytes(4, 'little')
+    n_ok = 0
+    for lane in range(lanes):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], w, trace=False)
+        assert ev.get_violations(lane) == ref.violations, lane
+        n_ok += not ref.violations
+    assert ev.counts() == (n_ok, lanes - n_ok)
+    off = zk.Evaluator()
+    off.set_option('fermat', '0')
+    off.declare_inputs(3, 4)
+    off.ingest_message(rel)
+    off.finalize()
+    off.set_inputs(inst, wit, lanes)
+    off.replay()
+    off.synchronize()
+    assert np.array_equal(off.lane_results(lanes)[0], ev.lane_results(lanes)[0])
+
+
 def test_noncanonical_inputs_are_flagged_not_guessed():
     """The reference keeps inputs unreduced (evaluator.rs:862-864,940-946); this path refuses
     them per lane instead of silently reducing."""

@@ -184,6 +184,31 @@ def test_synthetic_workload_small_against_oracle():
     assert info['slots'] <= 2 * 32 + 16
 
 
+def test_switch_ladder_becomes_one_entry_only_over_a_prime_field():
+    """A Switch weight is 1 - (case - cond)^(p-1) (evaluator.rs:823-839).  The production schedule replaces the
+    352-product ladder of a 254-bit prime field by one `x != 0` entry; the recording, the retain_all schedule and a
+    composite characteristic keep the ladder.  Values are checked by the simulator tests above and on the GPU."""
+    sizes = {}
+    for p in (circuits.BN254_R, 7 * 13):
+        _inst, _wit, rel = circuits.arith_example(p)
+        for name, kw, retain in (('on', {}, False), ('off', {'fermat': 0}, False), ('retain', {}, True)):
+            ev = zk.Evaluator()
+            for k, v in kw.items():
+                ev.set_option(k, str(v))
+            ev.declare_inputs(3, 4)
+            ev.ingest_message(rel)
+            assert ev.host_violations() == []
+            n_tape = ev.n_value_ops
+            ev.finalize(retain_all=retain)
+            sizes[(p, name)] = (ev.schedule_info()['device_ops'], ev.schedule_info()['levels'], n_tape)
+    big = circuits.BN254_R
+    assert sizes[(big, 'on')][2] == sizes[(big, 'off')][2] == 965          # the recording is the reference's trace
+    assert sizes[(big, 'on')][0] < 120 and sizes[(big, 'on')][1] < 60
+    assert sizes[(big, 'off')][0] > 600 and sizes[(big, 'off')][1] > 390
+    assert sizes[(big, 'retain')][0] >= 965
+    assert sizes[(91, 'on')] == sizes[(91, 'off')]                            # 91 = 7 * 13: no shortcut
+
+
 def test_layered_program_with_pair_entries_against_oracle():
     """The production schedule of a layered relation (gate fusion, pair entries for producers with two readers in
     one level, shared-operand order) interpreted entry by entry: the verdict and every surviving output wire equal

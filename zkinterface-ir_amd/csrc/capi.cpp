@@ -32,6 +32,7 @@ struct zkgpu_session {
   bool fuse = true;
   bool propagate_copies = true;
   bool pair = true;
+  bool fermat = true;
   uint32_t n_streams = 2;
   bool xcd_map = true;
   uint32_t level_ops_per_wave = 2;
@@ -368,6 +369,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     opt.retain_all = retain_all != 0;
     opt.sort_by_operand = s->sort_by_operand;
     opt.pair = s->pair;
+    opt.fermat = s->fermat;
     opt.fuse = s->fuse;
     opt.propagate_copies = s->propagate_copies;
     s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
@@ -498,6 +500,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "xcd_map") {
       s->xcd_map = v != "0";
       if (s->engine) s->engine->set_xcd_map(s->xcd_map);
+    } else if (k == "fermat") {
+      s->fermat = v != "0";
     } else if (k == "pair") {
       s->pair = v != "0";
     } else if (k == "propagate_copies") {

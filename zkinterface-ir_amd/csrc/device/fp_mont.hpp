@@ -43,6 +43,17 @@ __device__ __forceinline__ bool fp_is_zero(const Fp<N>& a) {
   return acc == 0;
 }
 
+// 1 (Montgomery form) if a != 0, else 0: the value of a^(p-1) over a prime field (Fermat), which is what the
+// Switch indicator ladder of the reference computes (evaluator.rs:801-839).
+template <int N>
+__device__ __forceinline__ Fp<N> fp_nonzero_indicator(const Fp<N>& a, const FieldParams& fp) {
+  const bool z = fp_is_zero<N>(a);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = z ? 0u : fp.one[i];
+  return r;
+}
+
 // a >= p ?
 template <int N>
 __device__ __forceinline__ bool fp_geq_p(const Fp<N>& a, const FieldParams& fp) {

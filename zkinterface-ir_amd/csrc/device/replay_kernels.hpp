@@ -28,6 +28,7 @@ enum OpKind : u32 {
   OP_AND = 10,      // boolean-mode ops on {0,1} (arith tables only see them for p=2)
   OP_XOR = 11,
   OP_NOT = 12,
+  OP_NZ = 13,  // 1 if the operand is non-zero else 0: x^(p-1) over a prime field (scheduler-made, schedule.cpp)
 };
 
 struct TapeOp {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
   uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
   constexpr int REC = Layout<N>::kRecord;
 
-  auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_NOP; };
+  auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_NOP; };  // OP_NZ reads a
   auto needs_b = [](u32 k) { return k == OP_ADD || k == OP_MUL || k == OP_AND || k == OP_XOR; };
 
   TapeOp op = args.ops[begin];
@@ -177,6 +178,7 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       case OP_ADDC: r = fp_add<N>(a, fp_load_const<N>(args.consts + (size_t)op.b * N), fp); break;
       case OP_MULC: r = fp_mul<N>(a, fp_load_const<N>(args.consts + (size_t)op.b * N), fp); break;
       case OP_COPY: r = a; break;
+      case OP_NZ: r = fp_nonzero_indicator<N>(a, fp); break;
       case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a * N); break;
       case OP_INSTANCE:
       case OP_WITNESS: {
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
       case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
       case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
       case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
+      case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
       case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
       case OP_INSTANCE:
       case OP_WITNESS: {

@@ -135,7 +135,7 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
         slot(i, dst); slot(i, a0);
         if (b0 >= n_consts) fail(i, "a constant");
         break;
-      case TK_COPY: case TK_NOT: slot(i, dst); slot(i, a0); break;
+      case TK_COPY: case TK_NOT: case TK_NZ: slot(i, dst); slot(i, a0); break;
       case TK_CONST:
         slot(i, dst);
         if (a0 >= n_consts) fail(i, "a constant");

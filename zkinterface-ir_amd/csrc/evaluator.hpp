@@ -15,6 +15,8 @@
 //        mul_constant(a,fe) and_(a,b) xor_(a,b) not_(a) instance(fe) witness(fe*)
 //   void assert_zero(w)            -- throws zki::Error when it can tell the wire is non-zero
 //   void note_assert_wire(WireId)  -- optional: local id of the wire about to be asserted
+//   size_t note_ladder_begin(); void note_ladder_end(size_t, Wire base, Wire result)  -- optional: the calls in
+//     between computed result = base^(modulus - 1) (the Switch indicator, evaluator.rs:801-839)
 #pragma once
 #include <algorithm>
 #include <deque>
@@ -256,7 +258,9 @@ class Evaluator {
     Wire minus_cond = as_negate(e, condition);
     Wire base = as_add(e, case_wire, minus_cond);
     if (e.exponent.zero) throw Panic("exponent 0 never reaches 1 (modulus 1)");  // unbounded recursion in the reference
+    const size_t mark = ladder_begin(e.backend, 0);
     Wire base_to_exp = exp(e, base, 0);
+    if (!e.is_boolean) ladder_end(e.backend, mark, base, base_to_exp, 0);  // base_to_exp = base^(modulus - 1)
     Wire right = as_negate(e, base_to_exp);
     return as_add_one(e, right);
   }
@@ -265,6 +269,18 @@ class Evaluator {
     return std::string("Wrong number of ") + what + " variables in call to function " + name + " (Expected " +
            std::to_string(expected) + " / Got " + std::to_string(got) + ").";
   }
+
+  // optional backend hooks around the exponent ladder of a Switch weight: a recording backend learns which of its
+  // calls compute base^(modulus - 1) and may evaluate that differently when it replays them
+  template <class BB>
+  static auto ladder_begin(BB& b, int) -> decltype(b.note_ladder_begin()) { return b.note_ladder_begin(); }
+  template <class BB>
+  static size_t ladder_begin(BB&, long) { return 0; }
+  template <class BB>
+  static auto ladder_end(BB& b, size_t mark, const Wire& base, const Wire& result, int)
+      -> decltype(b.note_ladder_end(mark, base, result), void()) { b.note_ladder_end(mark, base, result); }
+  template <class BB>
+  static void ladder_end(BB&, size_t, const Wire&, const Wire&, long) {}
 
   template <class BB>
   static auto note_assert(BB& b, WireId id, int) -> decltype(b.note_assert_wire(id), void()) { b.note_assert_wire(id); }

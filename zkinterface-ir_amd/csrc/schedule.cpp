@@ -1,5 +1,7 @@
 #include "schedule.hpp"
 
+#include "sieve/bignum.hpp"
+
 #include <string.h>
 
 #include <algorithm>
@@ -10,7 +12,7 @@ namespace {
 inline int n_inputs(uint8_t k) {
   switch (k) {
     case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR: return 2;
-    case TK_ADDC: case TK_MULC: case TK_COPY: case TK_NOT: case TK_ASSERT: return 1;
+    case TK_ADDC: case TK_MULC: case TK_COPY: case TK_NOT: case TK_ASSERT: case TK_NZ: return 1;
     default: return 0;  // CONST, INSTANCE, WITNESS, NOP
   }
 }
@@ -79,10 +81,74 @@ void locality_order(uint32_t* ops, size_t cnt, Gathered&& gathered) {
 
 }  // namespace
 
-Schedule build_schedule(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt) {
+namespace {
+
+// Switch weights are 1 - (case - cond)^(p-1) (evaluator.rs:823-839); the reference computes the power with a
+// square-and-multiply ladder (bits(p) squarings + popcount(p-1) multiplies: 352 dependent products at BN254, each of
+// them a level of its own).  For a prime p Fermat gives x^(p-1) = 1 for x != 0 and 0 for x = 0, so in the production
+// schedule the ladder's result becomes one entry `x != 0` and the ladder's own ops are dropped.  Only done when the
+// characteristic passes the primality test (sieve/bignum.cpp) and nothing outside a ladder reads its intermediates.
+bool rewrite_ladders(const Tape& in, const FieldHost& field, Tape* out, uint64_t* n_done) {
+  if (in.ladders.empty()) return false;
+  Value p_le;
+  for (uint32_t i = 0; i < field.nwords; ++i)
+    for (int b = 0; b < 4; ++b) p_le.push_back((uint8_t)(field.p[i] >> (8 * b)));
+  if (!is_probably_prime(p_le)) return false;
+  const size_t n = in.size();
+  std::vector<uint32_t> owner(n, kInf);  // ladder whose intermediate this op is
+  std::vector<uint8_t> ok(in.ladders.size(), 1);
+  for (size_t l = 0; l < in.ladders.size(); ++l) {
+    const Tape::Ladder& L = in.ladders[l];
+    if (L.result >= n || L.first > L.result || L.base >= L.first) { ok[l] = 0; continue; }
+    for (uint32_t i = L.first; i < L.result; ++i) {
+      if (owner[i] != kInf || in.kind[i] == TK_ASSERT) ok[l] = 0;
+      owner[i] = (uint32_t)l;
+    }
+  }
+  for (size_t j = 0; j < n; ++j) {
+    const int ni = n_inputs(in.kind[j]);
+    for (int k = 0; k < ni; ++k) {
+      const uint32_t src = k == 0 ? in.a[j] : in.b[j];
+      if (src >= n || owner[src] == kInf) continue;
+      const Tape::Ladder& L = in.ladders[owner[src]];
+      if (j < L.first || j > L.result) ok[owner[src]] = 0;  // read from outside the ladder
+    }
+  }
+  bool any = false;
+  for (size_t l = 0; l < in.ladders.size(); ++l) any = any || ok[l];
+  if (!any) return false;
+  out->kind = in.kind;
+  out->a = in.a;
+  out->b = in.b;
+  out->assert_op = in.assert_op;
+  out->assert_wire = in.assert_wire;
+  out->consts = in.consts;
+  out->n_instance = in.n_instance;
+  out->n_witness = in.n_witness;
+  out->n_value_ops = in.n_value_ops;
+  for (size_t l = 0; l < in.ladders.size(); ++l) {
+    if (!ok[l]) continue;
+    const Tape::Ladder& L = in.ladders[l];
+    for (uint32_t i = L.first; i < L.result; ++i) out->kind[i] = TK_NOP;
+    out->kind[L.result] = TK_NZ;
+    out->a[L.result] = L.base;
+    out->b[L.result] = 0;
+    ++*n_done;
+  }
+  return true;
+}
+
+}  // namespace
+
+Schedule build_schedule(const Tape& recorded, const FieldHost& field, const ScheduleOptions& opt) {
+  Tape rewritten;
+  uint64_t n_ladders = 0;
+  const bool use_rewritten = opt.fermat && !opt.retain_all && !field.is_two && rewrite_ladders(recorded, field, &rewritten, &n_ladders);
+  const Tape& tape = use_rewritten ? rewritten : recorded;
   Schedule s;
   const size_t n = tape.size();
   s.retain_all = opt.retain_all;
+  s.n_ladders = n_ladders;
   s.boolean_path = field.is_two;
   s.slot_of.assign(n, kNoWire);
   s.level_of.assign(n, 0);
@@ -121,6 +187,8 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   // readable (retain_all dumps, wires alive at the end) are kept.
   std::vector<uint32_t> opa(tape.a), opb(tape.b);
   std::vector<uint8_t> absorbed(n, 0);  // 1 = evaluated inside its reader (fusion), 2 = elided copy
+  for (size_t i = 0; i < n; ++i)
+    if (tape.kind[i] == TK_NOP) absorbed[i] = 2;  // dropped ladder ops: no entry, no slot, read nothing
   const bool propagate = opt.propagate_copies && !opt.retain_all;
   if (propagate) {
     std::vector<uint8_t> is_pinned(n, 0);
@@ -238,7 +306,7 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
   }
 
   // ---- order ops by (level, kind): counting sort ------------------------
-  constexpr uint32_t kKinds = TK_NOT + 1;
+  constexpr uint32_t kKinds = TK_NZ + 1;
   std::vector<uint64_t> bucket((size_t)n_levels * kKinds + 1, 0);
   size_t n_live = 0;
   for (size_t i = 0; i < n; ++i)
@@ -372,7 +440,7 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
           d.a0 = s.slot_of[opa[i]];
           d.b0 = opb[i];
           break;
-        case TK_COPY: case TK_NOT: d.a0 = s.slot_of[opa[i]]; break;
+        case TK_COPY: case TK_NOT: case TK_NZ: d.a0 = s.slot_of[opa[i]]; break;
         case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a0 = opa[i]; break;
         case TK_ASSERT:
           d.a0 = s.slot_of[opa[i]];
@@ -398,7 +466,7 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
         d.a = s.slot_of[opa[i]];
         d.b = opb[i];
         break;
-      case TK_COPY: case TK_NOT: d.a = s.slot_of[opa[i]]; break;
+      case TK_COPY: case TK_NOT: case TK_NZ: d.a = s.slot_of[opa[i]]; break;
       case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a = opa[i]; break;
       case TK_ASSERT:
         d.a = s.slot_of[opa[i]];

@@ -39,6 +39,7 @@ struct ScheduleOptions {
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
   int sort_by_operand = 2;          // order of a level's ops: 0 tape order, 1 by first-operand slot, 2 shared-operand walk
   bool fuse = true;                 // absorb single-reader Add/Mul producers into their consumer (never with retain_all)
+  bool fermat = true;               // a Switch exponent ladder x^(p-1), p prime, becomes one `x != 0` entry (never with retain_all)
   bool pair = true;                 // one entry for the two same-level readers of a producer nobody else reads (never with retain_all)
   bool propagate_copies = true;     // readers use a copy's source; unobserved copies are not materialised (never with retain_all)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
@@ -50,6 +51,7 @@ struct Schedule {
   bool fused = false;
   uint64_t n_absorbed = 0;
   uint64_t n_copies_elided = 0;
+  uint64_t n_ladders = 0;           // exponent ladders replaced by one entry each
   uint64_t n_paired = 0;            // producers evaluated inside a pair entry (counted in n_absorbed too)
   std::vector<Launch> launches;
   std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)

@@ -7,7 +7,7 @@ namespace zki {
 const char* tape_kind_name(uint8_t k) {
   static const char* names[] = {"nop", "add", "mul", "addc", "mulc", "copy", "constant",
                                 "instance", "witness", "assert_zero", "and", "xor", "not"};
-  return k <= TK_NOT ? names[k] : "?";
+  return k <= TK_NOT ? names[k] : k == TK_NZ ? "nz" : "?";
 }
 
 // ---------------------------------------------------------------- FieldHost

@@ -17,6 +17,7 @@ namespace zki {
 enum TapeKind : uint8_t {
   TK_NOP = 0, TK_ADD = 1, TK_MUL = 2, TK_ADDC = 3, TK_MULC = 4, TK_COPY = 5, TK_CONST = 6,
   TK_INSTANCE = 7, TK_WITNESS = 8, TK_ASSERT = 9, TK_AND = 10, TK_XOR = 11, TK_NOT = 12,
+  TK_NZ = 13,  // scheduler only: 1 if the operand is non-zero else 0 (= x^(p-1) for a prime p), never recorded
 };
 const char* tape_kind_name(uint8_t k);  // names of SURVEY.md Appendix A ("copy", "mul", ...)
 
@@ -50,6 +51,12 @@ struct Tape {
   std::vector<uint64_t> assert_wire;   // local id printed in "Wire_{} (may be weighted) ..."
   // constant pool: distinct little-endian byte strings
   std::vector<Value> consts;
+  // Exponent ladders of Switch weights (evaluator.rs:801-839): ops [first, result] compute
+  // result = base^(modulus - 1) and nothing outside reads any of them but `result`.
+  struct Ladder {
+    uint32_t first, result, base;
+  };
+  std::vector<Ladder> ladders;
   uint32_t n_instance = 0, n_witness = 0;  // input positions referenced (max + 1)
   uint64_t n_value_ops = 0;
 
@@ -83,6 +90,10 @@ class TapeBackend {
   Wire constant(FieldElement val);
   void assert_zero(const Wire& w);
   void note_assert_wire(WireId local_id) { pending_assert_wire_ = local_id; }
+  size_t note_ladder_begin() const { return tape_.size(); }
+  void note_ladder_end(size_t first, const Wire& base, const Wire& result) {
+    if (result >= first && base < first) tape_.ladders.push_back({(uint32_t)first, result, base});
+  }
   Wire add(const Wire& x, const Wire& y) { return arith(TK_ADD, x, y); }
   Wire multiply(const Wire& x, const Wire& y) { return arith(TK_MUL, x, y); }
   Wire add_constant(const Wire& x, FieldElement c);
