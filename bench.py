@@ -90,6 +90,8 @@ def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, stream
     ev.set_option('fuse', os.environ.get('ZKI_FUSE', '1'))
     if os.environ.get('ZKI_OPW'):
         ev.set_option('level_ops_per_wave', os.environ['ZKI_OPW'])
+    if os.environ.get('ZKI_GRAPH'):
+        ev.set_option('graph', os.environ['ZKI_GRAPH'])
     if os.environ.get('ZKI_XCD_MAP'):
         ev.set_option('xcd_map', os.environ['ZKI_XCD_MAP'])
     if os.environ.get('ZKI_SORT_BY_OPERAND'):

@@ -121,6 +121,8 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "streams" = 1..4 (lane shares replayed concurrently, default 2),
  * "sort_by_operand" = 0|1|2 (order of the ops inside a level: tape order, by first operand, or a depth-first
  * walk over shared operands so that the readers of a wire run back to back; default 2),
+ * "graph" = 0|1 (replay the captured hipGraph of the whole launch sequence instead of issuing it launch by launch;
+ * default 0: measured slower on ROCm 7.2),
  * "xcd_map" = 0|1 (launches over a multiple of 8 lane blocks give each XCD its own lane blocks; default 1),
  * "level_ops_per_wave" = 1..8 (program entries of a wide level walked by one wave, interleaved over the 4 waves
  * of a workgroup; default 2),

@@ -35,6 +35,7 @@ struct zkgpu_session {
   bool fermat = true;
   uint32_t n_streams = 2;
   bool xcd_map = true;
+  int graph_mode = 0;
   uint32_t level_ops_per_wave = 2;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
@@ -87,6 +88,7 @@ void need_engine(zkgpu_session* s) {
     e->set_lane_group(s->lane_group);
     e->set_streams(s->n_streams);
     e->set_xcd_map(s->xcd_map);
+    e->set_graph_mode(s->graph_mode);
     e->set_level_ops_per_wave(s->level_ops_per_wave);
     if (s->r1cs_extra_vars) e->reserve_extra_slots(s->r1cs_extra_vars);
     s->engine = std::move(e);
@@ -497,6 +499,10 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "level_ops_per_wave") {
       s->level_ops_per_wave = (uint32_t)std::max(1, atoi(v.c_str()));
       if (s->engine) s->engine->set_level_ops_per_wave(s->level_ops_per_wave);
+    } else if (k == "graph") {
+      if (v == "0" || v == "1") s->graph_mode = atoi(v.c_str());
+      else throw std::runtime_error("graph must be 0 or 1");
+      if (s->engine) s->engine->set_graph_mode(s->graph_mode);
     } else if (k == "xcd_map") {
       s->xcd_map = v != "0";
       if (s->engine) s->engine->set_xcd_map(s->xcd_map);

@@ -71,6 +71,7 @@ Engine::Engine() {
 }
 
 Engine::~Engine() {
+  if (graph_exec_) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec_);
   free_batch();
   dfree(d_ops_);
   dfree(d_consts_);
@@ -109,6 +110,7 @@ void Engine::free_batch() {
   dfree(d_r1cs_fail_);
   d_inst_ = d_wit_ = nullptr;
   batch_ = 0;
+  graph_dirty_ = true;  // every pointer a captured replay holds is gone
 }
 
 // Every index a kernel will dereference is checked on the host before the program is uploaded: a slot, constant
@@ -331,6 +333,7 @@ void Engine::upload_inputs(const uint8_t* inst, const uint8_t* wit) {
   if (!d_wit_own_) HIP_OK(hipMalloc(&d_wit_own_, std::max<size_t>(wb, 64)));
   if (ib) staged_upload(d_inst_own_, inst, ib);
   if (wb) staged_upload(d_wit_own_, wit, wb);
+  if (d_inst_ != d_inst_own_ || d_wit_ != d_wit_own_) graph_dirty_ = true;
   d_inst_ = d_inst_own_;
   d_wit_ = d_wit_own_;
 }
@@ -366,6 +369,7 @@ void Engine::staged_upload(void* dst, const uint8_t* src, size_t bytes) {
 
 void Engine::use_device_inputs(const void* d_inst, const void* d_wit) {
   if (!batch_) throw std::runtime_error("Engine: set_batch() first");
+  if (d_inst_ != d_inst || d_wit_ != d_wit) graph_dirty_ = true;
   d_inst_ = d_inst;
   d_wit_ = d_wit;
 }
@@ -498,7 +502,6 @@ void Engine::replay(bool time_each_launch) {
   if (!batch_) throw std::runtime_error("Engine: set_batch() first");
   if ((n_inst_ && !d_inst_) || (n_wit_ && !d_wit_)) throw std::runtime_error("Engine: inputs not set");
   hipStream_t st = (hipStream_t)stream_;
-  const size_t padded_lanes = (size_t)lane_blocks_ * lanes_per_block_;
   if (time_each_launch) {
     while (launch_events_.size() < 2 * sched_.launches.size()) {
       hipEvent_t e;
@@ -507,6 +510,63 @@ void Engine::replay(bool time_each_launch) {
     }
   }
   HIP_OK(hipEventRecord((hipEvent_t)ev_begin_, st));
+  const bool graphed = use_graph() && !time_each_launch;
+  if (graphed) {
+    // the memsets, the kernels of every lane group on every stream and the verdict kernel as one captured submission
+    if (!graph_exec_ || graph_dirty_) capture_graph();
+    HIP_OK(hipGraphLaunch((hipGraphExec_t)graph_exec_, st));
+  } else {
+    enqueue_replay(time_each_launch);
+  }
+  HIP_OK(hipEventRecord((hipEvent_t)ev_end_, st));
+  HIP_OK(hipGetLastError());
+  timings_.clear();
+  if (time_each_launch && !lds_path_) {
+    HIP_OK(hipStreamSynchronize(st));
+    for (size_t li = 0; li < sched_.launches.size(); ++li) {
+      LaunchTiming t;
+      t.launch = (uint32_t)li;
+      t.count = sched_.launches[li].count;
+      HIP_OK(hipEventElapsedTime(&t.ms, (hipEvent_t)launch_events_[2 * li], (hipEvent_t)launch_events_[2 * li + 1]));
+      timings_.push_back(t);
+    }
+  }
+}
+
+// hipGraph replay is off by default: measured on ROCm 7.2 / MI355X it is slower than issuing the launches on the two
+// streams (BN254 Switch example, 18 kernels per replay: 0.113 -> 0.186 ms at 1024 witnesses; C2, 518 kernels per replay:
+// 8.83 -> 12.71 ms) -- the captured fork/join of the two lane shares no longer overlaps.  "graph" = 1 keeps the path
+// testable for later ROCm releases.
+bool Engine::use_graph() const { return graph_mode_ == 1 && !lds_path_; }
+
+void Engine::capture_graph() {
+  hipStream_t st = (hipStream_t)stream_;
+  if (graph_exec_) {
+    (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec_);
+    graph_exec_ = nullptr;
+  }
+  hipGraph_t graph = nullptr;
+  HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  try {
+    enqueue_replay(false);
+  } catch (...) {
+    (void)hipStreamEndCapture(st, &graph);
+    if (graph) (void)hipGraphDestroy(graph);
+    throw;
+  }
+  HIP_OK(hipStreamEndCapture(st, &graph));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  HIP_OK(e);
+  graph_exec_ = exec;
+  graph_dirty_ = false;
+}
+
+// The device work of one replay, enqueued on the engine's streams (directly, or into a graph capture).
+void Engine::enqueue_replay(bool time_each_launch) {
+  hipStream_t st = (hipStream_t)stream_;
+  const size_t padded_lanes = (size_t)lane_blocks_ * lanes_per_block_;
   HIP_OK(hipMemsetAsync(d_first_fail_, 0xFF, padded_lanes * 4, st));
   HIP_OK(hipMemsetAsync(d_flags_, 0, padded_lanes * 4, st));
   HIP_OK(hipMemsetAsync(d_counts_, 0, 16, st));
@@ -556,19 +616,6 @@ void Engine::replay(bool time_each_launch) {
   zkgpu::verdict_kernel<<<(batch_ + 255) / 256, 256, 0, st>>>((const zkgpu::u32*)d_first_fail_,
                                                               (const zkgpu::u32*)d_flags_, batch_,
                                                               (unsigned long long*)d_counts_);
-  HIP_OK(hipEventRecord((hipEvent_t)ev_end_, st));
-  HIP_OK(hipGetLastError());
-  timings_.clear();
-  if (time_each_launch && !lds_path_) {
-    HIP_OK(hipStreamSynchronize(st));
-    for (size_t li = 0; li < sched_.launches.size(); ++li) {
-      LaunchTiming t;
-      t.launch = (uint32_t)li;
-      t.count = sched_.launches[li].count;
-      HIP_OK(hipEventElapsedTime(&t.ms, (hipEvent_t)launch_events_[2 * li], (hipEvent_t)launch_events_[2 * li + 1]));
-      timings_.push_back(t);
-    }
-  }
 }
 
 void Engine::reserve_extra_slots(uint32_t n) {

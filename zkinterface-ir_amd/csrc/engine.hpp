@@ -37,12 +37,13 @@ class Engine {
   void use_device_inputs(const void* d_inst, const void* d_wit);      // already resident
   // Limit how many lanes are replayed together (0 = all): lane groups run one
   // after the other so that a group's live wires stay in the 256 MiB Infinity Cache.
-  void set_lane_group(uint32_t lanes) { lane_group_ = lanes; }
+  void set_lane_group(uint32_t lanes) { lane_group_ = lanes; graph_dirty_ = true; }
+  void set_graph_mode(int mode) { graph_mode_ = mode; graph_dirty_ = true; }  // 0 off (default), 1 on
   // Replay the lane blocks as `n` interleaved halves on `n` HIP streams (1..4): the levels of one
   // half fill the kernel-boundary bubbles and wave tails of the other.
-  void set_xcd_map(bool on) { xcd_map_ = on; }
-  void set_level_ops_per_wave(uint32_t n) { level_ops_per_wave_ = n < 1 ? 1 : (n > 8 ? 8 : n); }
-  void set_streams(uint32_t n) { n_streams_ = n < 1 ? 1 : (n > kMaxStreams ? kMaxStreams : n); }
+  void set_xcd_map(bool on) { xcd_map_ = on; graph_dirty_ = true; }
+  void set_level_ops_per_wave(uint32_t n) { level_ops_per_wave_ = n < 1 ? 1 : (n > 8 ? 8 : n); graph_dirty_ = true; }
+  void set_streams(uint32_t n) { n_streams_ = n < 1 ? 1 : (n > kMaxStreams ? kMaxStreams : n); graph_dirty_ = true; }
   static constexpr uint32_t kMaxStreams = 4;
   static constexpr uint64_t kInfinityCacheBudget = 288ull << 20;  // wire-table bytes kept in flight per lane group
   // GF(2): 0 = pick automatically, 1 = force the HBM-table kernel, 2 = require the LDS-resident kernel
@@ -98,6 +99,12 @@ class Engine {
   void* ev_join_[3] = {nullptr, nullptr, nullptr};
   uint32_t n_streams_ = 2;
   bool xcd_map_ = true;
+  int graph_mode_ = 0;
+  bool graph_dirty_ = true;
+  void* graph_exec_ = nullptr;
+  bool use_graph() const;
+  void capture_graph();
+  void enqueue_replay(bool time_each_launch);
   uint32_t level_ops_per_wave_ = 2;
   void* ev_begin_ = nullptr;
   void* ev_end_ = nullptr;
@@ -135,7 +142,7 @@ class Engine {
   bool force_writeback_ = false;
  public:
   // pinned wires (Evaluator::get) need the LDS-resident values written back to HBM
-  void set_writeback(bool on) { force_writeback_ = on; }
+  void set_writeback(bool on) { force_writeback_ = on; graph_dirty_ = true; }
  private:
   unsigned char field_params_[192];  // zkgpu::FieldParams, opaque here
 };
