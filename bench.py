@@ -37,17 +37,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
 
 
-def pmc_traffic(width, batch, nwords_bytes):
+def pmc_traffic(width, batch, nwords_bytes, workload='c2'):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; tools/pmc_traffic.py
-    applies the gfx950 corrections).  Only valid for the grid it was measured on."""
+    applies the gfx950 corrections).  Only valid for the grid it was measured on (the default sizes)."""
+    path = PMC_TRAFFIC_JSON if workload == 'c2' else os.path.join(ROOT, 'profiles', 'pmc_traffic_%s.json' % workload)
     try:
-        d = json.load(open(PMC_TRAFFIC_JSON))
+        d = json.load(open(path))
     except (OSError, ValueError):
         return None, None
-    if d.get('workload') != 'c2' or (width, batch) != (4096, 1024):
+    default = {'c2': (4096, 1024), 'c4': (16384, 4096), 'c5': (1 << 20, 1024)}[workload]
+    if d.get('workload') != workload or (width, batch) != default:
         return None, None
-    return d['traffic_bytes_per_launch'], os.path.relpath(PMC_TRAFFIC_JSON, ROOT)
+    return d['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)
 
 
 class _DevU64x2:
@@ -222,7 +224,8 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
                        'wire_table_GB': round(ev.table_bytes / 1e9, 2), 'satisfied': total[0], 'failed': total[1],
                        'host_seconds': {'build_s': round(t1 - t0, 2), 'witness_generation_s': round(t2 - t1, 2)}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'r1cs_row_kernel<8,false>',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(M, batch, wl.width, 'c5')[0],
+                         'traffic_source': pmc_traffic(M, batch, wl.width, 'c5')[1], 'kernel': 'r1cs_row_kernel<8,false>',
                          'launches_per_step': 1, 'avg_launch_ms': kernel_ms,
                          'algorithmic_bytes_per_launch': bytes_per_launch},
         }
@@ -358,7 +361,7 @@ def main():
         kernel_ms = float(np.mean(ev_ms)) / max(wide_launches, 1)
         bytes_per_launch = algo_bytes_per_lane * batch / max(wide_launches, 1)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(wl.W, batch, wl.width) if args.workload == 'c2' else (None, None)
+        traffic, traffic_src = pmc_traffic(wl.W, batch, wl.width, args.workload)
         if args.workload == 'c2':
             metric = 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses'
             dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'

@@ -27,6 +27,14 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 F=$(find /tmp/pmc_f -name '*counter_collection.csv' | head -1)
 W=$(find /tmp/pmc_w -name '*counter_collection.csv' | head -1)
 python3 $ROOT/tools/pmc_traffic.py $F $W $OUT/pmc_traffic.json 1000000 'replay_fused_kernel<8' c2 > /dev/null
+for wl in c4 c5; do
+  echo "[collect] pmc passes ($wl)"
+  rm -rf /tmp/pmc_f_$wl /tmp/pmc_w_$wl
+  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f_$wl -- python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_f_$wl.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$wl -- python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_w_$wl.log 2>&1
+  K='bool_lds_kernel'; [ $wl = c5 ] && K='r1cs_row_kernel<8, false>'
+  python3 $ROOT/tools/pmc_traffic.py $(find /tmp/pmc_f_$wl -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_w_$wl -name '*counter_collection.csv' | head -1) $OUT/pmc_traffic_$wl.json 1000 "$K" $wl > /dev/null
+done
 head -4 $F > $OUT/pmc_fetch_sample.csv
 head -4 $W > $OUT/pmc_write_sample.csv
 echo "[collect] done"
