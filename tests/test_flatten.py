@@ -72,3 +72,41 @@ def test_flatten_tool_writes_an_equisatisfiable_workspace(tmp_path):
         gs = ev.stats()['gate_stats']
         assert gs['functions_called'] == gs['switches'] == gs['for_loops'] == 0
     assert cli.main(['flatten', str(src), '--out', str(tmp_path / 'x.sieve')], err=io.StringIO()) == 1
+
+
+@pytest.mark.parametrize('name,gate_set,absent', [
+    ('arith_101_correct', '@add,@mul', ('add_constant_gates', 'mul_constant_gates')),
+    ('arith_101_incorrect', '@add,@mul,@mulc', ('add_constant_gates',)),
+    ('bool_correct', '@xor,@and,@add', ('not_gates', 'add_constant_gates')),
+    ('bool_correct', '@add,@mul,@addc', ('xor_gates', 'and_gates', 'not_gates')),
+])
+def test_expand_definable_rewrites_the_missing_gates(tmp_path, name, gate_set, absent):
+    """`expand-definable --gate-set ...` (cli.rs:515-555, consumers/exp_definable.rs): the flattened relation uses
+    only the target gateset and is equisatisfiable with the original statement."""
+    import io
+    from zkinterface_ir_amd import cli
+    src, dst = tmp_path / 'src', tmp_path / 'out'
+    src.mkdir()
+    bufs = golden_buffers(name)
+    for k, b in enumerate(bufs):
+        (src / ('%03d.sieve' % k)).write_bytes(b)
+    err = io.StringIO()
+    assert cli.main(['expand-definable', str(src), '--gate-set', gate_set, '--out', str(dst)], err=err) == 0, err.getvalue()
+    ev = zk.Evaluator()
+    ev.set_option('metrics', '1')
+    ev.set_option('validate', 'prover')
+    ev.ingest_paths([str(dst)])
+    gs = ev.stats()['gate_stats']
+    assert all(gs[k] == 0 for k in absent), gs
+    flat = OracleRun(files=[str(dst / n) for n in ('000_instance.sieve', '001_witness.sieve', '002_relation.sieve')])
+    assert (flat.violations == []) == (OracleRun(buffers=bufs).violations == [])
+
+
+def test_expand_definable_refuses_what_the_reference_panics_on(tmp_path):
+    from zkinterface_ir_amd import flatten as fl2
+    ev = zk.Evaluator.from_messages(golden_buffers('bool_correct'))
+    with pytest.raises(ValueError, match='Cannot replace XOR by ADD if ADD is not supported.'):
+        fl2.flatten(ev, bytes([2]), boolean=True, gate_mask=fl2.parse_gate_set('@and,@not'))
+    with pytest.raises(ValueError, match='Unable to parse the following gateset'):
+        fl2.parse_gate_set('@add,@nope')
+    assert fl2.parse_gate_set('arithmetic') == 0xF and fl2.parse_gate_set(' @xor, @and,') == 0x300

@@ -61,15 +61,28 @@ def main(argv=None, err=sys.stderr, out=sys.stdout):
     argv = list(sys.argv[1:] if argv is None else argv)
     if len(argv) >= 3 and argv[0] == 'synth' and argv[1] in ('c2', 'c4'):
         return synth(argv[1], argv[2], lane=int(argv[3]) if len(argv) > 3 else 0, corrupt='--incorrect' in argv, err=err)
-    if len(argv) >= 4 and argv[0] == 'flatten' and '--out' in argv:  # cli.rs:442-472
-        k = argv.index('--out')
-        out_dir, paths = argv[k + 1], argv[1:k] + argv[k + 2:]
+    if len(argv) >= 4 and argv[0] in ('flatten', 'expand-definable') and '--out' in argv:  # cli.rs:442-472,515-555
+        rest = argv[1:]
+        gate_mask = None
+        if '--gate-set' in rest:
+            g = rest.index('--gate-set')
+            from zkinterface_ir_amd.flatten import parse_gate_set
+            try:
+                gate_mask = parse_gate_set(rest[g + 1])
+            except ValueError as e:
+                print('Error: %s' % e, file=err)
+                return 1
+            rest = rest[:g] + rest[g + 2:]
+        if argv[0] == 'expand-definable' and gate_mask is None:
+            return 0  # cli.rs:520: without --gate-set the tool does nothing
+        k = rest.index('--out')
+        out_dir, paths = rest[k + 1], rest[:k] + rest[k + 2:]
         if out_dir.endswith('.sieve'):
             print('Error: IR flattening requires a directory as output value', file=err)
             return 1
         from zkinterface_ir_amd.flatten import flatten_workspace
         try:
-            flatten_workspace(paths, out_dir)
+            flatten_workspace(paths, out_dir, gate_mask if argv[0] == 'expand-definable' else None)
         except (ValueError, Exception) as e:  # noqa: B014 -- any recording error is reported like the reference's Err
             print('Error: %s' % e, file=err)
             return 1
@@ -78,6 +91,7 @@ def main(argv=None, err=sys.stderr, out=sys.stdout):
     if len(argv) < 2 or argv[0] not in tools:
         print('usage: cli.py evaluate|validate|metrics|valid-eval-metrics <workspace dir | file.sieve ...>\n'
               '       cli.py flatten <workspace dir | file.sieve ...> --out <dir>\n'
+              '       cli.py expand-definable <workspace dir | file.sieve ...> --gate-set "@add,@mul,..." --out <dir>\n'
               '       cli.py synth c2|c4 <out dir> [lane] [--incorrect]', file=err)
         return 2
     import zkinterface_ir_amd as zk
