@@ -229,6 +229,18 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
                          'launches_per_step': 1, 'avg_launch_ms': kernel_ms,
                          'algorithmic_bytes_per_launch': bytes_per_launch},
         }
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
+            # the row check on the host cores for a bounded sample of the same lanes (oracle/cpu_opt.cpp:
+            # the mathematical definition -- the reference itself holds no row checker)
+            sys.path.insert(0, os.path.join(ROOT, 'tests'))
+            import oracle_lib
+            threads = min(os.cpu_count() or 1, 64)
+            sample = min(batch, 4 * threads)
+            ff_cpu, secs = oracle_lib.r1cs_check(row_ptr, tv, tc, cb, wl.mod_le, w[:sample], wl.n_base + 1 + M, M, threads)
+            assert np.array_equal(ff_cpu, np.asarray(ff[:sample])), 'CPU row check disagrees with the GPU'
+            out['cpu_baseline'] = {'value': n_rows * sample / secs, 'unit': 'row-checks/s', 'cores': threads, 'kind': 'port',
+                                   'sample': '%d witnesses of the same %d-row system, 4x64 Montgomery row check on %d '
+                                             'threads, %.1f s wall (witness generation excluded)' % (sample, n_rows, threads, secs)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

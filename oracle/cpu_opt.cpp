@@ -118,4 +118,67 @@ double zko_opt_eval(const uint8_t* kinds, const uint32_t* a, const uint32_t* b, 
   return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// CPU statement of the R1CS row check <a,w> * <b,w> = <c,w> (the zkinterface `Simulator` the reference's tests run on
+// ToR1CSConverter output, rust/src/consumers/to_r1cs.rs:583-589; that crate is not under /root/reference, so this is the
+// mathematical definition) -- the `cpu_baseline` of bench.py --workload c5 and a second checker for the row kernel.
+// CSR as zkgpu_r1cs_load_csr takes it: row_ptr[3*rows+1] (A, B, C segments), term_var (variable id, or 2^64-1 = the
+// constant one), term_coef (index into coefs, coef_width bytes each, little-endian).  base[lane][n_base][width] are the
+// variables 0..n_base-1; variables n_base.. are assigned first, in row order, by every row r < n_assign whose C is the
+// single term 1*z (z = <a,w>*<b,w>), untimed.  first_fail[lane] = first failing row or 0xFFFFFFFF.
+// Returns the wall-clock seconds of the check alone.
+double zko_r1cs_check(const uint32_t* row_ptr, const uint64_t* term_var, const uint32_t* term_coef, uint32_t n_rows,
+                      const uint8_t* coefs, uint32_t coef_width, uint32_t n_coefs, const uint8_t* mod_le, uint32_t mod_len,
+                      const uint8_t* base, uint32_t n_base, uint32_t n_vars, uint32_t width, uint32_t n_assign,
+                      uint32_t batch, uint32_t threads, uint32_t* first_fail) {
+  Field f;
+  f.init(mod_le, mod_len);
+  std::vector<F4> cm(n_coefs);
+  for (uint32_t i = 0; i < n_coefs; ++i) cm[i] = f.from_bytes(coefs + (size_t)i * coef_width, coef_width);
+  std::vector<std::vector<F4>> vars(batch);
+  auto lincomb = [&](const std::vector<F4>& v, uint32_t t0, uint32_t t1) {
+    F4 acc;
+    memset(&acc, 0, sizeof acc);
+    for (uint32_t t = t0; t < t1; ++t) {
+      const F4& x = term_var[t] == ~0ull ? f.one : v[term_var[t]];
+      acc = f.add(acc, f.mul(x, cm[term_coef[t]]));
+    }
+    return acc;
+  };
+  auto run = [&](bool check) {
+    std::atomic<uint32_t> next(0);
+    auto worker = [&]() {
+      for (;;) {
+        const uint32_t lane = next.fetch_add(1);
+        if (lane >= batch) break;
+        std::vector<F4>& v = vars[lane];
+        if (!check) {
+          v.resize(n_vars);
+          for (uint32_t k = 0; k < n_base; ++k) v[k] = f.from_bytes(base + ((size_t)lane * n_base + k) * width, width);
+          for (uint32_t r = 0; r < n_assign; ++r) {
+            const uint32_t* rp = row_ptr + 3 * (size_t)r;
+            v[term_var[rp[2]]] = f.mul(lincomb(v, rp[0], rp[1]), lincomb(v, rp[1], rp[2]));
+          }
+        } else {
+          uint32_t ff = 0xFFFFFFFFu;
+          for (uint32_t r = 0; r < n_rows; ++r) {
+            const uint32_t* rp = row_ptr + 3 * (size_t)r;
+            const F4 ab = f.mul(lincomb(v, rp[0], rp[1]), lincomb(v, rp[1], rp[2]));
+            const F4 c = lincomb(v, rp[2], rp[3]);
+            if (memcmp(ab.l, c.l, 32) != 0 && ff == 0xFFFFFFFFu) ff = r;
+          }
+          first_fail[lane] = ff;
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& th : pool) th.join();
+  };
+  run(false);
+  auto t0 = std::chrono::steady_clock::now();
+  run(true);
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 }  // extern "C"

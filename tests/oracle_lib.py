@@ -54,7 +54,30 @@ def load():
                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p,
                                  ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                  ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.zko_r1cs_check.restype = ctypes.c_double
+    lib.zko_r1cs_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p,
+                                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p,
+                                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                   ctypes.c_uint32, ctypes.c_void_p]
     return lib
+
+
+def r1cs_check(row_ptr, term_var, term_coef, coef_bytes, modulus_le, base, n_vars, n_assign, threads):
+    """CPU row check of a CSR system (oracle/cpu_opt.cpp zko_r1cs_check): base = uint8 [batch][n_base][width] values of
+    the variables 0..n_base-1, the rest are assigned by the first n_assign product rows.  Returns (first_fail, seconds)."""
+    import numpy as np
+    lib = load()
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+    term_var = np.ascontiguousarray(term_var, dtype=np.uint64)
+    term_coef = np.ascontiguousarray(term_coef, dtype=np.uint32)
+    coef_bytes = np.ascontiguousarray(coef_bytes, dtype=np.uint8)
+    base = np.ascontiguousarray(base, dtype=np.uint8)
+    batch, n_base, width = base.shape
+    ff = np.zeros(batch, dtype=np.uint32)
+    secs = lib.zko_r1cs_check(row_ptr.ctypes.data, term_var.ctypes.data, term_coef.ctypes.data, (len(row_ptr) - 1) // 3,
+                              coef_bytes.tobytes(), coef_bytes.shape[1], coef_bytes.shape[0], modulus_le, len(modulus_le),
+                              base.ctypes.data, n_base, n_vars, width, n_assign, batch, threads, ff.ctypes.data)
+    return ff, secs
 
 
 def opt_eval(kinds, a, b, constants, modulus_le, inst, n_inst, wit, n_wit, width, batch, threads, dump_lane=None):

@@ -573,6 +573,10 @@ def test_r1cs_csr_rows_with_coefficients(p):
     ff, counts = ev.r1cs_results(batch)
     assert counts == (0, batch)            # the appended false row fails in every lane
     assert all(int(x) == wl.M + 1 for x in ff)
+    # the CPU row check (oracle/cpu_opt.cpp, the cpu_baseline of bench.py --workload c5) sees the same first failing row
+    from oracle_lib import r1cs_check
+    ff_cpu, _ = r1cs_check(row_ptr, tv, tc, cb, wl.mod_le, w, wl.n_base + 1 + wl.M, wl.M, 4)
+    assert np.array_equal(ff_cpu, ff)
 
 
 def test_synth_workspace_round_trips_through_files_and_oracle(tmp_path):

@@ -59,3 +59,30 @@ def test_boolean_relation_is_refused():
     ev = zk.Evaluator.from_messages(golden_buffers('bool_correct'))
     with pytest.raises(zk.ZkGpuError):
         ev.r1cs_from_tape()
+
+
+@pytest.mark.parametrize('p', [101, 2 ** 61 - 1, circuits.BN254_R])
+def test_cpu_row_check_against_python_integers(p):
+    """oracle/cpu_opt.cpp zko_r1cs_check (the C5 cpu_baseline and second checker of the row kernel): product-row
+    assignment and the check of every row against plain Python integer arithmetic."""
+    import numpy as np
+    from oracle_lib import r1cs_check
+    from zkinterface_ir_amd import workloads
+    wl = workloads.R1csSynthetic(M=300, n_base=24, n_coefs=50, seed=7, p=p)
+    row_ptr, tv, tc, cb = wl.csr()
+    batch = 6
+    w = wl.witnesses(batch)
+    coefs = [int.from_bytes(cb[i].tobytes(), 'little') for i in range(len(cb))]
+    expect = []
+    for lane in range(batch):
+        val = {k: int.from_bytes(w[lane, k].tobytes(), 'little') for k in range(wl.n_witness)}
+        for r in range(wl.M):
+            terms = [(int(tv[7 * r + k]), coefs[int(tc[7 * r + k])]) for k in range(6)]
+            a = sum(c * val[v] for v, c in terms[:3]) % p
+            b = sum(c * val[v] for v, c in terms[3:]) % p
+            val[wl.n_base + 1 + r] = a * b % p
+        e = val[wl.last_z] if lane % 2 == 0 else (val[wl.last_z] + 1) % p   # odd lanes: the comparison row fails
+        w[lane, wl.n_base] = np.frombuffer(e.to_bytes(wl.width, 'little'), dtype=np.uint8)
+        expect.append(0xFFFFFFFF if lane % 2 == 0 else wl.M)
+    ff, _ = r1cs_check(row_ptr, tv, tc, cb, wl.mod_le, w, wl.n_base + 1 + wl.M, wl.M, 2)
+    assert ff.tolist() == expect
