@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void bool_replay_kernel(const BoolReplayArgs a
   const u64 valid_mask = lane0 >= args.batch ? 0ull
                          : (args.batch - lane0 >= 64 ? ~0ull : ((1ull << (args.batch - lane0)) - 1));
   for (u32 i = begin; i < end; ++i) {
-    const TapeOp op = args.ops[i];
+    const TapeOp op = load_op_scalar(args.ops, i);
     u64 r = 0;
     bool has_out = true;
     switch (op.kind) {

@@ -38,6 +38,18 @@ struct TapeOp {
   u32 kind;
 };
 
+// wave-uniform program entry on the scalar path (see load_entry_scalar below for the why)
+__device__ __forceinline__ TapeOp load_op_scalar(const TapeOp* ops, u32 i) {
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* q = (cu32*)(unsigned long long)(ops + __builtin_amdgcn_readfirstlane(i));
+  TapeOp op;
+  op.dst = q[0];
+  op.a = q[1];
+  op.b = q[2];
+  op.kind = q[3];
+  return op;
+}
+
 constexpr u32 kNoFail = 0xFFFFFFFFu;
 constexpr u32 kLaneFlagNonCanonical = 1u;
 
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
   auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_NOP; };  // OP_NZ reads a
   auto needs_b = [](u32 k) { return k == OP_ADD || k == OP_MUL || k == OP_AND || k == OP_XOR; };
 
-  TapeOp op = args.ops[begin];
+  TapeOp op = load_op_scalar(args.ops, begin);
   Fp<N> a, b;
   if (needs_a(op.kind)) a = wire_load<N>(T + (size_t)op.a * REC);
   if (needs_b(op.kind)) b = wire_load<N>(T + (size_t)op.b * REC);
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
     Fp<N> na, nb;
     nop.kind = OP_NOP;
     if (PIPE && i + 1 < end) {
-      nop = args.ops[i + 1];
+      nop = load_op_scalar(args.ops, i + 1);
       if (needs_a(nop.kind)) na = wire_load<N>(T + (size_t)nop.a * REC);
       if (needs_b(nop.kind)) nb = wire_load<N>(T + (size_t)nop.b * REC);
     }
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       // evaluator.rs:801-820): the next op usually consumes the value just produced -- forward it
       // from registers instead of reading the wire table back.
       const u32 produced = has_out ? op.dst : 0xFFFFFFFFu;
-      op = args.ops[i + 1];
+      op = load_op_scalar(args.ops, i + 1);
       if (needs_a(op.kind)) a = (op.a == produced) ? r : wire_load<N>(T + (size_t)op.a * REC);
       if (needs_b(op.kind)) b = (op.b == produced) ? r : wire_load<N>(T + (size_t)op.b * REC);
     }
