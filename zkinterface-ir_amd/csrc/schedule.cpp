@@ -140,24 +140,45 @@ bool rewrite_ladders(const Tape& in, const FieldHost& field, Tape* out, uint64_t
 
 }  // namespace
 
-Schedule build_schedule(const Tape& recorded, const FieldHost& field, const ScheduleOptions& opt) {
-  Tape rewritten;
-  uint64_t n_ladders = 0;
-  const bool use_rewritten = opt.fermat && !opt.retain_all && !field.is_two && rewrite_ladders(recorded, field, &rewritten, &n_ladders);
-  const Tape& tape = use_rewritten ? rewritten : recorded;
-  Schedule s;
-  const size_t n = tape.size();
-  s.retain_all = opt.retain_all;
-  s.n_ladders = n_ladders;
-  s.boolean_path = field.is_two;
-  s.slot_of.assign(n, kNoWire);
-  s.level_of.assign(n, 0);
-  if (n == 0) return s;
+namespace {
 
+// The stages of build_schedule(): one object holds the working arrays, one method per stage, run in this order.
+struct ScheduleBuilder {
+  const Tape& tape;
+  const FieldHost& field;
+  const ScheduleOptions& opt;
+  Schedule s;
+  size_t n = 0;
+  std::vector<uint8_t> const_odd;       // GF(2): parity of every constant
+  uint32_t bool_zero_const = 0;         // GF(2): index of the synthetic constant 0
+  std::vector<uint32_t> opa, opb;       // operands resolved through copy chains
+  std::vector<uint8_t> absorbed;        // 0 = own entry; 1 = evaluated inside its reader (fusion); 2 = elided (copy, dropped
+                                        // ladder op); 3 = shared producer of a pair entry; 4 = second value of a pair entry
+  std::vector<uint32_t> first_use, last_use;
+  uint32_t n_levels = 0;
+  std::vector<uint32_t> pair_second;    // first gate of a pair entry -> second gate (allocated when pairing runs)
+  std::vector<uint32_t> order;          // entries in program order
+  std::vector<uint64_t> level_start;    // level l = order[level_start[l] .. level_start[l + 1])
+  size_t n_live = 0;
+
+  ScheduleBuilder(const Tape& t, const FieldHost& f, const ScheduleOptions& o) : tape(t), field(f), opt(o) {}
+
+  void device_constants();
+  void propagate_copies();
+  void levelise();
+  void fuse_and_pair();
+  void order_by_level();
+  int gathered(uint32_t i, uint32_t out[4]) const;
+  void assign_slots();
+  void emit_entries();
+  void emit_launches();
+};
+
+void ScheduleBuilder::device_constants() {
   // ---- constant pool in device form -------------------------------------
   const uint32_t n_consts = (uint32_t)tape.consts.size();
-  std::vector<uint8_t> const_odd(n_consts, 0);
-  uint32_t bool_zero_const = 0;
+  const_odd.assign(n_consts, 0);
+  bool_zero_const = 0;
   if (s.boolean_path) {
     s.words_per_const = 1;
     s.const_words.resize(n_consts + 1);
@@ -178,15 +199,18 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
       memcpy(&s.const_words[(size_t)i * field.nwords], m, 4 * field.nwords);
     }
   }
+}
 
+void ScheduleBuilder::propagate_copies() {
   // ---- copy propagation ------------------------------------------------------
   // The reference's scoping (ingest_subcircuit, evaluator.rs:698-746) copies every input into and every
   // output out of a call / loop body / switch branch: about half of the backend calls of a structured
   // relation are copies.  A copy has the value of its source, so readers are pointed at the source and a
   // copy nobody can observe any more is not materialised.  Copies that must stay
   // readable (retain_all dumps, wires alive at the end) are kept.
-  std::vector<uint32_t> opa(tape.a), opb(tape.b);
-  std::vector<uint8_t> absorbed(n, 0);  // 1 = evaluated inside its reader (fusion), 2 = elided copy
+  opa = tape.a;
+  opb = tape.b;
+  absorbed.assign(n, 0);
   for (size_t i = 0; i < n; ++i)
     if (tape.kind[i] == TK_NOP) absorbed[i] = 2;  // dropped ladder ops: no entry, no slot, read nothing
   const bool propagate = opt.propagate_copies && !opt.retain_all;
@@ -209,10 +233,13 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
       }
     }
   }
+}
 
+void ScheduleBuilder::levelise() {
   // ---- dependency levels (ASAP for ops with inputs) ----------------------
   std::vector<uint32_t>& level = s.level_of;
-  std::vector<uint32_t> first_use(n, kInf), last_use(n, 0);
+  first_use.assign(n, kInf);
+  last_use.assign(n, 0);
   std::vector<uint8_t> used(n, 0);
   for (size_t i = 0; i < n; ++i) {
     const int ni = n_inputs(tape.kind[i]);
@@ -232,7 +259,7 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
   for (size_t i = 0; i < n; ++i)
     if (n_inputs(tape.kind[i]) == 0 && tape.kind[i] != TK_NOP)
       level[i] = first_use[i] == kInf ? 0 : first_use[i] - 1;
-  uint32_t n_levels = 0;
+  n_levels = 0;
   for (size_t i = 0; i < n; ++i) {
     if (absorbed[i]) continue;
     const int ni = n_inputs(tape.kind[i]);
@@ -245,13 +272,16 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
   for (uint32_t h : opt.pinned)
     if (h < n) last_use[h] = kInf;
   s.n_levels = n_levels;
+}
 
+void ScheduleBuilder::fuse_and_pair() {
   // ---- gate fusion ---------------------------------------------------------
   // An Add/Mul whose value has exactly one reader, itself an Add/Mul, is evaluated inside that reader
   // (depth 1: an op that absorbs cannot be absorbed, an absorbed op has absorbed nothing).  The value is
   // then never materialised, so this is only done when nobody can ask for it afterwards.
+  std::vector<uint32_t>& level = s.level_of;
   const bool fuse = opt.fuse && !opt.retain_all && !s.boolean_path;
-  std::vector<uint32_t> pair_second;  // first gate of a pair entry -> second gate (allocated when pairing runs)
+  pair_second.clear();
   if (fuse) {
     std::vector<uint32_t> reads(n, 0), reader(n, 0), reader0(n, 0);
     std::vector<uint8_t> has_absorbed(n, 0);
@@ -304,25 +334,29 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
     }
     s.fused = s.n_absorbed != 0;
   }
+}
 
+void ScheduleBuilder::order_by_level() {
   // ---- order ops by (level, kind): counting sort ------------------------
   constexpr uint32_t kKinds = TK_NZ + 1;
   std::vector<uint64_t> bucket((size_t)n_levels * kKinds + 1, 0);
-  size_t n_live = 0;
+  const std::vector<uint32_t>& level = s.level_of;
+  n_live = 0;
   for (size_t i = 0; i < n; ++i)
     if (!absorbed[i]) { ++bucket[(size_t)level[i] * kKinds + tape.kind[i] + 1]; ++n_live; }
   for (size_t k = 1; k < bucket.size(); ++k) bucket[k] += bucket[k - 1];
-  std::vector<uint32_t> order(n_live);
+  order.assign(n_live, 0);
   {
     std::vector<uint64_t> cursor(bucket.begin(), bucket.end() - 1);
     for (size_t i = 0; i < n; ++i)
       if (!absorbed[i]) order[cursor[(size_t)level[i] * kKinds + tape.kind[i]]++] = (uint32_t)i;
   }
-  std::vector<uint64_t> level_start(n_levels + 1);
+  level_start.assign(n_levels + 1, 0);
   for (uint32_t l = 0; l <= n_levels; ++l) level_start[l] = bucket[(size_t)l * kKinds];
+}
 
-  // wires an op gathers from the table (resolved through elided copies and fused producers)
-  auto gathered = [&](uint32_t i, uint32_t out[4]) {
+// wires an op gathers from the table (resolved through elided copies and fused producers)
+int ScheduleBuilder::gathered(uint32_t i, uint32_t out[4]) const {
     int k = 0;
     const int ni = n_inputs(tape.kind[i]);
     auto push = [&](uint32_t p) {
@@ -338,8 +372,9 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
     if (ni >= 1) push(opa[i]);
     if (ni == 2) push(opb[i]);
     return k;  // (a pair entry's fifth wire, the second gate's own operand, is left out of the locality graph)
-  };
+}
 
+void ScheduleBuilder::assign_slots() {
   // ---- slots: liveness-based reuse, level by level ----------------------
   std::vector<uint32_t> free_slots;
   std::vector<uint32_t> expire_head(n_levels + 1, kInf), expire_next(n, kInf);  // intrusive lists per last_use level
@@ -367,7 +402,8 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
       }
     }
     if (opt.sort_by_operand >= 2 && !s.boolean_path && level_start[l + 1] - level_start[l] > 8)
-      locality_order(order.data() + level_start[l], level_start[l + 1] - level_start[l], gathered);
+      locality_order(order.data() + level_start[l], level_start[l + 1] - level_start[l],
+                     [&](uint32_t i, uint32_t* out) { return gathered(i, out); });
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
       const uint32_t i = order[k];
       if (tape.kind[i] == TK_ASSERT || tape.kind[i] == TK_NOP) continue;
@@ -400,7 +436,9 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
     }
   }
   s.n_slots = std::max<uint32_t>(n_slots, 1);
+}
 
+void ScheduleBuilder::emit_entries() {
   // ---- device ops ----------------------------------------------------------
   if (s.fused) {
     s.ops2.resize(n_live);
@@ -485,7 +523,9 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
     }
     s.ops[k] = d;
   }
+}
 
+void ScheduleBuilder::emit_launches() {
   // ---- launches -------------------------------------------------------------
   uint32_t l = 0;
   while (l < n_levels) {
@@ -510,7 +550,33 @@ Schedule build_schedule(const Tape& recorded, const FieldHost& field, const Sche
     }
     if (L.count) s.launches.push_back(L);
   }
-  return s;
+}
+
+}  // namespace
+
+Schedule build_schedule(const Tape& recorded, const FieldHost& field, const ScheduleOptions& opt) {
+  Tape rewritten;
+  uint64_t n_ladders = 0;
+  const bool use_rewritten = opt.fermat && !opt.retain_all && !field.is_two && rewrite_ladders(recorded, field, &rewritten, &n_ladders);
+  const Tape& tape = use_rewritten ? rewritten : recorded;
+  ScheduleBuilder b(tape, field, opt);
+  Schedule& s = b.s;
+  b.n = tape.size();
+  s.retain_all = opt.retain_all;
+  s.n_ladders = n_ladders;
+  s.boolean_path = field.is_two;
+  s.slot_of.assign(b.n, kNoWire);
+  s.level_of.assign(b.n, 0);
+  if (b.n == 0) return s;
+  b.device_constants();
+  b.propagate_copies();
+  b.levelise();
+  b.fuse_and_pair();
+  b.order_by_level();
+  b.assign_slots();
+  b.emit_entries();
+  b.emit_launches();
+  return std::move(b.s);
 }
 
 }  // namespace zki
