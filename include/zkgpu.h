@@ -114,7 +114,8 @@ int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* 
 int zkgpu_set_inputs_device(zkgpu_session* s, const void* d_instances, const void* d_witnesses, uint32_t batch);
 /* use the values of the ingested Instance / Witness messages as a batch of one */
 int zkgpu_set_inputs_from_messages(zkgpu_session* s);
-/* replay lane groups of this many witnesses one after the other (0 = whole batch at once) */
+/* replay lane groups of this many witnesses one after the other; 0 (default) = automatic: the largest group whose
+ * wire table stays in the 256 MiB Infinity Cache (whole XCD rounds per stream), or the whole batch when it fits */
 int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 
 /* options: "max_tape_ops" = N (default 2^30: loops are unrolled, this bounds a corrupt loop bound),
