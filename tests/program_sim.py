@@ -55,10 +55,11 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                     r = (x + y) % p
                 elif kind == OP['mul']:
                     r = x * y * rinv % p
-                elif kind == OP['and']:
-                    r = x & y
-                else:
-                    r = x ^ y
+                elif boolean:
+                    r = x & y if kind == OP['and'] else x ^ y
+                else:  # integer bit operation on the canonical values, then % p (evaluator.rs:924-933)
+                    xi, yi = x * rinv % p, y * rinv % p
+                    r = ((xi & yi) if kind == OP['and'] else (xi ^ yi)) % p * R % p
                 if second:  # pair entry: a second gate of the level shares operand a
                     assert kind in (OP['add'], OP['mul'])
                     reads.add(c0)
@@ -86,7 +87,7 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
             elif kind == OP['not']:
                 assert slots[a] is not None
                 reads.add(a)
-                r = 1 - slots[a]
+                r = 1 - slots[a] if boolean else (R % p if slots[a] == 0 else 0)
             elif kind == OP['const']:
                 r = consts[a]
             elif kind in (OP['instance'], OP['witness']):

@@ -250,8 +250,10 @@ class Gen:
         rows_i, rows_w = [], []
         for _ in range(lanes):
             def val():
-                if self.boolean:
+                if self.boolean and self.p == 2:
                     return r.randrange(2)
+                if self.boolean:  # boolean gateset over an odd field: the gates are integer bit operations
+                    return r.choice(small) if r.random() < 0.3 else r.randrange(self.p)
                 return r.choice(small) % self.p if r.random() < 0.6 else r.randrange(self.p)
             rows_i.append([val() for _ in range(self.n_inst)])
             rows_w.append([val() for _ in range(self.n_wit)])

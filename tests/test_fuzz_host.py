@@ -8,7 +8,8 @@ from helpers import oracle_lane
 from random_circuits import Gen
 import zkinterface_ir_amd as zk
 
-FIELDS = [(101, False), (circuits.BN254_R, False), (2, True), (2 ** 61 - 1, False), (2, False)]
+FIELDS = [(101, False), (circuits.BN254_R, False), (2, True), (2 ** 61 - 1, False), (2, False), (101, True),
+          (circuits.BN254_R, True)]
 
 
 def expected_product_violations(ev, first_fail):
@@ -23,7 +24,7 @@ def expected_product_violations(ev, first_fail):
     return out
 
 
-@pytest.mark.parametrize('seed', range(40))
+@pytest.mark.parametrize('seed', range(56))
 def test_random_relation_against_oracle(seed):
     p, boolean = FIELDS[seed % len(FIELDS)]
     g = Gen(seed, p, boolean)

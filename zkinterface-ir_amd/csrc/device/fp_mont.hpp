@@ -54,6 +54,51 @@ __device__ __forceinline__ Fp<N> fp_nonzero_indicator(const Fp<N>& a, const Fiel
   return r;
 }
 
+// forward declarations for the integer-bitwise gates below
+template <int N>
+__device__ __forceinline__ Fp<N> fp_from_mont(const Fp<N>& a, const FieldParams& fp);
+template <int N>
+__device__ __forceinline__ Fp<N> fp_to_mont(const Fp<N>& a, const FieldParams& fp);
+template <int N>
+__device__ __forceinline__ bool fp_geq_p(const Fp<N>& a, const FieldParams& fp);
+
+// `and` / `xor` of PlaintextBackend over an odd field (evaluator.rs:924-933): the bit operation on the canonical
+// integers, then `% p`.  a & b <= min(a, b) < p needs no reduction; a ^ b < 2^bits(p) < 2p needs one subtraction.
+template <int N>
+__device__ __forceinline__ Fp<N> fp_bit_and(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
+  const Fp<N> x = fp_from_mont<N>(a, fp), y = fp_from_mont<N>(b, fp);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = x.w[i] & y.w[i];
+  return fp_to_mont<N>(r, fp);
+}
+template <int N>
+__device__ __forceinline__ Fp<N> fp_bit_xor(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
+  const Fp<N> x = fp_from_mont<N>(a, fp), y = fp_from_mont<N>(b, fp);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = x.w[i] ^ y.w[i];
+  if (fp_geq_p<N>(r, fp)) {
+    u64 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const u64 d = (u64)r.w[i] - fp.p[i] - borrow;
+      r.w[i] = (u32)d;
+      borrow = (d >> 63) & 1;
+    }
+  }
+  return fp_to_mont<N>(r, fp);
+}
+// `not` of PlaintextBackend (evaluator.rs:935-938): 1 if the value is zero, else 0.
+template <int N>
+__device__ __forceinline__ Fp<N> fp_is_zero_indicator(const Fp<N>& a, const FieldParams& fp) {
+  const bool z = fp_is_zero<N>(a);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = z ? fp.one[i] : 0u;
+  return r;
+}
+
 // a >= p ?
 template <int N>
 __device__ __forceinline__ bool fp_geq_p(const Fp<N>& a, const FieldParams& fp) {

@@ -25,7 +25,7 @@ enum OpKind : u32 {
   OP_INSTANCE = 7,  // dst = to_mont(instance[lane][a])
   OP_WITNESS = 8,   // dst = to_mont(witness[lane][a])
   OP_ASSERT = 9,    // a must be zero; b = assert sequence number
-  OP_AND = 10,      // boolean-mode ops on {0,1} (arith tables only see them for p=2)
+  OP_AND = 10,      // and / xor / not: bits for p = 2 (bool_kernels.hpp); integer bit ops then % p for an odd p
   OP_XOR = 11,
   OP_NOT = 12,
   OP_NZ = 13,  // 1 if the operand is non-zero else 0: x^(p-1) over a prime field (scheduler-made, schedule.cpp)
@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       case OP_MULC: r = fp_mul<N>(a, fp_load_const<N>(args.consts + (size_t)op.b * N), fp); break;
       case OP_COPY: r = a; break;
       case OP_NZ: r = fp_nonzero_indicator<N>(a, fp); break;
+      case OP_AND: r = fp_bit_and<N>(a, b, fp); break;   // integer bit ops of PlaintextBackend over an odd field
+      case OP_XOR: r = fp_bit_xor<N>(a, b, fp); break;
+      case OP_NOT: r = fp_is_zero_indicator<N>(a, fp); break;
       case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a * N); break;
       case OP_INSTANCE:
       case OP_WITNESS: {
@@ -326,6 +329,9 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
       case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
       case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
       case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
+      case OP_AND: r = fp_bit_and<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp); break;
+      case OP_XOR: r = fp_bit_xor<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp); break;
+      case OP_NOT: r = fp_is_zero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
       case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
       case OP_INSTANCE:
       case OP_WITNESS: {

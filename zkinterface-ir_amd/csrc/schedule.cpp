@@ -474,6 +474,10 @@ void ScheduleBuilder::emit_entries() {
             operand(opb[i], &d.b0, &d.b1, 10);
           }
           break;
+        case TK_AND: case TK_XOR:
+          d.a0 = s.slot_of[opa[i]];
+          d.b0 = s.slot_of[opb[i]];
+          break;
         case TK_ADDC: case TK_MULC:
           d.a0 = s.slot_of[opa[i]];
           d.b0 = opb[i];

@@ -109,7 +109,6 @@ void TapeBackend::set_field(const Value& modulus, uint32_t degree, bool is_boole
       throw Error("GPU backend: the field changed between Relation messages");
     return;
   }
-  if (is_boolean && !f.is_two) throw Error("GPU backend: boolean gate set over a field with p != 2 is not supported");
   field_ = f;
   field_set_ = true;
   is_boolean_ = is_boolean;
@@ -148,9 +147,9 @@ TapeBackend::Wire TapeBackend::arith(uint8_t kind, uint32_t a, uint32_t b) {
 
 TapeBackend::Wire TapeBackend::bitwise(uint8_t kind, uint32_t a, uint32_t b) {
   need_field();
-  // PlaintextBackend applies & ^ to the integers and then `% m` (evaluator.rs:924-938);
-  // that only coincides with field arithmetic for p == 2.
-  if (!field_.is_two) throw Error("GPU backend: and/xor/not over a field with p != 2 is not supported");
+  // PlaintextBackend applies & ^ to the integers and then `% m`, and `not` is `is_zero ? 1 : 0`
+  // (evaluator.rs:924-938); for p == 2 that is the bit-packed path, for an odd p the arithmetic kernels do the
+  // same on the canonical values (fp_bit_and / fp_bit_xor / fp_is_zero_indicator, device/fp_mont.hpp).
   return push(kind, a, b);
 }
 
