@@ -29,6 +29,11 @@ def test_c_example_and_cli_print_the_reference_verdicts(tmp_path):
                            '-Wl,-rpath,' + os.path.dirname(zk.LIB_PATH), '-o', exe])
     r = subprocess.run([exe] + REF_EXAMPLES, capture_output=True, text=True)
     assert r.returncode == 0 and 'The statement is TRUE!' in r.stderr
+    r = subprocess.run([exe, '--valid-eval-metrics'] + REF_EXAMPLES, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert 'The statement is COMPLIANT with the specification!' in r.stderr and 'The statement is TRUE!' in r.stderr
+    import json
+    assert json.loads(r.stdout[r.stdout.index('{'):])['gate_stats']['functions_called'] == 4
     err = io.StringIO()
     assert cli.main(['evaluate'] + REF_EXAMPLES, err=err) == 0
     assert err.getvalue() == '\nThe statement is TRUE!\n'
