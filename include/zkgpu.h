@@ -65,6 +65,11 @@ int zkgpu_backend_not(zkgpu_session* s, uint32_t a, uint32_t* out);             
  * instance / witness stream; the values themselves arrive per lane through zkgpu_set_inputs. */
 int zkgpu_backend_instance(zkgpu_session* s, uint32_t position, uint32_t* out);
 int zkgpu_backend_witness(zkgpu_session* s, uint32_t position, uint32_t* out);
+/* Optional hint from the caller's Evaluator (rust/src/consumers/evaluator.rs:823-839 compute_weight): the backend calls
+ * made since zkgpu_tape_len() read `first_call` computed result = base^(modulus - 1), the Switch indicator.  With the
+ * hint the production schedule may evaluate the ladder as one `base != 0` entry when the characteristic is prime
+ * (option "fermat"); without it the ladder is replayed product by product.  The bundled Evaluator gives it itself. */
+int zkgpu_backend_ladder(zkgpu_session* s, uint64_t first_call, uint32_t base, uint32_t result);
 
 /* ---- 2. Evaluator / Source entry points ---------------------------------- */
 /* A byte stream of one or more size-prefixed messages (consumers/utils.rs:6-41).

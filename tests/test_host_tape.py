@@ -209,6 +209,45 @@ def test_switch_ladder_becomes_one_entry_only_over_a_prime_field():
     assert sizes[(91, 'on')] == sizes[(91, 'off')]                            # 91 = 7 * 13: no shortcut
 
 
+def test_trait_level_ladder_hint():
+    """A caller that drives the ZKBackend entry points itself (the Rust Evaluator of INTEGRATION.md) can name the
+    exponent ladder of a Switch weight with zkgpu_backend_ladder; the schedule then shrinks exactly as with the
+    bundled Evaluator, and both forms give weight 1 for cond == case and 0 otherwise."""
+    p = circuits.BN254_R
+    minus_one = (p - 1).to_bytes(32, 'little')
+
+    def record(hint):
+        ev = zk.Evaluator()
+        ev.backend_set_field(p.to_bytes(32, 'little'))
+        cond = ev.backend_witness(0)
+        case = ev.backend_constant(bytes([7]))
+        base = ev.backend_add(case, ev.backend_mul_constant(cond, minus_one))
+        first = ev.tape_len
+        bits = bin(p - 1)[2:]                      # square-and-multiply, most significant bit first
+        acc = ev.backend_copy(base)
+        for b in bits[1:]:
+            acc = ev.backend_multiply(acc, acc)
+            if b == '1':
+                acc = ev.backend_multiply(acc, base)
+        if hint:
+            ev.backend_ladder(first, base, acc)
+        weight = ev.backend_add_constant(ev.backend_mul_constant(acc, minus_one), bytes([1]))
+        # assert weight * (cond - 7) == 0 and (1 - weight) * 1 == 0 only when cond == 7: check the weight directly
+        ev.backend_assert_zero(ev.backend_add_constant(weight, minus_one), 0)      # fails unless weight == 1
+        ev.finalize()
+        return ev
+    plain, hinted = record(False), record(True)
+    assert plain.schedule_info()['device_ops'] > 200 and hinted.schedule_info()['device_ops'] < 12
+    for ev in (plain, hinted):
+        ops, launches, consts, _ = ev.schedule_dump()
+        info = ev.schedule_info()
+        for cond, ok in ((7, True), (8, False), (0, False), (p - 1, False)):
+            _, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, [], [cond])
+            assert not noncanon and (ff is None) == ok, (cond, ff)
+    with pytest.raises(zk.ZkGpuError, match='not a range of recorded calls'):
+        hinted.backend_ladder(10 ** 9, 0, 1)
+
+
 def test_layered_program_with_pair_entries_against_oracle():
     """The production schedule of a layered relation (gate fusion, pair entries for producers with two readers in
     one level, shared-operand order) interpreted entry by entry: the verdict and every surviving output wire equal

@@ -62,6 +62,7 @@ def lib():
         'zkgpu_backend_not': (ci, [vp, u32, u32p]),
         'zkgpu_backend_instance': (ci, [vp, u32, u32p]),
         'zkgpu_backend_witness': (ci, [vp, u32, u32p]),
+        'zkgpu_backend_ladder': (ci, [vp, u64, u32, u32]),
         'zkgpu_ingest_messages': (ci, [vp, u8p, sz]),
         'zkgpu_ingest_paths': (ci, [vp, ctypes.POINTER(ctypes.c_char_p), sz]),
         'zkgpu_declare_inputs': (ci, [vp, u32, u32]),
@@ -272,6 +273,10 @@ class Evaluator:
     def backend_instance(self, position):
         return self._wire(self.L.zkgpu_backend_instance, position)
 
+    def backend_ladder(self, first_call, base, result):
+        """hint: the calls first_call.. computed result = base^(modulus - 1) (include/zkgpu.h)"""
+        self._ck(self.L.zkgpu_backend_ladder(self.h, first_call, base, result))
+
     def backend_witness(self, position):
         return self._wire(self.L.zkgpu_backend_witness, position)
 
@@ -301,6 +306,11 @@ class Evaluator:
             self.L.zkgpu_constant_bytes(self.h, i, buf, n)
             out.append(buf.raw[:n])
         return out
+
+    @property
+    def tape_len(self):
+        """backend calls recorded so far (value-returning calls and assert_zero)"""
+        return self.L.zkgpu_tape_len(self.h)
 
     @property
     def n_value_ops(self):

@@ -285,6 +285,13 @@ int zkgpu_backend_xor(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
 int zkgpu_backend_not(zkgpu_session* s, uint32_t a, uint32_t* out) {
   return guarded(s, [&] { *out = s->backend.not_(a); });
 }
+int zkgpu_backend_ladder(zkgpu_session* s, uint64_t first_call, uint32_t base, uint32_t result) {
+  return guarded(s, [&] {
+    if (first_call > s->backend.tape().size() || result >= s->backend.tape().size())
+      throw std::runtime_error("zkgpu_backend_ladder: not a range of recorded calls");
+    s->backend.note_ladder_end((size_t)first_call, base, result);
+  });
+}
 int zkgpu_backend_instance(zkgpu_session* s, uint32_t position, uint32_t* out) {
   return guarded(s, [&] { *out = s->backend.instance(TapeBackend::instance_ref(position)); });
 }
