@@ -354,14 +354,19 @@ def main():
     # PCIe-inclusive figure (never `value`): the boundary hands over host buffers every step
     pcie_ms = None
     if world == 1:
-        ib, wb = inst.tobytes(), wit.tobytes()
+        # page-locked host buffers (what a streaming caller would use): the DMA engine reads them directly
+        pin_i = torch.from_numpy(np.ascontiguousarray(inst).reshape(-1)).pin_memory()
+        pin_w = torch.from_numpy(np.ascontiguousarray(wit).reshape(-1)).pin_memory()
+        ib, wb = pin_i.data_ptr(), pin_w.data_ptr()
         ev.set_inputs(ib, wb, batch)
+        ev.replay()
+        ev.synchronize()
         tp = time.perf_counter()
-        for _ in range(3):
+        for _ in range(6):   # batch k+1 is handed over while batch k replays (two input sets, copy stream)
             ev.set_inputs(ib, wb, batch)
             ev.replay()
-            ev.synchronize()
-        pcie_ms = (time.perf_counter() - tp) * 1e3 / 3
+        ev.synchronize()
+        pcie_ms = (time.perf_counter() - tp) * 1e3 / 6
     exp_sat = workloads.expected_satisfied(batch * world)
     assert total[0] == exp_sat and total[0] + total[1] == batch * world, (total, exp_sat)
 

@@ -749,3 +749,43 @@ def test_graph_replay_gives_the_same_results():
         flat = results['0'] + results['1']
         assert all(r == flat[0] for r in flat)
         assert 0 < flat[0][0][0] < lanes
+
+
+def test_inputs_handed_over_while_the_previous_batch_replays():
+    """zkgpu_set_inputs fills the input set the replay in flight is not reading (copy stream, two sets): a stream of
+    different batches, each handed over right after the previous replay was queued, gives every batch its own answer."""
+    wl = workloads.ArithLayered(W=512, D=6, n_instance0=16, n_out=8)
+    batch = 256
+    ev, inst, wit, n_bad = _layered_session(wl, batch)
+    good = (inst.copy(), wit.copy())
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (batch - n_bad, n_bad)
+    bad_w = wit.copy()
+    bad_w[:, :, 0] ^= 1                       # every witness value of every lane changed: every statement false
+    seen = []
+    for k in range(6):
+        w = good[1] if k % 2 == 0 else bad_w
+        ev.set_inputs(inst.tobytes(), w.tobytes(), batch)   # overlaps the replay queued in the previous iteration
+        ev.replay()
+        if k % 3 == 2:
+            ev.synchronize()
+        seen.append(None)
+    ev.synchronize()
+    assert ev.counts()[0] == 0                # the last batch handed over was the damaged one
+    ev.set_inputs(inst.tobytes(), good[1].tobytes(), batch)
+    ev.set_inputs(inst.tobytes(), bad_w.tobytes(), batch)   # two uploads in a row, then the good one again
+    ev.set_inputs(inst.tobytes(), good[1].tobytes(), batch)
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (batch - n_bad, n_bad)
+    # page-locked caller memory is read by the DMA engine directly (no staging copy): same answers
+    import torch
+    pin_i = torch.from_numpy(np.ascontiguousarray(inst).reshape(-1)).pin_memory()
+    pin_bad = torch.from_numpy(np.ascontiguousarray(bad_w).reshape(-1)).pin_memory()
+    pin_good = torch.from_numpy(np.ascontiguousarray(good[1]).reshape(-1)).pin_memory()
+    for pin_w, want in ((pin_bad, (0, batch)), (pin_good, (batch - n_bad, n_bad)), (pin_bad, (0, batch))):
+        ev.set_inputs(pin_i.data_ptr(), pin_w.data_ptr(), batch)
+        ev.replay()
+        ev.synchronize()
+        assert ev.counts() == want

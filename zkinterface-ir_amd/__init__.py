@@ -355,9 +355,13 @@ class Evaluator:
         return ops, launches, consts[:info['const_words']], slot_of[:self.L.zkgpu_tape_len(self.h)]
 
     def set_inputs(self, instances, witnesses, batch):
-        """instances / witnesses: bytes-like of [batch][n][elem_bytes] (or None when n == 0)."""
-        self._keep = (bytes(instances) if instances is not None else None,
-                      bytes(witnesses) if witnesses is not None else None)
+        """instances / witnesses: bytes-like of [batch][n][elem_bytes] (or None when n == 0), or the integer address
+        of such a host buffer (e.g. `tensor.data_ptr()` of a pinned torch tensor: read by DMA without a staging copy)."""
+        def arg(x):
+            if x is None or isinstance(x, int):
+                return x
+            return bytes(x)
+        self._keep = (arg(instances), arg(witnesses))
         self._ck(self.L.zkgpu_set_inputs(self.h, self._keep[0], self._keep[1], batch))
 
     def set_inputs_device(self, d_instances, d_witnesses, batch):

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "device/bool_kernels.hpp"
 #include "device/r1cs_kernels.hpp"
@@ -91,6 +93,10 @@ Engine::~Engine() {
     if (h_stage_[k]) (void)hipHostFree(h_stage_[k]);
     if (ev_stage_[k]) (void)hipEventDestroy((hipEvent_t)ev_stage_[k]);
   }
+  if (ev_upload_) (void)hipEventDestroy((hipEvent_t)ev_upload_);
+  for (int k = 0; k < 2; ++k)
+    if (ev_set_free_[k]) (void)hipEventDestroy((hipEvent_t)ev_set_free_[k]);
+  if (copy_stream_) (void)hipStreamDestroy((hipStream_t)copy_stream_);
   if (ev_fork_) (void)hipEventDestroy((hipEvent_t)ev_fork_);
   for (int k = 0; k < 3; ++k) {
     if (ev_join_[k]) (void)hipEventDestroy((hipEvent_t)ev_join_[k]);
@@ -103,8 +109,12 @@ void Engine::free_batch() {
   dfree(d_table_);
   dfree(d_first_fail_);
   dfree(d_flags_);
-  dfree(d_inst_own_);
-  dfree(d_wit_own_);
+  for (int k = 0; k < 2; ++k) {
+    dfree(d_inst_own_[k]);
+    dfree(d_wit_own_[k]);
+    set_read_[k] = false;
+  }
+  upload_pending_ = false;
   dfree(d_packed_inst_);
   dfree(d_packed_wit_);
   dfree(d_r1cs_fail_);
@@ -329,20 +339,70 @@ void Engine::upload_inputs(const uint8_t* inst, const uint8_t* wit) {
   const size_t ib = (size_t)batch_ * n_inst_ * elem_bytes_, wb = (size_t)batch_ * n_wit_ * elem_bytes_;
   if (ib && !inst) throw std::runtime_error("Engine: instance values missing");
   if (wb && !wit) throw std::runtime_error("Engine: witness values missing");
-  if (!d_inst_own_) HIP_OK(hipMalloc(&d_inst_own_, std::max<size_t>(ib, 64)));
-  if (!d_wit_own_) HIP_OK(hipMalloc(&d_wit_own_, std::max<size_t>(wb, 64)));
-  if (ib) staged_upload(d_inst_own_, inst, ib);
-  if (wb) staged_upload(d_wit_own_, wit, wb);
-  if (d_inst_ != d_inst_own_ || d_wit_ != d_wit_own_) graph_dirty_ = true;
-  d_inst_ = d_inst_own_;
-  d_wit_ = d_wit_own_;
+  if (!copy_stream_) {
+    hipStream_t cs;
+    HIP_OK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    copy_stream_ = cs;
+    hipEvent_t e;
+    HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ev_upload_ = e;
+    for (int k = 0; k < 2; ++k) {
+      HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ev_set_free_[k] = e;
+    }
+  }
+  // the other set: whatever replay is queued or running keeps reading the current one
+  const int k = own_set_ ^ 1;
+  hipStream_t cs = (hipStream_t)copy_stream_;
+  if (!d_inst_own_[k]) HIP_OK(hipMalloc(&d_inst_own_[k], std::max<size_t>(ib, 64)));
+  if (!d_wit_own_[k]) HIP_OK(hipMalloc(&d_wit_own_[k], std::max<size_t>(wb, 64)));
+  if (set_read_[k]) HIP_OK(hipStreamWaitEvent(cs, (hipEvent_t)ev_set_free_[k], 0));  // its last reader has finished
+  if (ib) staged_upload(d_inst_own_[k], inst, ib);
+  if (wb) staged_upload(d_wit_own_[k], wit, wb);
+  HIP_OK(hipEventRecord((hipEvent_t)ev_upload_, cs));
+  upload_pending_ = true;
+  own_set_ = k;
+  if (d_inst_ != d_inst_own_[k] || d_wit_ != d_wit_own_[k]) graph_dirty_ = true;
+  d_inst_ = d_inst_own_[k];
+  d_wit_ = d_wit_own_[k];
 }
 
-// Host -> HBM through two pinned staging buffers: the CPU copy of chunk k overlaps the DMA of chunk k-1.
+// The staging copy is what bounds a hand-over (one core moves ~10 GB/s, the link more): large chunks are copied by
+// four threads.
+static void parallel_copy(uint8_t* dst, const uint8_t* src, size_t n) {
+  constexpr size_t kMinPerThread = 1u << 20;
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t parts = std::min<size_t>(std::min<size_t>(4, hw ? hw : 1), n / kMinPerThread);
+  if (parts <= 1) {
+    memcpy(dst, src, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t step = (n / parts + 63) & ~(size_t)63;
+  for (size_t t = 1; t < parts; ++t) {
+    const size_t lo = t * step, hi = std::min(n, lo + step);
+    if (lo < hi) pool.emplace_back([=] { memcpy(dst + lo, src + lo, hi - lo); });
+  }
+  memcpy(dst, src, std::min(n, step));
+  for (auto& th : pool) th.join();
+}
+
+// Host -> HBM through two pinned staging buffers on the copy stream: the CPU copy of chunk k overlaps the DMA of
+// chunk k-1, and the whole upload overlaps the replay that is still reading the other input set.  Returns once the
+// caller's memory has been read (the last DMAs may still be in flight; the next replay waits for them on the GPU).
 // (A plain hipMemcpy from pageable memory measured ~4 GB/s here.)
 void Engine::staged_upload(void* dst, const uint8_t* src, size_t bytes) {
   constexpr size_t kChunk = 16u << 20;
-  hipStream_t st = (hipStream_t)stream_;
+  hipStream_t cs = (hipStream_t)copy_stream_;
+  // Page-locked caller memory (hipHostMalloc / hipHostRegister, e.g. a pinned torch tensor) is read by the DMA engine
+  // directly: no staging copy.  The call still returns only when the caller's buffer has been read.
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeHost) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
+    HIP_OK(hipStreamSynchronize(cs));
+    return;
+  }
+  (void)hipGetLastError();  // an unregistered pointer makes the query fail: not an error here
   for (int k = 0; k < 2; ++k) {
     if (!h_stage_[k]) HIP_OK(hipHostMalloc(&h_stage_[k], kChunk, hipHostMallocDefault));
     if (!ev_stage_[k]) {
@@ -352,19 +412,17 @@ void Engine::staged_upload(void* dst, const uint8_t* src, size_t bytes) {
     }
   }
   size_t done = 0;
-  int k = 0;
-  bool used[2] = {false, false};
   while (done < bytes) {
     const size_t n = std::min(kChunk, bytes - done);
-    if (used[k]) HIP_OK(hipEventSynchronize((hipEvent_t)ev_stage_[k]));  // buffer k free again
-    memcpy(h_stage_[k], src + done, n);
-    HIP_OK(hipMemcpyAsync((uint8_t*)dst + done, h_stage_[k], n, hipMemcpyHostToDevice, st));
-    HIP_OK(hipEventRecord((hipEvent_t)ev_stage_[k], st));
-    used[k] = true;
+    const int k = stage_next_;
+    if (stage_used_[k]) HIP_OK(hipEventSynchronize((hipEvent_t)ev_stage_[k]));  // staging buffer k free again
+    parallel_copy((uint8_t*)h_stage_[k], src + done, n);
+    HIP_OK(hipMemcpyAsync((uint8_t*)dst + done, h_stage_[k], n, hipMemcpyHostToDevice, cs));
+    HIP_OK(hipEventRecord((hipEvent_t)ev_stage_[k], cs));
+    stage_used_[k] = true;
     done += n;
-    k ^= 1;
+    stage_next_ ^= 1;
   }
-  HIP_OK(hipStreamSynchronize(st));
 }
 
 void Engine::use_device_inputs(const void* d_inst, const void* d_wit) {
@@ -509,6 +567,10 @@ void Engine::replay(bool time_each_launch) {
       launch_events_.push_back(e);
     }
   }
+  if (upload_pending_) {  // the inputs this replay reads are still arriving on the copy stream
+    HIP_OK(hipStreamWaitEvent(st, (hipEvent_t)ev_upload_, 0));
+    upload_pending_ = false;
+  }
   HIP_OK(hipEventRecord((hipEvent_t)ev_begin_, st));
   const bool graphed = use_graph() && !time_each_launch;
   if (graphed) {
@@ -519,6 +581,10 @@ void Engine::replay(bool time_each_launch) {
     enqueue_replay(time_each_launch);
   }
   HIP_OK(hipEventRecord((hipEvent_t)ev_end_, st));
+  if (copy_stream_ && d_inst_ == d_inst_own_[own_set_] && d_wit_ == d_wit_own_[own_set_]) {
+    HIP_OK(hipEventRecord((hipEvent_t)ev_set_free_[own_set_], st));  // the next upload into this set waits for it
+    set_read_[own_set_] = true;
+  }
   HIP_OK(hipGetLastError());
   timings_.clear();
   if (time_each_launch && !lds_path_) {

@@ -115,14 +115,24 @@ class Engine {
   void* d_first_fail_ = nullptr;
   void* d_flags_ = nullptr;
   void* d_counts_ = nullptr;
-  void* d_inst_own_ = nullptr;
-  void* d_wit_own_ = nullptr;
+  // Engine-owned input buffers, two sets: an upload fills the set the replay in flight is not reading, on its own
+  // copy stream, so handing over batch k+1 overlaps the replay of batch k.
+  void* d_inst_own_[2] = {nullptr, nullptr};
+  void* d_wit_own_[2] = {nullptr, nullptr};
+  int own_set_ = 0;                          // set the last upload went to
+  void* copy_stream_ = nullptr;
+  void* ev_upload_ = nullptr;                // end of the last upload (the next replay waits for it)
+  void* ev_set_free_[2] = {nullptr, nullptr};  // end of the last replay that read set k
+  bool upload_pending_ = false;
+  bool set_read_[2] = {false, false};
   const void* d_inst_ = nullptr;
   const void* d_wit_ = nullptr;
   void* d_packed_inst_ = nullptr;  // GF(2) path
   void* d_packed_wit_ = nullptr;
   void* h_stage_[2] = {nullptr, nullptr};  // pinned staging for host -> HBM input uploads
   void* ev_stage_[2] = {nullptr, nullptr};
+  bool stage_used_[2] = {false, false};
+  int stage_next_ = 0;
   void* d_r1cs_rows_ = nullptr;
   void* d_r1cs_terms_ = nullptr;
   void* d_r1cs_coefs_ = nullptr;
