@@ -10,6 +10,10 @@ checks, the verdict reduction) and, for N > 1, the RCCL all-reduce of the
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes, started
+before anything in this process touches the GPU); rank 0 prints the JSON line.  With fewer than N devices visible
+the ranks share the card and the count reduction runs over gloo (rehearsal of the same sharding; the line says so).
 """
 import argparse
 import json
@@ -139,6 +143,14 @@ def cpu_baseline(wl, msgs, inst, wit, gates, ev=None):
         extra = {'cpu_opt': {'value': gates * opt_lanes / osecs, 'unit': 'gate-ops/s', 'cores': threads,
                              'what': 'optimised CPU evaluator (flat wire array, 4x64 Montgomery, flattened tape), '
                                      '%d witnesses in %.1f s' % (opt_lanes, osecs)}}
+    # the oracle's verdicts on the sample are the check of the GPU counts: the expected outputs the session was
+    # built with come from a GPU probe pass, so without this a wrong but self-consistent kernel would pass
+    from zkinterface_ir_amd import workloads
+    want = workloads.expected_satisfied(lanes)
+    assert int(sum(ok)) == want, 'oracle: %d of %d sample lanes satisfied, expected %d' % (int(sum(ok)), lanes, want)
+    if ev is not None:
+        ff = np.asarray(ev.lane_results(inst.shape[0])[0][:lanes])
+        assert np.array_equal(ff == 0xFFFFFFFF, np.asarray(ok, dtype=bool)), 'GPU and oracle verdicts differ on the sample'
     return {**extra, 'value': gates * lanes / secs, 'unit': 'gate-ops/s', 'cores': threads, 'kind': 'port',
             'sample': '%d witnesses of the same %d-gate relation, one reference-style Evaluator run per witness, '
                       '%d threads, %.1f s wall (single witness: %.2f s)' % (lanes, gates, threads, secs, per_lane),
@@ -247,6 +259,35 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
         dist.destroy_process_group()
 
 
+def launch_ranks(n):
+    """Start one child process per rank (never exec: this process stays a plain parent and has not touched the
+    GPU) and return the first non-zero exit code, or 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:      # a rank died: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -263,23 +304,25 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))   # nothing in this process has touched torch or the GPU
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                     '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
-        args.gpus = world
-    if not torch.cuda.is_available():
+    args.gpus = world
+    if os.environ.get('ZKI_BENCH_FAIL_RANK') == str(rank) and world > 1:
+        sys.exit('rank %d told to fail (launcher test)' % rank)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0 or not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU: the replay path has no CPU fallback')
-    # one process per GPU.  ZKI_DIST_BACKEND=gloo (+ several ranks on one card) is the rehearsal mode used
-    # on single-GPU boxes: same sharding and reductions, collectives on CPU tensors.
-    backend = os.environ.get('ZKI_DIST_BACKEND', 'nccl')
-    dev_index = local_rank % torch.cuda.device_count()
+    # One process per GPU, counts reduced by RCCL.  With fewer devices than ranks (a one-GPU box) the ranks share
+    # the card and the reduction runs over gloo on CPU tensors: a rehearsal of the same sharding, said so in the line.
+    backend = os.environ.get('ZKI_DIST_BACKEND', 'nccl' if n_dev >= world else 'gloo')
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     red_dev = 'cuda' if backend == 'nccl' else 'cpu'
     if world > 1:
@@ -367,6 +410,7 @@ def main():
             ev.replay()
         ev.synchronize()
         pcie_ms = (time.perf_counter() - tp) * 1e3 / 6
+        assert list(ev.counts()) == total, (ev.counts(), total)   # the handed-over batches give the resident answer
     exp_sat = workloads.expected_satisfied(batch * world)
     assert total[0] == exp_sat and total[0] + total[1] == batch * world, (total, exp_sat)
 
@@ -403,7 +447,8 @@ def main():
                        'program_entries': info['device_ops'],
                        'gates_evaluated_inside_their_reader': int(len(kinds)) - info['device_ops'],
                        'wire_table_MB': round(ev.table_bytes / 1e6, 1), 'lane_group': args.lane_group,
-                       'parallelism': 'witness lanes sharded over %d GPU(s); one all-reduce of 2 x u64' % world,
+                       'parallelism': 'witness lanes sharded over %d rank(s) on %d device(s); one all-reduce of 2 x u64 (%s)'
+                                      % (world, min(world, n_dev), 'none' if world == 1 else 'RCCL' if backend == 'nccl' else backend + ' rehearsal'),
                        'pcie_inclusive_ms_per_step': None if pcie_ms is None else round(pcie_ms, 3),
                        'satisfied': total[0], 'failed': total[1], 'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -1,7 +1,9 @@
-"""CPU rehearsal of the N > 1 path (gloo, world size 2): lanes are sharded contiguously,
-every rank evaluates only its shard, and the only exchange is one all-reduce of the
-{satisfied, failed} counters -- exactly what bench.py does over RCCL.  The per-shard
-evaluation is done by the oracle here (no GPU in this tier)."""
+"""CPU tier, sharding arithmetic only (gloo, world size 2): lanes are sharded contiguously, every rank
+owns a slice of the global batch, and the only exchange is one all-reduce of the {satisfied, failed}
+counters plus the max-over-ranks timing.  No line of the product runs here -- there is no GPU in this
+tier, so the per-shard verdicts come from the oracle.  The product's own N > 1 path (bench.py launching
+its ranks, one Engine per rank, the reduction of the device counters) is run by tests/test_multi_rank.py
+in the GPU tier."""
 import os
 import socket
 import sys

@@ -763,16 +763,18 @@ def test_inputs_handed_over_while_the_previous_batch_replays():
     assert ev.counts() == (batch - n_bad, n_bad)
     bad_w = wit.copy()
     bad_w[:, :, 0] ^= 1                       # every witness value of every lane changed: every statement false
-    seen = []
-    for k in range(6):
-        w = good[1] if k % 2 == 0 else bad_w
-        ev.set_inputs(inst.tobytes(), w.tobytes(), batch)   # overlaps the replay queued in the previous iteration
+    answers = {True: (batch - n_bad, n_bad), False: (0, batch)}
+    pending = None                            # answer the replay in flight must give
+    for k in range(8):
+        is_good = k % 2 == 0
+        w = good[1] if is_good else bad_w
+        ev.set_inputs(inst.tobytes(), w.tobytes(), batch)   # handed over while replay k-1 is still queued or running
+        if pending is not None:
+            assert ev.counts() == pending, 'replay %d read the inputs handed over for replay %d' % (k - 1, k)
         ev.replay()
-        if k % 3 == 2:
-            ev.synchronize()
-        seen.append(None)
-    ev.synchronize()
-    assert ev.counts()[0] == 0                # the last batch handed over was the damaged one
+        pending = answers[is_good]
+    assert ev.counts() == pending             # the last batch handed over was the damaged one
+    assert pending == (0, batch)
     ev.set_inputs(inst.tobytes(), good[1].tobytes(), batch)
     ev.set_inputs(inst.tobytes(), bad_w.tobytes(), batch)   # two uploads in a row, then the good one again
     ev.set_inputs(inst.tobytes(), good[1].tobytes(), batch)

@@ -248,6 +248,45 @@ def test_trait_level_ladder_hint():
         hinted.backend_ladder(10 ** 9, 0, 1)
 
 
+def test_bogus_and_overlapping_ladder_hints_leave_the_schedule_alone():
+    """zkgpu_backend_ladder is a public entry: a range that is not the reference's square-and-multiply recursion over
+    p - 1 (evaluator.rs:801-820), two hints over the same calls, or a hint under is_boolean (where `as_mul` is `and`)
+    must not change the program -- the schedule is the one of the unhinted recording."""
+    p = circuits.BN254_R
+    minus_one = (p - 1).to_bytes(32, 'little')
+
+    def record(mode):
+        ev = zk.Evaluator()
+        ev.backend_set_field(p.to_bytes(32, 'little'), 1, mode == 'boolean')
+        cond = ev.backend_witness(0)
+        base = ev.backend_add(ev.backend_constant(bytes([7])), ev.backend_mul_constant(cond, minus_one))
+        first = ev.tape_len
+        bits = bin(p - 1)[2:]
+        acc = ev.backend_copy(base)
+        for k, b in enumerate(bits[1:]):
+            acc = ev.backend_multiply(acc, acc)
+            if b == '1' or (mode == 'extra_multiply' and k == 5):     # one multiply too many: not base^(p-1)
+                acc = ev.backend_multiply(acc, base)
+        if mode == 'wrong_base':
+            ev.backend_ladder(first, cond, acc)
+        elif mode == 'short_range':
+            ev.backend_ladder(first + 2, base, acc)
+        elif mode == 'overlap':
+            ev.backend_ladder(first, base, acc)
+            ev.backend_ladder(first, base, acc)
+        elif mode != 'none':
+            ev.backend_ladder(first, base, acc)
+        weight = ev.backend_add_constant(ev.backend_mul_constant(acc, minus_one), bytes([1]))
+        ev.backend_assert_zero(ev.backend_add_constant(weight, minus_one), 0)
+        ev.finalize()
+        return ev.schedule_info()['device_ops']
+    plain = record('none')
+    assert record('good') < 12 < plain
+    for mode in ('wrong_base', 'short_range', 'overlap', 'boolean'):
+        assert record(mode) == plain, mode
+    assert record('extra_multiply') >= plain
+
+
 def test_layered_program_with_pair_entries_against_oracle():
     """The production schedule of a layered relation (gate fusion, pair entries for producers with two readers in
     one level, shared-operand order) interpreted entry by entry: the verdict and every surviving output wire equal

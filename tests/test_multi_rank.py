@@ -1,0 +1,58 @@
+"""GPU tier: the product's N > 1 path, started the way the driver starts it (`python bench.py --gpus N`, no external
+launcher).  On a one-GPU box the ranks share the card and the count reduction runs over gloo (bench.py picks that
+itself when fewer devices than ranks are visible): same lane sharding, same per-rank Engine, same reduction of the
+engine's device counters as the 8-GPU run over RCCL (BASELINE configs[2])."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from zkinterface_ir_amd import workloads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, timeout=600):
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + [str(a) for a in args], env=env,
+                         capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout      # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_launches_two_ranks_itself_and_reduces_the_counts():
+    r = run_bench('--gpus', 2, '--steps', 2, '--warmup', 1, '--batch-per-gpu', 256, '--width', 512, '--depth', 8,
+                  '--no-cpu-baseline')
+    assert r['n_gpus'] == 2 and r['scaling'] == 'weak'
+    # lanes 0..511 of the global batch: corrupted 0, 97, 194, 291, 388, 485 -- 3 on each rank
+    assert r['config']['satisfied'] == workloads.expected_satisfied(512) == 506
+    assert r['config']['failed'] == 6
+    assert r['value'] > 0 and r['roofline']['frac'] > 0
+
+
+@pytest.mark.gpu
+def test_three_ranks_uneven_corruption_boolean_and_r1cs():
+    r = run_bench('--gpus', 3, '--workload', 'c4', '--steps', 1, '--warmup', 1, '--batch-per-gpu', 128, '--width', 256,
+                  '--depth', 6, '--no-cpu-baseline')
+    assert r['n_gpus'] == 3
+    assert r['config']['satisfied'] == workloads.expected_satisfied(384) == 380   # 0, 97 | 194 | 291
+    r = run_bench('--gpus', 2, '--workload', 'c5', '--steps', 1, '--warmup', 1, '--batch-per-gpu', 128, '--width', 2048,
+                  '--no-cpu-baseline')
+    assert r['n_gpus'] == 2 and r['config']['satisfied'] == workloads.expected_satisfied(256) == 253
+
+
+@pytest.mark.gpu
+def test_a_failing_rank_fails_the_launcher():
+    env = dict(os.environ, ZKI_BENCH_FAIL_RANK='1')
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                          '--batch-per-gpu', '64', '--width', '64', '--depth', '3', '--no-cpu-baseline'], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0

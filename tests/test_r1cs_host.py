@@ -86,3 +86,74 @@ def test_cpu_row_check_against_python_integers(p):
         expect.append(0xFFFFFFFF if lane % 2 == 0 else wl.M)
     ff, _ = r1cs_check(row_ptr, tv, tc, cb, wl.mod_le, w, wl.n_base + 1 + wl.M, wl.M, 2)
     assert ff.tolist() == expect
+
+
+def _csr_session(M=12):
+    import numpy as np
+    from zkinterface_ir_amd import workloads
+    wl = workloads.R1csSynthetic(M=M, n_base=8, n_coefs=10, seed=3)
+    ev = zk.Evaluator()
+    ev.declare_inputs(0, wl.n_witness)
+    ev.ingest_message(wl.base_relation())
+    ev.finalize(retain_all=True)
+    return ev, wl, [np.array(x) for x in wl.csr()]
+
+
+def test_load_csr_rejects_indices_the_host_would_walk_off():
+    """zkgpu_r1cs_load_csr checks what it indexes with: a row_ptr that steps back or does not start at 0,
+    a coefficient index past the pool, a zero coefficient width."""
+    ev, wl, (row_ptr, tv, tc, cb) = _csr_session()
+    bad = row_ptr.copy(); bad[5] = bad[4] - 1
+    with pytest.raises(zk.ZkGpuError, match='row_ptr decreases'):
+        ev.r1cs_load_csr(bad, tv, tc, cb, wl.width, wl.M)
+    bad = row_ptr.copy(); bad[0] = 1
+    with pytest.raises(zk.ZkGpuError, match=r'row_ptr\[0\] must be 0'):
+        ev.r1cs_load_csr(bad, tv, tc, cb, wl.width, wl.M)
+    bad = tc.copy(); bad[3] = len(cb)
+    with pytest.raises(zk.ZkGpuError, match='names coefficient'):
+        ev.r1cs_load_csr(row_ptr, tv, bad, cb, wl.width, wl.M)
+    bad = tv.copy(); bad[2] = 10 ** 9
+    with pytest.raises(zk.ZkGpuError, match='variable out of range'):
+        ev.r1cs_load_csr(row_ptr, bad, tc, cb, wl.width, wl.M)
+    ev.r1cs_load_csr(row_ptr, tv, tc, cb, wl.width, wl.M)     # the untouched system loads
+
+
+def test_assign_refuses_rows_it_cannot_assign():
+    """zkgpu_r1cs_assign writes <a,w>*<b,w> into C's variable: any other shape of C, a row range past the system, two
+    rows assigning one variable or a row reading what the same call assigns is an error on the host, before the GPU is
+    touched (the kernel stores unconditionally)."""
+    import numpy as np
+    ev, wl, (row_ptr, tv, tc, cb) = _csr_session()
+    one = int(np.where((cb[:, 0] == 1) & (cb[:, 1:] == 0).all(axis=1))[0][0]) if ((cb[:, 0] == 1) & (cb[:, 1:] == 0).all(axis=1)).any() else None
+    # the comparison row of the synthetic system (last row) has C = the expected-output variable; rows 0..M-1 are product rows
+    ev.r1cs_load_csr(row_ptr, tv, tc, cb, wl.width, wl.M)
+    with pytest.raises(zk.ZkGpuError, match='row range out of bounds'):
+        ev.r1cs_assign(0, wl.M + 5)
+    with pytest.raises(zk.ZkGpuError, match='reads a variable that a row of the same call assigns'):
+        ev.r1cs_assign(0, wl.M)                                # rows of later levels read z of earlier ones
+    # C with two terms / C = constant one / coefficient != 1
+    def reload(mut):
+        e2, _, (rp, v, c, b) = _csr_session()
+        rp, v, c = mut(rp.copy(), v.copy(), c.copy())
+        e2.r1cs_load_csr(rp, v, c, b, wl.width, wl.M)
+        return e2
+    def two_terms(rp, v, c):      # move B's last term of row 0 into C
+        rp[2] -= 1
+        return rp, v, c
+    with pytest.raises(zk.ZkGpuError, match='has 2 terms in C'):
+        reload(two_terms).r1cs_assign(0, 1)
+    def const_one(rp, v, c):
+        v[rp[2]] = 2 ** 64 - 1
+        return rp, v, c
+    with pytest.raises(zk.ZkGpuError, match='C is the constant one'):
+        reload(const_one).r1cs_assign(0, 1)
+    def other_coef(rp, v, c):
+        c[rp[2]] = (c[rp[2]] + 1) % len(cb) if one is None or (c[rp[2]] + 1) % len(cb) != one else (c[rp[2]] + 2) % len(cb)
+        return rp, v, c
+    with pytest.raises(zk.ZkGpuError, match="coefficient of C's variable is not 1"):
+        reload(other_coef).r1cs_assign(0, 1)
+    def same_target(rp, v, c):
+        v[rp[3 + 2]] = v[rp[2]]    # row 1 assigns row 0's variable
+        return rp, v, c
+    with pytest.raises(zk.ZkGpuError, match='two rows of the call assign the same variable'):
+        reload(same_target).r1cs_assign(0, 2)

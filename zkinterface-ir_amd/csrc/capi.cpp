@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -228,6 +229,37 @@ void build_device_rows(zkgpu_session* s, SlotOf&& slot_of_var) {
   }
   s->r1cs_coef_words = cm.words;
   s->r1cs_on_device = false;
+}
+
+// zkgpu_r1cs_assign stores <a,w>*<b,w> into the slot of C's only term (r1cs_row_kernel<N, true>): every row of the
+// call must have exactly that shape, and no row of the call may read a slot another row of it writes -- checked here,
+// on the host, so that a row of any other shape is an error and never a stray store on the GPU.
+void r1cs_check_assignable(zkgpu_session* s, uint32_t first_row, uint32_t n_rows) {
+  if (!s->r1cs_ready) throw std::runtime_error("no R1CS: call zkgpu_r1cs_from_tape or zkgpu_r1cs_load_csr");
+  const auto& rows = s->r1cs_rows_dev;
+  const auto& terms = s->r1cs_terms_dev;
+  if ((uint64_t)first_row + n_rows > rows.size()) throw std::runtime_error("zkgpu_r1cs_assign: row range out of bounds");
+  std::vector<uint32_t> targets;
+  targets.reserve(n_rows);
+  for (uint32_t r = first_row; r < first_row + n_rows; ++r) {
+    const uint32_t na = rows[r].counts & 0xFF, nb = (rows[r].counts >> 8) & 0xFF, nc = (rows[r].counts >> 16) & 0xFF;
+    const std::string where = "zkgpu_r1cs_assign: row " + std::to_string(r);
+    if (nc != 1) throw std::runtime_error(where + " has " + std::to_string(nc) + " terms in C (exactly one variable with coefficient 1 is assignable)");
+    const R1csTermDev& c = terms[rows[r].first + na + nb];
+    if (c.coef != 0xFFFFFFFFu) throw std::runtime_error(where + ": the coefficient of C's variable is not 1");
+    if (c.slot == 0xFFFFFFFFu) throw std::runtime_error(where + ": C is the constant one, not a variable");
+    targets.push_back(c.slot);
+  }
+  std::sort(targets.begin(), targets.end());
+  if (std::adjacent_find(targets.begin(), targets.end()) != targets.end())
+    throw std::runtime_error("zkgpu_r1cs_assign: two rows of the call assign the same variable");
+  for (uint32_t r = first_row; r < first_row + n_rows; ++r) {
+    const uint32_t na = rows[r].counts & 0xFF, nb = (rows[r].counts >> 8) & 0xFF;
+    for (uint32_t t = rows[r].first; t < rows[r].first + na + nb; ++t)
+      if (terms[t].slot != 0xFFFFFFFFu && std::binary_search(targets.begin(), targets.end(), terms[t].slot))
+        throw std::runtime_error("zkgpu_r1cs_assign: row " + std::to_string(r) +
+                                 " reads a variable that a row of the same call assigns (split the call by dependency level)");
+  }
 }
 
 void r1cs_to_device(zkgpu_session* s) {
@@ -746,11 +778,25 @@ int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_p
   return guarded(s, [&] {
     if (!s->finalized || !s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) first: variables are tape values");
     if (s->engine) throw std::runtime_error("load the CSR before the first zkgpu_set_inputs* call (the table is sized once)");
+    if (!row_ptr || (n_coefs && (!coef_bytes || coef_width == 0)))
+      throw std::runtime_error("zkgpu_r1cs_load_csr: row_ptr / coefficient bytes missing or coef_width is 0");
     R1cs r;
     r.row_ptr.assign(row_ptr, row_ptr + 3 * (size_t)n_rows + 1);
+    // the term arrays hold row_ptr[3 * n_rows] entries: row_ptr must start at 0 and never step back, or a row
+    // would index outside them
+    if (r.row_ptr[0] != 0) throw std::runtime_error("zkgpu_r1cs_load_csr: row_ptr[0] must be 0");
+    for (size_t i = 1; i < r.row_ptr.size(); ++i)
+      if (r.row_ptr[i] < r.row_ptr[i - 1])
+        throw std::runtime_error("zkgpu_r1cs_load_csr: row_ptr decreases at entry " + std::to_string(i));
     const size_t n_terms = r.row_ptr.back();
+    if (n_terms && (!term_var || !term_coef)) throw std::runtime_error("zkgpu_r1cs_load_csr: term arrays missing");
     r.terms.resize(n_terms);
-    for (size_t i = 0; i < n_terms; ++i) r.terms[i] = R1csTerm{term_var[i], term_coef[i]};
+    for (size_t i = 0; i < n_terms; ++i) {
+      if (term_coef[i] >= n_coefs)
+        throw std::runtime_error("zkgpu_r1cs_load_csr: term " + std::to_string(i) + " names coefficient " +
+                                 std::to_string(term_coef[i]) + " of " + std::to_string(n_coefs));
+      r.terms[i] = R1csTerm{term_var[i], term_coef[i]};
+    }
     for (uint32_t i = 0; i < n_coefs; ++i)
       r.coefs.emplace_back(coef_bytes + (size_t)i * coef_width, coef_bytes + (size_t)(i + 1) * coef_width);
     const uint64_t n_ops = s->value_op_index.size();
@@ -771,6 +817,7 @@ int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_p
 
 int zkgpu_r1cs_assign(zkgpu_session* s, uint32_t first_row, uint32_t n_rows) {
   return guarded(s, [&] {
+    r1cs_check_assignable(s, first_row, n_rows);
     r1cs_to_device(s);
     s->engine->r1cs_run(true, first_row, n_rows);
   });

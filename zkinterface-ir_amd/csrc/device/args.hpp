@@ -1,0 +1,188 @@
+// Records shared by the host engine and the gfx950 kernels: program entries, kernel argument blocks and the
+// host-callable launchers.  The kernels themselves live in the other headers of this directory and are compiled
+// in translation units of their own (kernels_arith.hip once per field width, kernels_bool.hip), so that the
+// engine's host code never instantiates a kernel and the widths build in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zkgpu {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int kMaxWords = 12;  // fields up to 384 bits
+
+// Per-field constants, passed by value in the kernarg segment (wave-uniform:
+// the compiler keeps them in SGPRs).
+struct FieldParams {
+  u32 p[kMaxWords];    // modulus, little-endian 32-bit words
+  u32 r2[kMaxWords];   // R^2 mod p   (to_mont multiplier)
+  u32 one[kMaxWords];  // R mod p     (Montgomery form of 1)
+  u32 n0inv;           // -p^{-1} mod 2^32
+  u32 nwords;          // N actually used (2, 4, ..., 12)
+};
+
+enum OpKind : u32 {
+  OP_NOP = 0,
+  OP_ADD = 1,       // dst = a + b
+  OP_MUL = 2,       // dst = a * b
+  OP_ADDC = 3,      // dst = a + const[b]
+  OP_MULC = 4,      // dst = a * const[b]
+  OP_COPY = 5,      // dst = a
+  OP_CONST = 6,     // dst = const[a]
+  OP_INSTANCE = 7,  // dst = to_mont(instance[lane][a])
+  OP_WITNESS = 8,   // dst = to_mont(witness[lane][a])
+  OP_ASSERT = 9,    // a must be zero; b = assert sequence number
+  OP_AND = 10,      // and / xor / not: bits for p = 2 (bool_kernels.hpp); integer bit ops then % p for an odd p
+  OP_XOR = 11,
+  OP_NOT = 12,
+  OP_NZ = 13,  // 1 if the operand is non-zero else 0: x^(p-1) over a prime field (scheduler-made, schedule.cpp)
+};
+
+struct TapeOp {
+  u32 dst;
+  u32 a;
+  u32 b;
+  u32 kind;
+};
+
+// 32-byte program entry of the fused schedule (host: DevOp2, schedule.hpp)
+struct TapeOp2 {
+  u32 dst, kind, a0, a1, b0, b1, pad0, pad1;
+};
+
+constexpr u32 kNoFail = 0xFFFFFFFFu;
+constexpr u32 kLaneFlagNonCanonical = 1u;
+
+struct ReplayArgs {
+  const TapeOp* ops;      // ops of this launch (device)
+  u32 n_ops;
+  u32 ops_per_wave;       // contiguous ops walked by one wave
+  uint4* table;           // wire table
+  u32 n_slots;            // slots per lane block
+  u32 batch;              // real lanes
+  u32 lb_base;            // first lane block of this launch (lane groups)
+  const u32* consts;      // constant pool, Montgomery form, N words each
+  const uint8_t* inst;    // [lane][n_inst][4N bytes] little-endian, canonical
+  const uint8_t* wit;     // [lane][n_wit][4N bytes]
+  u32 n_inst;
+  u32 n_wit;
+  u32* first_fail;        // [lane] min assert sequence number that failed
+  u32* lane_flags;        // [lane] sticky flags (non-canonical input ...)
+  u32 xcd_chunks;         // != 0: XCD-aware 1-D grid, see block_coords()
+};
+
+struct ReplayArgs2 {
+  const TapeOp2* ops;
+  u32 n_ops;
+  u32 ops_per_wave;
+  uint4* table;
+  u32 n_slots;
+  u32 batch;
+  u32 lb_base;
+  const u32* consts;
+  const uint8_t* inst;
+  const uint8_t* wit;
+  u32 n_inst;
+  u32 n_wit;
+  u32* first_fail;
+  u32* lane_flags;
+  u32 xcd_chunks;
+  u32 op_stride;          // 1 or 4, see the kernel
+};
+
+// instantiations of replay_fused_kernel (replay_kernels.hpp)
+constexpr int kFusedHot = 0, kFusedMisc = 1, kFusedAll = 2;
+
+struct BoolReplayArgs {
+  const TapeOp* ops;
+  u32 n_ops;
+  u32 ops_per_wave;
+  u64* table;
+  u32 n_slots;
+  u32 batch;
+  u32 lb_base;              // first lane block of this launch
+  u32 total_words;          // 64 * lane blocks
+  const u32* consts;        // 0/1 per constant
+  const u64* packed_inst;   // [n_inst][total_words]
+  const u64* packed_wit;    // [n_wit][total_words]
+  u32* first_fail;
+};
+
+struct LdsOp {  // 8-byte program entry; wide fields are split over the halves that the kind leaves unused
+  unsigned short dst, a, b, kind;
+};
+
+// The program is cut into kind-uniform chunks of at most kLdsRows rows of 2048 ops (the host sorts a
+// level by kind and pads every kind to a multiple of 2048 with ops writing a scratch slot), so the
+// inner loop carries no per-op decode: chunk = {first op, rows, kind | barrier_after << 8 | sequential << 9, -}.
+// A thread fetches two consecutive ops per row with one 16-byte load (8-byte loads stream at ~0.6x
+// the 16-byte rate, MI355X_MICROARCH.md).
+constexpr int kLdsRows = 4;
+constexpr int kLdsRowOps = 2048;
+
+struct BoolLdsArgs {
+  const LdsOp* ops;
+  const u32* chunks;
+  u32 n_chunks;
+  u32 n_slots;              // including the scratch slot
+  u32 batch;
+  u32 n_cols;               // 32-witness slices in the batch
+  u32 total_words64;        // 64 * lane blocks (layout of the packed inputs)
+  const u32* consts;
+  const u32* packed_inst;   // u32 view of packed[position][word64]
+  const u32* packed_wit;
+  u32* first_fail;
+  u64* table;               // HBM table (bool_replay_kernel layout) for the optional write-back
+  u32 writeback;
+};
+
+struct R1csRow {
+  u32 first;
+  u32 counts;  // nA | nB << 8 | nC << 16 | flags << 24
+};
+struct R1csTerm {
+  u32 slot;  // 0xFFFFFFFF: the constant one
+  u32 coef;  // 0xFFFFFFFF: coefficient 1
+};
+constexpr u32 kR1csBIsOne = 1u;
+
+struct R1csArgs {
+  const R1csRow* rows;
+  const R1csTerm* terms;
+  const u32* coefs;      // Montgomery form, N words each
+  u32 first_row, n_rows; // rows [first_row, first_row + n_rows) of this launch
+  const uint4* table;    // read side
+  uint4* table_out;      // ASSIGN: same table
+  u32 n_slots;
+  u32 batch;
+  u32* first_fail;       // CHECK: min failing row per lane
+};
+
+// ---- launchers (defined in kernels_arith.hip, one set per field width, and kernels_bool.hip) ----
+#define ZKGPU_DECLARE_WIDTH(W)                                                                                      \
+  void launch_replay_fused_w##W(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const FieldParams& fp);  \
+  void launch_replay_w##W(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp);     \
+  void launch_r1cs_w##W(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp);         \
+  void launch_dump_w##W(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,  \
+                        u32 batch, u32* out, const FieldParams& fp);
+ZKGPU_DECLARE_WIDTH(2)
+ZKGPU_DECLARE_WIDTH(4)
+ZKGPU_DECLARE_WIDTH(6)
+ZKGPU_DECLARE_WIDTH(8)
+ZKGPU_DECLARE_WIDTH(10)
+ZKGPU_DECLARE_WIDTH(12)
+#undef ZKGPU_DECLARE_WIDTH
+
+void launch_verdict(dim3 grid, hipStream_t st, const u32* first_fail, const u32* lane_flags, u32 batch,
+                    unsigned long long* counts);
+void launch_pack_inputs(dim3 grid, hipStream_t st, const uint8_t* raw, u32 n_vals, u32 batch, u32 total_words,
+                        u64* packed, u32* lane_flags);
+void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a);
+hipError_t bool_lds_set_max_shared(int bytes);
+void launch_bool_lds(u32 n_cols, size_t lds_bytes, hipStream_t st, const BoolLdsArgs& a);
+void launch_bool_dump(dim3 grid, hipStream_t st, const u64* table, u32 n_slots, const u32* slots, u32 n_dump,
+                      u32 batch, uint8_t* out);
+
+}  // namespace zkgpu

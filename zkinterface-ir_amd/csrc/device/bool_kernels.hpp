@@ -14,20 +14,25 @@
 
 namespace zkgpu {
 
-struct BoolReplayArgs {
-  const TapeOp* ops;
-  u32 n_ops;
-  u32 ops_per_wave;
-  u64* table;
-  u32 n_slots;
-  u32 batch;
-  u32 lb_base;              // first lane block of this launch
-  u32 total_words;          // 64 * lane blocks
-  const u32* consts;        // 0/1 per constant
-  const u64* packed_inst;   // [n_inst][total_words]
-  const u64* packed_wit;    // [n_wit][total_words]
-  u32* first_fail;
-};
+// Final verdict reduction (every field; lives here because this header is compiled exactly once): satisfied = lanes with no failing assert and no flag.
+// counts[0] += satisfied, counts[1] += failed (u64 each), one atomic per wave.
+__global__ __launch_bounds__(256) void verdict_kernel(const u32* __restrict__ first_fail,
+                                                       const u32* __restrict__ lane_flags, u32 batch,
+                                                       unsigned long long* __restrict__ counts) {
+  const u32 lane_g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = lane_g < batch;
+  const bool ok = valid && first_fail[lane_g] == kNoFail && lane_flags[lane_g] == 0;
+  const unsigned long long okm = __ballot(ok);
+  const unsigned long long vm = __ballot(valid);
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned long long n_ok = __popcll(okm);
+    const unsigned long long n_v = __popcll(vm);
+    if (n_v) {
+      atomicAdd(&counts[0], n_ok);
+      atomicAdd(&counts[1], n_v - n_ok);
+    }
+  }
+}
 
 // raw[lane][n_vals] bytes -> packed[pos][word]; flags lanes holding a value > 1.
 // One wave = 64 witnesses x 256 positions.  Each lane reads 16 of its bytes per load (rows are
@@ -124,34 +129,6 @@ __global__ __launch_bounds__(256) void bool_replay_kernel(const BoolReplayArgs a
 // separated by a workgroup barrier, and no wire value ever travels to HBM.
 // The only streamed data is the program itself (8 bytes per op, identical for
 // every workgroup, so it is served from L2).
-struct LdsOp {  // 8-byte program entry; wide fields are split over the halves that the kind leaves unused
-  unsigned short dst, a, b, kind;
-};
-
-// The program is cut into kind-uniform chunks of at most kLdsRows rows of 2048 ops (the host sorts a
-// level by kind and pads every kind to a multiple of 2048 with ops writing a scratch slot), so the
-// inner loop carries no per-op decode: chunk = {first op, rows, kind | barrier_after << 8 | sequential << 9, -}.
-// A thread fetches two consecutive ops per row with one 16-byte load (8-byte loads stream at ~0.6x
-// the 16-byte rate, MI355X_MICROARCH.md).
-constexpr int kLdsRows = 4;
-constexpr int kLdsRowOps = 2048;
-
-struct BoolLdsArgs {
-  const LdsOp* ops;
-  const u32* chunks;
-  u32 n_chunks;
-  u32 n_slots;              // including the scratch slot
-  u32 batch;
-  u32 n_cols;               // 32-witness slices in the batch
-  u32 total_words64;        // 64 * lane blocks (layout of the packed inputs)
-  const u32* consts;
-  const u32* packed_inst;   // u32 view of packed[position][word64]
-  const u32* packed_wit;
-  u32* first_fail;
-  u64* table;               // HBM table (bool_replay_kernel layout) for the optional write-back
-  u32 writeback;
-};
-
 __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, const BoolLdsArgs& args, u32 col,
                                          u32 valid_mask) {
   u32 r;

@@ -10,25 +10,9 @@
 //
 // Requirements: p odd, p < 2^(32*N), N <= 12 (384 bits).  p = 2 is handled by the Boolean path.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "args.hpp"
 
 namespace zkgpu {
-
-typedef uint32_t u32;
-typedef uint64_t u64;
-
-constexpr int kMaxWords = 12;  // fields up to 384 bits
-
-// Per-field constants, passed by value in the kernarg segment (wave-uniform:
-// the compiler keeps them in SGPRs).
-struct FieldParams {
-  u32 p[kMaxWords];    // modulus, little-endian 32-bit words
-  u32 r2[kMaxWords];   // R^2 mod p   (to_mont multiplier)
-  u32 one[kMaxWords];  // R mod p     (Montgomery form of 1)
-  u32 n0inv;           // -p^{-1} mod 2^32
-  u32 nwords;          // N actually used (2, 4, ..., 12)
-};
 
 template <int N>
 struct Fp {

@@ -10,28 +10,6 @@
 
 namespace zkgpu {
 
-struct R1csRow {
-  u32 first;
-  u32 counts;  // nA | nB << 8 | nC << 16 | flags << 24
-};
-struct R1csTerm {
-  u32 slot;  // 0xFFFFFFFF: the constant one
-  u32 coef;  // 0xFFFFFFFF: coefficient 1
-};
-constexpr u32 kR1csBIsOne = 1u;
-
-struct R1csArgs {
-  const R1csRow* rows;
-  const R1csTerm* terms;
-  const u32* coefs;      // Montgomery form, N words each
-  u32 first_row, n_rows; // rows [first_row, first_row + n_rows) of this launch
-  const uint4* table;    // read side
-  uint4* table_out;      // ASSIGN: same table
-  u32 n_slots;
-  u32 batch;
-  u32* first_fail;       // CHECK: min failing row per lane
-};
-
 template <int N>
 __device__ __forceinline__ Fp<N> r1cs_term_value(const R1csTerm term, const uint4* __restrict__ T,
                                                  const FieldParams& fp) {

@@ -14,30 +14,6 @@
 
 namespace zkgpu {
 
-enum OpKind : u32 {
-  OP_NOP = 0,
-  OP_ADD = 1,       // dst = a + b
-  OP_MUL = 2,       // dst = a * b
-  OP_ADDC = 3,      // dst = a + const[b]
-  OP_MULC = 4,      // dst = a * const[b]
-  OP_COPY = 5,      // dst = a
-  OP_CONST = 6,     // dst = const[a]
-  OP_INSTANCE = 7,  // dst = to_mont(instance[lane][a])
-  OP_WITNESS = 8,   // dst = to_mont(witness[lane][a])
-  OP_ASSERT = 9,    // a must be zero; b = assert sequence number
-  OP_AND = 10,      // and / xor / not: bits for p = 2 (bool_kernels.hpp); integer bit ops then % p for an odd p
-  OP_XOR = 11,
-  OP_NOT = 12,
-  OP_NZ = 13,  // 1 if the operand is non-zero else 0: x^(p-1) over a prime field (scheduler-made, schedule.cpp)
-};
-
-struct TapeOp {
-  u32 dst;
-  u32 a;
-  u32 b;
-  u32 kind;
-};
-
 // wave-uniform program entry on the scalar path (see load_entry_scalar below for the why)
 __device__ __forceinline__ TapeOp load_op_scalar(const TapeOp* ops, u32 i) {
   typedef const u32 __attribute__((address_space(4))) cu32;
@@ -49,27 +25,6 @@ __device__ __forceinline__ TapeOp load_op_scalar(const TapeOp* ops, u32 i) {
   op.kind = q[3];
   return op;
 }
-
-constexpr u32 kNoFail = 0xFFFFFFFFu;
-constexpr u32 kLaneFlagNonCanonical = 1u;
-
-struct ReplayArgs {
-  const TapeOp* ops;      // ops of this launch (device)
-  u32 n_ops;
-  u32 ops_per_wave;       // contiguous ops walked by one wave
-  uint4* table;           // wire table
-  u32 n_slots;            // slots per lane block
-  u32 batch;              // real lanes
-  u32 lb_base;            // first lane block of this launch (lane groups)
-  const u32* consts;      // constant pool, Montgomery form, N words each
-  const uint8_t* inst;    // [lane][n_inst][4N bytes] little-endian, canonical
-  const uint8_t* wit;     // [lane][n_wit][4N bytes]
-  u32 n_inst;
-  u32 n_wit;
-  u32* first_fail;        // [lane] min assert sequence number that failed
-  u32* lane_flags;        // [lane] sticky flags (non-canonical input ...)
-  u32 xcd_chunks;         // != 0: XCD-aware 1-D grid, see block_coords()
-};
 
 // Workgroup -> (chunk of ops, lane block).  Legacy grid: x = chunk, y = lane block; consecutive
 // chunks of one lane block then land on different XCDs (workgroups are dealt round-robin over the 8
@@ -149,7 +104,10 @@ __device__ __forceinline__ Fp<N> input_load(const uint8_t* __restrict__ base, u3
 // One wave = 64 witnesses x `ops_per_wave` consecutive tape ops.
 // PIPE: operands of op i+1 are requested before op i is computed; legal only
 // when the ops of one wave are mutually independent (a level of the schedule).
-template <int N, bool PIPE>
+// BITOPS: the and / xor arms of PlaintextBackend over an odd field (two from_mont + one to_mont each) are only
+// compiled into the instantiation the host picks for programs that contain them -- they cost the common
+// instantiation 19 VGPRs (83 -> 102) it never uses.
+template <int N, bool PIPE, bool BITOPS = true>
 __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, const FieldParams fp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
@@ -191,8 +149,12 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       case OP_MULC: r = fp_mul<N>(a, fp_load_const<N>(args.consts + (size_t)op.b * N), fp); break;
       case OP_COPY: r = a; break;
       case OP_NZ: r = fp_nonzero_indicator<N>(a, fp); break;
-      case OP_AND: r = fp_bit_and<N>(a, b, fp); break;   // integer bit ops of PlaintextBackend over an odd field
-      case OP_XOR: r = fp_bit_xor<N>(a, b, fp); break;
+      case OP_AND:   // integer bit ops of PlaintextBackend over an odd field
+        if constexpr (BITOPS) r = fp_bit_and<N>(a, b, fp); else has_out = false;
+        break;
+      case OP_XOR:
+        if constexpr (BITOPS) r = fp_bit_xor<N>(a, b, fp); else has_out = false;
+        break;
       case OP_NOT: r = fp_is_zero_indicator<N>(a, fp); break;
       case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a * N); break;
       case OP_INSTANCE:
@@ -235,30 +197,6 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
   }
 }
 
-// 32-byte program entry of the fused schedule (host: DevOp2, schedule.hpp)
-struct TapeOp2 {
-  u32 dst, kind, a0, a1, b0, b1, pad0, pad1;
-};
-
-struct ReplayArgs2 {
-  const TapeOp2* ops;
-  u32 n_ops;
-  u32 ops_per_wave;
-  uint4* table;
-  u32 n_slots;
-  u32 batch;
-  u32 lb_base;
-  const u32* consts;
-  const uint8_t* inst;
-  const uint8_t* wit;
-  u32 n_inst;
-  u32 n_wit;
-  u32* first_fail;
-  u32* lane_flags;
-  u32 xcd_chunks;
-  u32 op_stride;          // 1 or 4, see the kernel
-};
-
 // A program entry is the same for the whole wave: fetch it on the scalar path (s_load through the scalar cache
 // into SGPRs).  Left to itself hipcc reads it with a vector load + six v_readfirstlane, which waits in vmcnt in
 // front of the operand gathers and keeps the entry in VGPRs (80 -> 74 registers, 9.33 -> 9.25 ms on C2).
@@ -281,7 +219,39 @@ __device__ __forceinline__ TapeOp2 load_entry_scalar(const TapeOp2* ops, u32 i) 
 // Replay of the fused schedule: an Add/Mul operand may be `add(a0,a1)` / `mul(a0,a1)` evaluated in
 // registers -- the absorbed producer's value never goes to the wire table (one 32-B store and one
 // 32-B load less per fused pair).  All gathers of an op are issued before the arithmetic.
+//
+// Three instantiations per field width, chosen per launch by the host (the scheduler puts the Add/Mul entries
+// of a level first):
+//   kFusedHot  -- Add/Mul entries only (with fused producers and pair entries): what a wide level of an
+//                 arithmetic relation consists of.  No other arm is compiled in, so the register allocation is
+//                 that of the Add/Mul body alone (<= 80 VGPRs at 8 words: 6 waves per SIMD).
+//   kFusedMisc -- every kind except the integer bit operations over an odd field (inputs, constants, copies,
+//                 AddConstant/MulConstant, AssertZero, the `x != 0` indicator, and Add/Mul for sequential segments).
+//   kFusedAll  -- kFusedMisc + and / xor over an odd field (two from_mont + one to_mont each, evaluator.rs:924-933).
 template <int N>
+__device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restrict__ T, const FieldParams& fp) {
+  constexpr int REC = Layout<N>::kRecord;
+  const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
+  Fp<N> x0 = wire_load<N>(T + (size_t)op.a0 * REC), x1, y0 = wire_load<N>(T + (size_t)op.b0 * REC), y1;
+  if (ea) x1 = wire_load<N>(T + (size_t)op.a1 * REC);
+  if (eb) y1 = wire_load<N>(T + (size_t)op.b1 * REC);
+  if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp) : fp_mul<N>(x0, x1, fp);
+  if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp) : fp_mul<N>(y0, y1, fp);
+  Fp<N> r = kind == OP_ADD ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
+  u32 dst_slot = op.dst;
+  const u32 pair = (op.kind >> 12) & 3;
+  if (pair) {
+    // a second gate of the same level fed by the shared producer X: store the first result, fetch the second
+    // gate's other operand into registers the first no longer needs, and let the common store write it
+    wire_store<N>(T + (size_t)dst_slot * REC, r);
+    y0 = wire_load<N>(T + (size_t)op.pad1 * REC);
+    r = pair == 1 ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
+    dst_slot = op.pad0;
+  }
+  wire_store<N>(T + (size_t)dst_slot * REC, r);
+}
+
+template <int N, int CLS>
 __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 args, const FieldParams fp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
@@ -295,83 +265,55 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
   const u32 begin = stride == 1 ? (chunk * 4 + wave) * args.ops_per_wave : chunk * 4 * args.ops_per_wave + wave;
   if (begin >= args.n_ops) return;
   const u32 end = min(args.n_ops, begin + args.ops_per_wave * stride);
-  const u32 lane_g = lb * 64 + lane;
-  const bool lane_valid = lane_g < args.batch;
   uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
   constexpr int REC = Layout<N>::kRecord;
-  for (u32 i = begin; i < end; i += stride) {
-    const TapeOp2 op = load_entry_scalar(args.ops, i);
-    const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
-    Fp<N> r;
-    bool has_out = true;
-    u32 dst_slot = op.dst;
-    switch (kind) {
-      case OP_ADD:
-      case OP_MUL: {
-        Fp<N> x0 = wire_load<N>(T + (size_t)op.a0 * REC), x1, y0 = wire_load<N>(T + (size_t)op.b0 * REC), y1;
-        if (ea) x1 = wire_load<N>(T + (size_t)op.a1 * REC);
-        if (eb) y1 = wire_load<N>(T + (size_t)op.b1 * REC);
-        if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp) : fp_mul<N>(x0, x1, fp);
-        if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp) : fp_mul<N>(y0, y1, fp);
-        r = kind == OP_ADD ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
-        const u32 pair = (op.kind >> 12) & 3;
-        if (pair) {
-          // a second gate of the same level fed by the shared producer X: store the first result, fetch the second
-          // gate's other operand into registers the first no longer needs, and let the common store write it
-          wire_store<N>(T + (size_t)dst_slot * REC, r);
-          y0 = wire_load<N>(T + (size_t)op.pad1 * REC);
-          r = pair == 1 ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
-          dst_slot = op.pad0;
+  if constexpr (CLS == kFusedHot) {
+    for (u32 i = begin; i < end; i += stride) fused_addmul<N>(load_entry_scalar(args.ops, i), T, fp);
+  } else {
+    const u32 lane_g = lb * 64 + lane;
+    const bool lane_valid = lane_g < args.batch;
+    for (u32 i = begin; i < end; i += stride) {
+      const TapeOp2 op = load_entry_scalar(args.ops, i);
+      const u32 kind = op.kind & 0xFF;
+      Fp<N> r;
+      bool has_out = true;
+      switch (kind) {
+        case OP_ADD:
+        case OP_MUL: fused_addmul<N>(op, T, fp); has_out = false; break;
+        case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+        case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+        case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
+        case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
+        case OP_AND:
+          if constexpr (CLS == kFusedAll) r = fp_bit_and<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
+          else has_out = false;
+          break;
+        case OP_XOR:
+          if constexpr (CLS == kFusedAll) r = fp_bit_xor<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
+          else has_out = false;
+          break;
+        case OP_NOT: r = fp_is_zero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
+        case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
+        case OP_INSTANCE:
+        case OP_WITNESS: {
+          const bool is_inst = kind == OP_INSTANCE;
+          Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0,
+                                    lane_valid);
+          if (fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+          r = fp_to_mont<N>(raw, fp);
+          break;
         }
-        break;
-      }
-      case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
-      case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
-      case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
-      case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
-      case OP_AND: r = fp_bit_and<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp); break;
-      case OP_XOR: r = fp_bit_xor<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp); break;
-      case OP_NOT: r = fp_is_zero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
-      case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
-      case OP_INSTANCE:
-      case OP_WITNESS: {
-        const bool is_inst = kind == OP_INSTANCE;
-        Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0,
-                                  lane_valid);
-        if (fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
-        r = fp_to_mont<N>(raw, fp);
-        break;
-      }
-      case OP_ASSERT: {
-        has_out = false;
-        const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC));
-        if (__ballot(nz && lane_valid) != 0ull) {
-          if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b0);
+        case OP_ASSERT: {
+          has_out = false;
+          const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC));
+          if (__ballot(nz && lane_valid) != 0ull) {
+            if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b0);
+          }
+          break;
         }
-        break;
+        default: has_out = false; break;
       }
-      default: has_out = false; break;
-    }
-    if (has_out) wire_store<N>(T + (size_t)dst_slot * REC, r);
-  }
-}
-
-// Final verdict reduction: satisfied = lanes with no failing assert and no flag.
-// counts[0] += satisfied, counts[1] += failed (u64 each), one atomic per wave.
-__global__ __launch_bounds__(256) void verdict_kernel(const u32* __restrict__ first_fail,
-                                                       const u32* __restrict__ lane_flags, u32 batch,
-                                                       unsigned long long* __restrict__ counts) {
-  const u32 lane_g = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = lane_g < batch;
-  const bool ok = valid && first_fail[lane_g] == kNoFail && lane_flags[lane_g] == 0;
-  const unsigned long long okm = __ballot(ok);
-  const unsigned long long vm = __ballot(valid);
-  if ((threadIdx.x & 63) == 0) {
-    const unsigned long long n_ok = __popcll(okm);
-    const unsigned long long n_v = __popcll(vm);
-    if (n_v) {
-      atomicAdd(&counts[0], n_ok);
-      atomicAdd(&counts[1], n_v - n_ok);
+      if (has_out) wire_store<N>(T + (size_t)op.dst * REC, r);
     }
   }
 }

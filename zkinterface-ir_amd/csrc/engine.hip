@@ -7,9 +7,7 @@
 #include <thread>
 #include <vector>
 
-#include "device/bool_kernels.hpp"
-#include "device/r1cs_kernels.hpp"
-#include "device/replay_kernels.hpp"
+#include "device/args.hpp"
 #include "engine.hpp"
 
 namespace zki {
@@ -36,11 +34,40 @@ void dfree(T*& p) {
   }
 }
 
-// The scheduler always emits ops_per_wave = 1 for a level (measured fastest) and one wave per lane block
-// for sequential segments; neither wants the in-wave operand prefetch variant (PIPE, kept for tools/kbench).
-template <int N>
-void launch_arith(const zkgpu::ReplayArgs& a, const zkgpu::FieldParams& fp, bool, dim3 grid, hipStream_t st) {
-  zkgpu::replay_kernel<N, false><<<grid, 256, 0, st>>>(a, fp);
+// one launcher set per field width (kernels_arith.hip)
+#define ZK_WIDTHS(X) X(2) X(4) X(6) X(8) X(10) X(12)
+void launch_fused(uint32_t nwords, int cls, dim3 grid, hipStream_t st, const zkgpu::ReplayArgs2& a, const zkgpu::FieldParams& fp) {
+  switch (nwords) {
+#define X(W) case W: zkgpu::launch_replay_fused_w##W(cls, grid, st, a, fp); break;
+    ZK_WIDTHS(X)
+#undef X
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
+}
+void launch_plain(uint32_t nwords, bool bitops, dim3 grid, hipStream_t st, const zkgpu::ReplayArgs& a, const zkgpu::FieldParams& fp) {
+  switch (nwords) {
+#define X(W) case W: zkgpu::launch_replay_w##W(bitops, grid, st, a, fp); break;
+    ZK_WIDTHS(X)
+#undef X
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
+}
+void launch_r1cs(uint32_t nwords, bool assign, dim3 grid, hipStream_t st, const zkgpu::R1csArgs& a, const zkgpu::FieldParams& fp) {
+  switch (nwords) {
+#define X(W) case W: zkgpu::launch_r1cs_w##W(assign, grid, st, a, fp); break;
+    ZK_WIDTHS(X)
+#undef X
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
+}
+void launch_dump(uint32_t nwords, dim3 grid, hipStream_t st, const uint4* table, uint32_t n_slots, const uint32_t* slots,
+                 uint32_t n_dump, uint32_t batch, uint32_t* out, const zkgpu::FieldParams& fp) {
+  switch (nwords) {
+#define X(W) case W: zkgpu::launch_dump_w##W(grid, st, table, n_slots, slots, n_dump, batch, out, fp); break;
+    ZK_WIDTHS(X)
+#undef X
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
 }
 
 }  // namespace
@@ -293,8 +320,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
       if (!lo.empty()) HIP_OK(hipMemcpy(d_lds_ops_, lo.data(), lo.size() * sizeof(zkgpu::LdsOp), hipMemcpyHostToDevice));
       HIP_OK(hipMalloc(&d_launches_, std::max<size_t>(ln.size() * 4, 64)));
       if (!ln.empty()) HIP_OK(hipMemcpy(d_launches_, ln.data(), ln.size() * 4, hipMemcpyHostToDevice));
-      HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void*>(&zkgpu::bool_lds_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+      HIP_OK(zkgpu::bool_lds_set_max_shared((int)kLdsBytes));
       lds_path_ = true;
     } else if (bool_path_ == 2) {
       throw std::runtime_error("Engine: the relation keeps " + std::to_string(s.n_slots) +
@@ -462,7 +488,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.packed_inst = (const zkgpu::u64*)d_packed_inst_;
     a.packed_wit = (const zkgpu::u64*)d_packed_wit_;
     a.first_fail = (zkgpu::u32*)d_first_fail_;
-    zkgpu::bool_replay_kernel<<<grid, 256, 0, st>>>(a);
+    zkgpu::launch_bool_replay(grid, st, a);
     return;
   }
   if (sched_.fused) {
@@ -482,17 +508,27 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.n_wit = n_wit_;
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.lane_flags = (zkgpu::u32*)d_flags_;
-    a.xcd_chunks = xcd_chunks;
-    a.op_stride = (L.sequential || opw == 1) ? 1 : 4;
-    switch (nwords_) {
-      case 2: zkgpu::replay_fused_kernel<2><<<grid, 256, 0, st>>>(a, fp); break;
-      case 4: zkgpu::replay_fused_kernel<4><<<grid, 256, 0, st>>>(a, fp); break;
-      case 6: zkgpu::replay_fused_kernel<6><<<grid, 256, 0, st>>>(a, fp); break;
-      case 8: zkgpu::replay_fused_kernel<8><<<grid, 256, 0, st>>>(a, fp); break;
-      case 10: zkgpu::replay_fused_kernel<10><<<grid, 256, 0, st>>>(a, fp); break;
-      case 12: zkgpu::replay_fused_kernel<12><<<grid, 256, 0, st>>>(a, fp); break;
-      default: throw std::runtime_error("Engine: unsupported limb count");
+    if (L.sequential) {
+      a.xcd_chunks = 0;
+      a.op_stride = 1;
+      launch_fused(nwords_, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, grid, st, a, fp);
+      return;
     }
+    // a level: its Add/Mul entries (scheduled first) run in the instantiation that holds nothing else; the
+    // remaining kinds, if any, in a second launch of the general one.  Both read only earlier levels.
+    auto part = [&](uint32_t first, uint32_t count, int cls, bool wide) {
+      if (!count) return;
+      const uint32_t w = (wide && count >= 1024 * level_ops_per_wave_) ? level_ops_per_wave_ : 1;
+      const uint32_t nchunks = ((count + w - 1) / w + 3) / 4;
+      a.ops = (const zkgpu::TapeOp2*)d_ops_ + L.first + first;
+      a.n_ops = count;
+      a.ops_per_wave = w;
+      a.op_stride = w == 1 ? 1 : 4;
+      a.xcd_chunks = (xcd_map_ && lbs % 8 == 0 && nchunks >= 8) ? nchunks : 0;
+      launch_fused(nwords_, cls, a.xcd_chunks ? dim3(nchunks * lbs) : dim3(nchunks, lbs), st, a, fp);
+    };
+    part(0, L.hot_count, zkgpu::kFusedHot, true);
+    part(L.hot_count, L.count - L.hot_count, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, false);
     return;
   }
   zkgpu::ReplayArgs a;
@@ -512,15 +548,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   a.first_fail = (zkgpu::u32*)d_first_fail_;
   a.lane_flags = (zkgpu::u32*)d_flags_;
   a.xcd_chunks = xcd_chunks;
-  switch (nwords_) {
-    case 2: launch_arith<2>(a, fp, L.sequential, grid, st); break;
-    case 4: launch_arith<4>(a, fp, L.sequential, grid, st); break;
-    case 6: launch_arith<6>(a, fp, L.sequential, grid, st); break;
-    case 8: launch_arith<8>(a, fp, L.sequential, grid, st); break;
-    case 10: launch_arith<10>(a, fp, L.sequential, grid, st); break;
-    case 12: launch_arith<12>(a, fp, L.sequential, grid, st); break;
-    default: throw std::runtime_error("Engine: unsupported limb count");
-  }
+  launch_plain(nwords_, sched_.has_bitops, grid, st, a, fp);
 }
 
 void Engine::launch_range(uint32_t lb0, uint32_t lbs, bool time_each) {
@@ -639,11 +667,11 @@ void Engine::enqueue_replay(bool time_each_launch) {
   if (boolean_) {
     const uint32_t words = lane_blocks_ * 64;
     if (n_inst_)
-      zkgpu::pack_inputs_kernel<<<dim3((words + 3) / 4, (n_inst_ + 255) / 256), 256, 0, st>>>(
-          (const uint8_t*)d_inst_, n_inst_, batch_, words, (zkgpu::u64*)d_packed_inst_, (zkgpu::u32*)d_flags_);
+      zkgpu::launch_pack_inputs(dim3((words + 3) / 4, (n_inst_ + 255) / 256), st, (const uint8_t*)d_inst_, n_inst_, batch_,
+                                words, (zkgpu::u64*)d_packed_inst_, (zkgpu::u32*)d_flags_);
     if (n_wit_)
-      zkgpu::pack_inputs_kernel<<<dim3((words + 3) / 4, (n_wit_ + 255) / 256), 256, 0, st>>>(
-          (const uint8_t*)d_wit_, n_wit_, batch_, words, (zkgpu::u64*)d_packed_wit_, (zkgpu::u32*)d_flags_);
+      zkgpu::launch_pack_inputs(dim3((words + 3) / 4, (n_wit_ + 255) / 256), st, (const uint8_t*)d_wit_, n_wit_, batch_,
+                                words, (zkgpu::u64*)d_packed_wit_, (zkgpu::u32*)d_flags_);
   }
   if (lds_path_) {
     zkgpu::BoolLdsArgs a;
@@ -662,7 +690,7 @@ void Engine::enqueue_replay(bool time_each_launch) {
     a.table = (zkgpu::u64*)d_table_;
     a.writeback = (lds_writeback_ || force_writeback_) ? 1 : 0;
     const size_t lds_bytes = (((size_t)sched_.n_slots + 1) * 4 + 15) / 16 * 16;
-    zkgpu::bool_lds_kernel<<<a.n_cols, 1024, lds_bytes, st>>>(a);
+    zkgpu::launch_bool_lds(a.n_cols, lds_bytes, st, a);
   }
   uint32_t group_blocks = lane_blocks_;
   if (lane_group_) {
@@ -679,9 +707,8 @@ void Engine::enqueue_replay(bool time_each_launch) {
   if (time_each_launch) group_blocks = lane_blocks_;  // per-launch events describe whole-batch launches
   for (uint32_t lb0 = 0; lb0 < lane_blocks_ && !lds_path_; lb0 += group_blocks)
     launch_range(lb0, std::min(group_blocks, lane_blocks_ - lb0), time_each_launch);
-  zkgpu::verdict_kernel<<<(batch_ + 255) / 256, 256, 0, st>>>((const zkgpu::u32*)d_first_fail_,
-                                                              (const zkgpu::u32*)d_flags_, batch_,
-                                                              (unsigned long long*)d_counts_);
+  zkgpu::launch_verdict(dim3((batch_ + 255) / 256), st, (const zkgpu::u32*)d_first_fail_, (const zkgpu::u32*)d_flags_, batch_,
+                        (unsigned long long*)d_counts_);
 }
 
 void Engine::reserve_extra_slots(uint32_t n) {
@@ -753,24 +780,14 @@ void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
   a.batch = batch_;
   a.first_fail = (zkgpu::u32*)d_r1cs_fail_;
   const dim3 grid((n_rows + 3) / 4, lane_blocks_);
-#define ZK_R1CS(N)                                                                     \
-  case N:                                                                              \
-    if (assign) zkgpu::r1cs_row_kernel<N, true><<<grid, 256, 0, st>>>(a, fp);          \
-    else zkgpu::r1cs_row_kernel<N, false><<<grid, 256, 0, st>>>(a, fp);                \
-    break;
-  switch (nwords_) {
-    ZK_R1CS(2) ZK_R1CS(4) ZK_R1CS(6) ZK_R1CS(8) ZK_R1CS(10) ZK_R1CS(12)
-    default: throw std::runtime_error("Engine: unsupported limb count");
-  }
-#undef ZK_R1CS
+  launch_r1cs(nwords_, assign, grid, st, a, fp);
   HIP_OK(hipGetLastError());
 }
 
 void Engine::r1cs_finish_check() {
   hipStream_t st = (hipStream_t)stream_;
-  zkgpu::verdict_kernel<<<(batch_ + 255) / 256, 256, 0, st>>>((const zkgpu::u32*)d_r1cs_fail_,
-                                                              (const zkgpu::u32*)d_flags_, batch_,
-                                                              (unsigned long long*)d_r1cs_counts_);
+  zkgpu::launch_verdict(dim3((batch_ + 255) / 256), st, (const zkgpu::u32*)d_r1cs_fail_, (const zkgpu::u32*)d_flags_, batch_,
+                        (unsigned long long*)d_r1cs_counts_);
   HIP_OK(hipEventRecord((hipEvent_t)ev_r1cs_end_, st));
   HIP_OK(hipGetLastError());
 }
@@ -821,19 +838,9 @@ void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>
   const uint32_t lb64 = (batch_ + 63) / 64;
   // grid.x is limited to 2^31-1, grid.y to 65535: chunk the slot list
   if (boolean_) {
-    zkgpu::bool_dump_slots_kernel<<<dim3(k, lb64), 64, 0, st>>>((const zkgpu::u64*)d_table_, sched_.n_slots, d_slots,
-                                                                k, batch_, (uint8_t*)d_out);
+    zkgpu::launch_bool_dump(dim3(k, lb64), st, (const zkgpu::u64*)d_table_, sched_.n_slots, d_slots, k, batch_, (uint8_t*)d_out);
   } else {
-    const uint4* T = (const uint4*)d_table_;
-    switch (nwords_) {
-      case 2: zkgpu::dump_slots_kernel<2><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 4: zkgpu::dump_slots_kernel<4><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 6: zkgpu::dump_slots_kernel<6><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 8: zkgpu::dump_slots_kernel<8><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 10: zkgpu::dump_slots_kernel<10><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      case 12: zkgpu::dump_slots_kernel<12><<<dim3(k, lb64), 64, 0, st>>>(T, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp); break;
-      default: break;
-    }
+    launch_dump(nwords_, dim3(k, lb64), st, (const uint4*)d_table_, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp);
   }
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(st));

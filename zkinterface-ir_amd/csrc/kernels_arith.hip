@@ -1,0 +1,39 @@
+// GF(p) kernels for ONE field width: compiled once per width with -DZKGPU_W=<32-bit words> (2, 4, ..., 12), so
+// the six widths build in parallel and the engine's host code instantiates no kernel.  Defines the launchers
+// declared in device/args.hpp.
+#include "device/r1cs_kernels.hpp"
+#include "device/replay_kernels.hpp"
+
+#ifndef ZKGPU_W
+#error "compile with -DZKGPU_W=<words per field element>"
+#endif
+#define ZKGPU_CAT2(a, b) a##b
+#define ZKGPU_CAT(a, b) ZKGPU_CAT2(a, b)
+#define ZKGPU_FN(name) ZKGPU_CAT(name, ZKGPU_W)
+
+namespace zkgpu {
+
+void ZKGPU_FN(launch_replay_fused_w)(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const FieldParams& fp) {
+  if (cls == kFusedHot) replay_fused_kernel<ZKGPU_W, kFusedHot><<<grid, 256, 0, st>>>(a, fp);
+  else if (cls == kFusedMisc) replay_fused_kernel<ZKGPU_W, kFusedMisc><<<grid, 256, 0, st>>>(a, fp);
+  else replay_fused_kernel<ZKGPU_W, kFusedAll><<<grid, 256, 0, st>>>(a, fp);
+}
+
+// The scheduler always emits ops_per_wave = 1 for a level (measured fastest) and one wave per lane block
+// for sequential segments; neither wants the in-wave operand prefetch variant (PIPE, kept for tools/kbench).
+void ZKGPU_FN(launch_replay_w)(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp) {
+  if (bitops) replay_kernel<ZKGPU_W, false, true><<<grid, 256, 0, st>>>(a, fp);
+  else replay_kernel<ZKGPU_W, false, false><<<grid, 256, 0, st>>>(a, fp);
+}
+
+void ZKGPU_FN(launch_r1cs_w)(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp) {
+  if (assign) r1cs_row_kernel<ZKGPU_W, true><<<grid, 256, 0, st>>>(a, fp);
+  else r1cs_row_kernel<ZKGPU_W, false><<<grid, 256, 0, st>>>(a, fp);
+}
+
+void ZKGPU_FN(launch_dump_w)(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,
+                             u32 batch, u32* out, const FieldParams& fp) {
+  dump_slots_kernel<ZKGPU_W><<<grid, 64, 0, st>>>(table, n_slots, slots, n_dump, batch, out, fp);
+}
+
+}  // namespace zkgpu

@@ -95,16 +95,48 @@ bool rewrite_ladders(const Tape& in, const FieldHost& field, Tape* out, uint64_t
     for (int b = 0; b < 4; ++b) p_le.push_back((uint8_t)(field.p[i] >> (8 * b)));
   if (!is_probably_prime(p_le)) return false;
   const size_t n = in.size();
+  // bits of the exponent p - 1 (p is odd: clear bit 0)
+  uint32_t e[kFieldWords];
+  for (int i = 0; i < kFieldWords; ++i) e[i] = i < (int)field.nwords ? field.p[i] : 0;
+  e[0] &= ~1u;
+  int top_bit = -1;
+  for (int i = 32 * kFieldWords - 1; i >= 0 && top_bit < 0; --i)
+    if ((e[i / 32] >> (i % 32)) & 1) top_bit = i;
+  if (top_bit < 0) return false;
+  // A hint is only a hint (zkgpu_backend_ladder is a public entry): the range must BE the reference's
+  // square-and-multiply recursion over p - 1 (evaluator.rs:801-820) -- copy(base), then from the second highest bit
+  // down a squaring of the running value and, where the bit is set, a multiply by the base -- or it stays as recorded.
+  auto is_ladder = [&](const Tape::Ladder& L) {
+    if (L.result >= n || L.first > L.result || L.base >= L.first) return false;
+    uint32_t cur = L.first;
+    if (in.kind[cur] != TK_COPY || in.a[cur] != L.base) return false;
+    for (int shift = top_bit - 1; shift >= 0; --shift) {
+      if (++cur > L.result || in.kind[cur] != TK_MUL || in.a[cur] != cur - 1 || in.b[cur] != cur - 1) return false;
+      if ((e[shift / 32] >> (shift % 32)) & 1) {
+        if (++cur > L.result || in.kind[cur] != TK_MUL) return false;
+        const bool ab = in.a[cur] == cur - 1 && in.b[cur] == L.base, ba = in.a[cur] == L.base && in.b[cur] == cur - 1;
+        if (!ab && !ba) return false;
+      }
+    }
+    return cur == L.result;
+  };
   std::vector<uint32_t> owner(n, kInf);  // ladder whose intermediate this op is
   std::vector<uint8_t> ok(in.ladders.size(), 1);
   for (size_t l = 0; l < in.ladders.size(); ++l) {
     const Tape::Ladder& L = in.ladders[l];
-    if (L.result >= n || L.first > L.result || L.base >= L.first) { ok[l] = 0; continue; }
-    for (uint32_t i = L.first; i < L.result; ++i) {
-      if (owner[i] != kInf || in.kind[i] == TK_ASSERT) ok[l] = 0;
-      owner[i] = (uint32_t)l;
+    if (!is_ladder(L)) { ok[l] = 0; continue; }
+    for (uint32_t i = L.first; i <= L.result; ++i) {
+      if (owner[i] != kInf) {  // two hints over one op: neither is trusted, the first keeps the op
+        ok[l] = 0;
+        ok[owner[i]] = 0;
+      } else {
+        owner[i] = (uint32_t)l;
+      }
     }
   }
+  // the result is the one value others may read
+  for (size_t l = 0; l < in.ladders.size(); ++l)
+    if (in.ladders[l].result < n && owner[in.ladders[l].result] == l) owner[in.ladders[l].result] = kInf;
   for (size_t j = 0; j < n; ++j) {
     const int ni = n_inputs(in.kind[j]);
     for (int k = 0; k < ni; ++k) {
@@ -401,9 +433,17 @@ void ScheduleBuilder::assign_slots() {
         k = e;
       }
     }
-    if (opt.sort_by_operand >= 2 && !s.boolean_path && level_start[l + 1] - level_start[l] > 8)
-      locality_order(order.data() + level_start[l], level_start[l + 1] - level_start[l],
-                     [&](uint32_t i, uint32_t* out) { return gathered(i, out); });
+    if (opt.sort_by_operand >= 2 && !s.boolean_path) {
+      // the Add/Mul entries of a level come first (counting sort by kind) and run in a kernel instantiation of
+      // their own (engine.hip launch_one): the shared-operand walk orders the two parts separately
+      uint64_t mid = level_start[l];
+      while (mid < level_start[l + 1] && (tape.kind[order[mid]] == TK_ADD || tape.kind[order[mid]] == TK_MUL)) ++mid;
+      const uint64_t cut[3] = {level_start[l], mid, level_start[l + 1]};
+      for (int part = 0; part < 2; ++part)
+        if (cut[part + 1] - cut[part] > 8)
+          locality_order(order.data() + cut[part], cut[part + 1] - cut[part],
+                         [&](uint32_t i, uint32_t* out) { return gathered(i, out); });
+    }
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
       const uint32_t i = order[k];
       if (tape.kind[i] == TK_ASSERT || tape.kind[i] == TK_NOP) continue;
@@ -552,6 +592,12 @@ void ScheduleBuilder::emit_launches() {
       L.level_end = e;
       l = e;
     }
+    for (uint64_t k = L.first; k < (uint64_t)L.first + L.count; ++k) {
+      const uint8_t kind = tape.kind[order[k]];
+      if (!L.sequential && k == (uint64_t)L.first + L.hot_count && (kind == TK_ADD || kind == TK_MUL)) ++L.hot_count;
+      if (!s.boolean_path && (kind == TK_AND || kind == TK_XOR)) L.has_bitops = true;
+    }
+    s.has_bitops = s.has_bitops || L.has_bitops;
     if (L.count) s.launches.push_back(L);
   }
 }

@@ -32,6 +32,8 @@ struct Launch {
   uint32_t ops_per_wave = 1;  // count => one wave walks the whole launch in order
   bool sequential = false;    // ops depend on each other: no operand prefetch
   uint32_t level_begin = 0, level_end = 0;
+  uint32_t hot_count = 0;     // a level of the fused program: its first hot_count entries are the Add/Mul ones
+  bool has_bitops = false;    // holds and / xor over an odd field (the kernels' cold instantiation)
 };
 
 struct ScheduleOptions {
@@ -61,6 +63,7 @@ struct Schedule {
   uint32_t max_level_width = 0;
   bool retain_all = false;
   bool boolean_path = false;        // p == 2: bit-packed wires
+  bool has_bitops = false;          // some entry is and / xor over an odd field
   // constant pool in device form: arithmetic = Montgomery words (nwords each);
   // boolean = one u32 (0/1) per constant
   std::vector<uint32_t> const_words;

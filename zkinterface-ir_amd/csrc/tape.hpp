@@ -92,7 +92,9 @@ class TapeBackend {
   void note_assert_wire(WireId local_id) { pending_assert_wire_ = local_id; }
   size_t note_ladder_begin() const { return tape_.size(); }
   void note_ladder_end(size_t first, const Wire& base, const Wire& result) {
-    if (result >= first && base < first) tape_.ladders.push_back({(uint32_t)first, result, base});
+    // with is_boolean the "multiplies" of the ladder are `and` gates and Fermat says nothing about them
+    // (evaluator.rs:86-93): no hint is kept
+    if (!is_boolean_ && result >= first && base < first) tape_.ladders.push_back({(uint32_t)first, result, base});
   }
   Wire add(const Wire& x, const Wire& y) { return arith(TK_ADD, x, y); }
   Wire multiply(const Wire& x, const Wire& y) { return arith(TK_MUL, x, y); }
