@@ -96,6 +96,8 @@ def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, stream
     ev.set_option('fuse', os.environ.get('ZKI_FUSE', '1'))
     if os.environ.get('ZKI_OPW'):
         ev.set_option('level_ops_per_wave', os.environ['ZKI_OPW'])
+    if os.environ.get('ZKI_HOT_WAVES'):
+        ev.set_option('hot_waves', os.environ['ZKI_HOT_WAVES'])
     if os.environ.get('ZKI_GRAPH'):
         ev.set_option('graph', os.environ['ZKI_GRAPH'])
     if os.environ.get('ZKI_XCD_MAP'):

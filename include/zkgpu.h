@@ -131,7 +131,9 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * default 0: measured slower on ROCm 7.2),
  * "xcd_map" = 0|1 (launches over a multiple of 8 lane blocks give each XCD its own lane blocks; default 1),
  * "level_ops_per_wave" = 1..8 (program entries of a wide level walked by one wave, interleaved over the 4 waves
- * of a workgroup; default 2),
+ * of a workgroup; default 1: with the Add/Mul kernel at 60 VGPRs = 8 waves per SIMD one entry per wave measured fastest),
+ * "hot_waves" = 0 | 3..7 (cap on the resident waves per SIMD of the Add/Mul kernel, by an unused LDS allocation;
+ * 0 = no cap, the default -- a tuning handle, every cap measured slower on C2),
  * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),
  * "fermat" = 0|1 (the exponent ladder x^(p-1) of a Switch weight becomes one `x != 0` entry when the characteristic
  * passes the primality test; never with retain_all; default 1),
@@ -203,7 +205,8 @@ int zkgpu_r1cs_info(const zkgpu_session* s, uint64_t out[4]);
 int zkgpu_r1cs_export(const zkgpu_session* s, uint32_t* row_ptr, uint64_t* term_var, uint32_t* term_coef,
                       uint64_t* var_of_op);
 size_t zkgpu_r1cs_coef_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap);
-/* A caller-supplied constraint system in CSR form over the session's wire table (retain_all): a term's
+/* A caller-supplied constraint system in CSR form over the session's wire table (retain_all); the term arrays hold
+ * row_ptr[3 * n_rows] entries, row_ptr starts at 0 and never decreases, term_coef[i] < n_coefs (all checked).  A term's
  * variable is the index of a value-returning backend call (k < zkgpu_tape_value_ops), an extra variable
  * (k - value_ops < n_extra_vars, stored behind the program's slots) or 0xFFFF...F for the constant one;
  * term_coef indexes coef_bytes (n_coefs little-endian strings of coef_width bytes). */
@@ -211,13 +214,17 @@ int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_p
                         const uint32_t* term_coef, const uint8_t* coef_bytes, uint32_t coef_width, uint32_t n_coefs,
                         uint32_t n_extra_vars);
 /* rows [first_row, first_row+n_rows): write <a,w>*<b,w> into the single variable of C (witness generation
- * of product rows; the rows of one call must not depend on each other) */
+ * of product rows).  Checked on the host before anything is launched: every row's C is exactly one variable with
+ * coefficient 1, no two rows assign the same variable, and no row reads a variable a row of the same call assigns
+ * (split the rows by dependency level) -- anything else is an error, never a store to the wrong place. */
 int zkgpu_r1cs_assign(zkgpu_session* s, uint32_t first_row, uint32_t n_rows);
 int zkgpu_r1cs_check(zkgpu_session* s);                       /* asynchronous: all rows, all lanes */
 /* first_fail_row[lane] = smallest violated row or ZKGPU_NO_FAIL; counts = {lanes satisfying all rows, others} */
 int zkgpu_r1cs_results(zkgpu_session* s, uint32_t* first_fail_row, uint64_t counts[2]);
 /* value of a variable of a loaded CSR for every lane: out[lane][elem_bytes] */
 int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out);
+/* the same for n_vars variables at once: out[lane][k][elem_bytes] */
+int zkgpu_r1cs_get_vars(zkgpu_session* s, const uint64_t* vars, uint32_t n_vars, uint8_t* out);
 float zkgpu_r1cs_last_ms(const zkgpu_session* s);             /* HIP-event time of the last check */
 
 #ifdef __cplusplus

@@ -39,8 +39,8 @@ def test_bench_launches_two_ranks_itself_and_reduces_the_counts():
 
 @pytest.mark.gpu
 def test_three_ranks_uneven_corruption_boolean_and_r1cs():
-    r = run_bench('--gpus', 3, '--workload', 'c4', '--steps', 1, '--warmup', 1, '--batch-per-gpu', 128, '--width', 256,
-                  '--depth', 6, '--no-cpu-baseline')
+    r = run_bench('--gpus', 3, '--workload', 'c4', '--steps', 1, '--warmup', 1, '--batch-per-gpu', 128, '--width', 2048,
+                  '--depth', 4, '--no-cpu-baseline')
     assert r['n_gpus'] == 3
     assert r['config']['satisfied'] == workloads.expected_satisfied(384) == 380   # 0, 97 | 194 | 291
     r = run_bench('--gpus', 2, '--workload', 'c5', '--steps', 1, '--warmup', 1, '--batch-per-gpu', 128, '--width', 2048,

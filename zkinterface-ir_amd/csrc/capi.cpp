@@ -37,7 +37,8 @@ struct zkgpu_session {
   uint32_t n_streams = 2;
   bool xcd_map = true;
   int graph_mode = 0;
-  uint32_t level_ops_per_wave = 2;
+  uint32_t level_ops_per_wave = 1;
+  uint32_t hot_waves = 0;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
   bool r1cs_ready = false, r1cs_on_device = false, r1cs_loaded_csr = false;
@@ -91,6 +92,7 @@ void need_engine(zkgpu_session* s) {
     e->set_xcd_map(s->xcd_map);
     e->set_graph_mode(s->graph_mode);
     e->set_level_ops_per_wave(s->level_ops_per_wave);
+    e->set_hot_waves(s->hot_waves);
     if (s->r1cs_extra_vars) e->reserve_extra_slots(s->r1cs_extra_vars);
     s->engine = std::move(e);
   }
@@ -538,6 +540,9 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "level_ops_per_wave") {
       s->level_ops_per_wave = (uint32_t)std::max(1, atoi(v.c_str()));
       if (s->engine) s->engine->set_level_ops_per_wave(s->level_ops_per_wave);
+    } else if (k == "hot_waves") {
+      s->hot_waves = (uint32_t)std::max(0, atoi(v.c_str()));
+      if (s->engine) s->engine->set_hot_waves(s->hot_waves);
     } else if (k == "graph") {
       if (v == "0" || v == "1") s->graph_mode = atoi(v.c_str());
       else throw std::runtime_error("graph must be 0 or 1");
@@ -841,20 +846,25 @@ int zkgpu_r1cs_results(zkgpu_session* s, uint32_t* first_fail_row, uint64_t coun
   });
 }
 
-int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out) {
+int zkgpu_r1cs_get_vars(zkgpu_session* s, const uint64_t* vars, uint32_t n_vars, uint8_t* out) {
   return guarded(s, [&] {
     need_engine(s);
-    if (!s->r1cs_ready || !s->r1cs_loaded_csr) throw std::runtime_error("zkgpu_r1cs_get_var needs a CSR loaded with zkgpu_r1cs_load_csr");
+    if (!s->r1cs_ready || !s->r1cs_loaded_csr) throw std::runtime_error("zkgpu_r1cs_get_vars needs a CSR loaded with zkgpu_r1cs_load_csr");
     const uint64_t n_ops = s->value_op_index.size();
-    uint32_t slot;
-    if (var < n_ops) slot = s->sched.slot_of[s->value_op_index[var]];
-    else if (var - n_ops < s->r1cs_extra_vars) slot = s->sched.n_slots + (uint32_t)(var - n_ops);
-    else throw std::runtime_error("variable out of range");
+    std::vector<uint32_t> slots(n_vars);
+    for (uint32_t k = 0; k < n_vars; ++k) {
+      const uint64_t var = vars[k];
+      if (var < n_ops) slots[k] = s->sched.slot_of[s->value_op_index[var]];
+      else if (var - n_ops < s->r1cs_extra_vars) slots[k] = s->sched.n_slots + (uint32_t)(var - n_ops);
+      else throw std::runtime_error("variable out of range");
+    }
     std::vector<uint8_t> tmp;
-    s->engine->dump_slots(std::vector<uint32_t>(1, slot), &tmp);
+    s->engine->dump_slots(slots, &tmp);
     if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
   });
 }
+
+int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out) { return zkgpu_r1cs_get_vars(s, &var, 1, out); }
 
 float zkgpu_r1cs_last_ms(const zkgpu_session* s) { return (s && s->engine) ? s->engine->last_r1cs_ms() : 0.f; }
 

@@ -162,7 +162,8 @@ struct R1csArgs {
 
 // ---- launchers (defined in kernels_arith.hip, one set per field width, and kernels_bool.hip) ----
 #define ZKGPU_DECLARE_WIDTH(W)                                                                                      \
-  void launch_replay_fused_w##W(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const FieldParams& fp);  \
+  void launch_replay_fused_w##W(int cls, dim3 grid, size_t lds_pad, hipStream_t st, const ReplayArgs2& a,         \
+                                const FieldParams& fp);                                                             \
   void launch_replay_w##W(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp);     \
   void launch_r1cs_w##W(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp);         \
   void launch_dump_w##W(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,  \

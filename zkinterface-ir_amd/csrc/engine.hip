@@ -36,9 +36,10 @@ void dfree(T*& p) {
 
 // one launcher set per field width (kernels_arith.hip)
 #define ZK_WIDTHS(X) X(2) X(4) X(6) X(8) X(10) X(12)
-void launch_fused(uint32_t nwords, int cls, dim3 grid, hipStream_t st, const zkgpu::ReplayArgs2& a, const zkgpu::FieldParams& fp) {
+void launch_fused(uint32_t nwords, int cls, dim3 grid, size_t lds_pad, hipStream_t st, const zkgpu::ReplayArgs2& a,
+                  const zkgpu::FieldParams& fp) {
   switch (nwords) {
-#define X(W) case W: zkgpu::launch_replay_fused_w##W(cls, grid, st, a, fp); break;
+#define X(W) case W: zkgpu::launch_replay_fused_w##W(cls, grid, lds_pad, st, a, fp); break;
     ZK_WIDTHS(X)
 #undef X
     default: throw std::runtime_error("Engine: unsupported limb count");
@@ -511,7 +512,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     if (L.sequential) {
       a.xcd_chunks = 0;
       a.op_stride = 1;
-      launch_fused(nwords_, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, grid, st, a, fp);
+      launch_fused(nwords_, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, grid, 0, st, a, fp);
       return;
     }
     // a level: its Add/Mul entries (scheduled first) run in the instantiation that holds nothing else; the
@@ -525,7 +526,9 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
       a.ops_per_wave = w;
       a.op_stride = w == 1 ? 1 : 4;
       a.xcd_chunks = (xcd_map_ && lbs % 8 == 0 && nchunks >= 8) ? nchunks : 0;
-      launch_fused(nwords_, cls, a.xcd_chunks ? dim3(nchunks * lbs) : dim3(nchunks, lbs), st, a, fp);
+      // hot_waves_: cap on resident waves per SIMD for the Add/Mul kernel (a 256-thread workgroup is one wave per SIMD)
+      const size_t pad = (cls == zkgpu::kFusedHot && hot_waves_ >= 3 && hot_waves_ < 8) ? (160 * 1024 / hot_waves_) & ~(size_t)255 : 0;
+      launch_fused(nwords_, cls, a.xcd_chunks ? dim3(nchunks * lbs) : dim3(nchunks, lbs), pad, st, a, fp);
     };
     part(0, L.hot_count, zkgpu::kFusedHot, true);
     part(L.hot_count, L.count - L.hot_count, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, false);

@@ -43,6 +43,7 @@ class Engine {
   // half fill the kernel-boundary bubbles and wave tails of the other.
   void set_xcd_map(bool on) { xcd_map_ = on; graph_dirty_ = true; }
   void set_level_ops_per_wave(uint32_t n) { level_ops_per_wave_ = n < 1 ? 1 : (n > 8 ? 8 : n); graph_dirty_ = true; }
+  void set_hot_waves(uint32_t n) { hot_waves_ = n; graph_dirty_ = true; }  // 0 = whatever the registers allow
   void set_streams(uint32_t n) { n_streams_ = n < 1 ? 1 : (n > kMaxStreams ? kMaxStreams : n); graph_dirty_ = true; }
   static constexpr uint32_t kMaxStreams = 4;
   static constexpr uint64_t kInfinityCacheBudget = 288ull << 20;  // wire-table bytes kept in flight per lane group
@@ -105,7 +106,8 @@ class Engine {
   bool use_graph() const;
   void capture_graph();
   void enqueue_replay(bool time_each_launch);
-  uint32_t level_ops_per_wave_ = 2;
+  uint32_t level_ops_per_wave_ = 1;
+  uint32_t hot_waves_ = 0;
   void* ev_begin_ = nullptr;
   void* ev_end_ = nullptr;
   std::vector<void*> launch_events_;

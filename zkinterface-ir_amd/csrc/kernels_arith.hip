@@ -13,8 +13,11 @@
 
 namespace zkgpu {
 
-void ZKGPU_FN(launch_replay_fused_w)(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const FieldParams& fp) {
-  if (cls == kFusedHot) replay_fused_kernel<ZKGPU_W, kFusedHot><<<grid, 256, 0, st>>>(a, fp);
+// lds_pad: dynamic LDS the kernel never touches -- the engine's handle on how many workgroups (= waves per SIMD) a CU
+// holds at once, since an unused allocation is the only occupancy limit that can be chosen per launch.
+void ZKGPU_FN(launch_replay_fused_w)(int cls, dim3 grid, size_t lds_pad, hipStream_t st, const ReplayArgs2& a,
+                                     const FieldParams& fp) {
+  if (cls == kFusedHot) replay_fused_kernel<ZKGPU_W, kFusedHot><<<grid, 256, lds_pad, st>>>(a, fp);
   else if (cls == kFusedMisc) replay_fused_kernel<ZKGPU_W, kFusedMisc><<<grid, 256, 0, st>>>(a, fp);
   else replay_fused_kernel<ZKGPU_W, kFusedAll><<<grid, 256, 0, st>>>(a, fp);
 }
