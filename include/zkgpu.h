@@ -70,6 +70,12 @@ int zkgpu_backend_witness(zkgpu_session* s, uint32_t position, uint32_t* out);
  * hint the production schedule may evaluate the ladder as one `base != 0` entry when the characteristic is prime
  * (option "fermat"); without it the ladder is replayed product by product.  The bundled Evaluator gives it itself. */
 int zkgpu_backend_ladder(zkgpu_session* s, uint64_t first_call, uint32_t base, uint32_t result);
+/* Optional: the caller let go of `wire` -- no later call will name it.  This is `impl Drop for` the Rust binding's Wire
+ * type: the reference's Evaluator owns its wires (`HashMap<WireId, B::Wire>`, evaluator.rs:158-185) and drops them on
+ * `Free`, at sub-circuit scope exit and at the end of expressions.  The streaming scheduler (option "stream") uses the
+ * drops to recycle wire-table slots and fuse gates before the rest of the relation has arrived; without them every
+ * value stays materialised until zkgpu_finalize.  The bundled Evaluator reports drops itself. */
+int zkgpu_backend_drop(zkgpu_session* s, uint32_t wire);
 
 /* ---- 2. Evaluator / Source entry points ---------------------------------- */
 /* A byte stream of one or more size-prefixed messages (consumers/utils.rs:6-41).

@@ -117,7 +117,8 @@ def test_full_size_c4_against_the_cpu_checker_and_the_oracle_digests(c4_referenc
     assert ev.host_violations() == []
     ev.finalize()
     info = ev.schedule_info()
-    assert ev.n_value_ops == wl.W * (wl.D + 1) + 2 * wl.n_out and ev.n_asserts == wl.n_out
+    # inputs + gates + per output {Instance, Xor, the copy AssertZero makes of its wire (evaluator.rs:340)}
+    assert ev.n_value_ops == wl.W * (wl.D + 1) + 3 * wl.n_out and ev.n_asserts == wl.n_out
     ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
     assert ev.uses_lds_path() == (path == 'lds')
     if path == 'lds':

@@ -62,6 +62,7 @@ def lib():
         'zkgpu_backend_not': (ci, [vp, u32, u32p]),
         'zkgpu_backend_instance': (ci, [vp, u32, u32p]),
         'zkgpu_backend_witness': (ci, [vp, u32, u32p]),
+        'zkgpu_backend_drop': (ci, [vp, u32]),
         'zkgpu_backend_ladder': (ci, [vp, u64, u32, u32]),
         'zkgpu_ingest_messages': (ci, [vp, u8p, sz]),
         'zkgpu_ingest_paths': (ci, [vp, ctypes.POINTER(ctypes.c_char_p), sz]),
@@ -277,6 +278,9 @@ class Evaluator:
     def backend_ladder(self, first_call, base, result):
         """hint: the calls first_call.. computed result = base^(modulus - 1) (include/zkgpu.h)"""
         self._ck(self.L.zkgpu_backend_ladder(self.h, first_call, base, result))
+
+    def backend_drop(self, w):
+        self._ck(self.L.zkgpu_backend_drop(self.h, w))
 
     def backend_witness(self, position):
         return self._wire(self.L.zkgpu_backend_witness, position)

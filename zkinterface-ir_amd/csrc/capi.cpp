@@ -287,52 +287,58 @@ int zkgpu_backend_set_field(zkgpu_session* s, const uint8_t* modulus_le, size_t 
   return guarded(s, [&] { s->backend.set_field(Value(modulus_le, modulus_le + len), degree, is_boolean != 0); });
 }
 int zkgpu_backend_copy(zkgpu_session* s, uint32_t wire, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.copy(wire); });
+  return guarded(s, [&] { *out = s->backend.h_copy(wire); });
 }
 int zkgpu_backend_constant(zkgpu_session* s, const uint8_t* v, size_t len, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.constant(TapeBackend::from_bytes_le(Value(v, v + len))); });
+  return guarded(s, [&] { *out = s->backend.h_constant(TapeBackend::from_bytes_le(Value(v, v + len))); });
 }
 int zkgpu_backend_assert_zero(zkgpu_session* s, uint32_t wire, uint64_t local_wire_id) {
   return guarded(s, [&] {
     s->backend.note_assert_wire(local_wire_id);
-    s->backend.assert_zero(wire);
+    s->backend.h_assert_zero(wire);
   });
 }
 int zkgpu_backend_add(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.add(a, b); });
+  return guarded(s, [&] { *out = s->backend.h_add(a, b); });
 }
 int zkgpu_backend_multiply(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.multiply(a, b); });
+  return guarded(s, [&] { *out = s->backend.h_multiply(a, b); });
 }
 int zkgpu_backend_add_constant(zkgpu_session* s, uint32_t a, const uint8_t* c, size_t len, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.add_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
+  return guarded(s, [&] { *out = s->backend.h_add_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
 }
 int zkgpu_backend_mul_constant(zkgpu_session* s, uint32_t a, const uint8_t* c, size_t len, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.mul_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
+  return guarded(s, [&] { *out = s->backend.h_mul_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
 }
 int zkgpu_backend_and(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.and_(a, b); });
+  return guarded(s, [&] { *out = s->backend.h_and(a, b); });
 }
 int zkgpu_backend_xor(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.xor_(a, b); });
+  return guarded(s, [&] { *out = s->backend.h_xor(a, b); });
 }
 int zkgpu_backend_not(zkgpu_session* s, uint32_t a, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.not_(a); });
+  return guarded(s, [&] { *out = s->backend.h_not(a); });
 }
 int zkgpu_backend_ladder(zkgpu_session* s, uint64_t first_call, uint32_t base, uint32_t result) {
   return guarded(s, [&] {
     if (first_call > s->backend.tape().size() || result >= s->backend.tape().size())
       throw std::runtime_error("zkgpu_backend_ladder: not a range of recorded calls");
-    s->backend.note_ladder_end((size_t)first_call, base, result);
+    s->backend.h_ladder((size_t)first_call, base, result);
+  });
+}
+int zkgpu_backend_drop(zkgpu_session* s, uint32_t wire) {
+  return guarded(s, [&] {
+    if (wire >= s->backend.tape().size()) throw std::runtime_error("zkgpu_backend_drop: not a wire of this session");
+    s->backend.drop_wire(wire);
   });
 }
 int zkgpu_backend_instance(zkgpu_session* s, uint32_t position, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.instance(TapeBackend::instance_ref(position)); });
+  return guarded(s, [&] { *out = s->backend.h_instance(TapeBackend::instance_ref(position)); });
 }
 int zkgpu_backend_witness(zkgpu_session* s, uint32_t position, uint32_t* out) {
   return guarded(s, [&] {
     TapeElement e = TapeBackend::witness_ref(position);
-    *out = s->backend.witness(&e);
+    *out = s->backend.h_witness(&e);
   });
 }
 
@@ -415,7 +421,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     opt.fermat = s->fermat;
     opt.fuse = s->fuse;
     opt.propagate_copies = s->propagate_copies;
-    s->ev.values().for_each([&](WireId, const uint32_t& h) { opt.pinned.push_back(h); });
+    s->ev.values().for_each([&](WireId, const TapeWire& w) { opt.pinned.push_back(w.h); });
     s->n_pinned = opt.pinned.size();
     s->sched = build_schedule(s->backend.tape(), s->backend.field(), opt);
     s->retain_all = opt.retain_all;
@@ -715,11 +721,11 @@ int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, ui
 
 int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out) {
   if (!s) return -1;
-  const uint32_t* h = s->ev.get(wire_id);
-  if (!h) return 3;  // "No value given for wire_{id}"
+  const TapeWire* w = s->ev.get(wire_id);
+  if (!w) return 3;  // "No value given for wire_{id}"
   return guarded(s, [&] {
     need_engine(s);
-    std::vector<uint32_t> slots(1, s->sched.slot_of[*h]);
+    std::vector<uint32_t> slots(1, s->sched.slot_of[w->h]);
     std::vector<uint8_t> tmp;
     s->engine->dump_slots(slots, &tmp);
     if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());

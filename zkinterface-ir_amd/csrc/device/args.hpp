@@ -21,6 +21,9 @@ struct FieldParams {
   u32 one[kMaxWords];  // R mod p     (Montgomery form of 1)
   u32 n0inv;           // -p^{-1} mod 2^32
   u32 nwords;          // N actually used (2, 4, ..., 12)
+  // conditional subtractions that make the lazily reduced sum of K Montgomery products canonical: the sum is below
+  // (K * p / R + 1) * p, so ceil(K * p / R) of them (host: Engine::load_program); index K - 1, K = 1..4
+  u32 dot_rounds[4];
 };
 
 enum OpKind : u32 {
@@ -158,6 +161,7 @@ struct R1csArgs {
   u32 n_slots;
   u32 batch;
   u32* first_fail;       // CHECK: min failing row per lane
+  u32 one_coef;          // index of the Montgomery form of 1 in `coefs` (the host appends it to the pool)
 };
 
 // ---- launchers (defined in kernels_arith.hip, one set per field width, and kernels_bool.hip) ----

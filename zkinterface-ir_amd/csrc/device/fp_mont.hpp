@@ -130,6 +130,14 @@ __device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const Fi
       : "v"(x), "v"(y)                                                                        \
       : "vcc")
 
+// The same with the second factor in an SGPR (a wave-uniform coefficient word, a word of p): VOP3 takes one scalar
+// source, so no VGPR copy of it is needed.
+#define ZKGPU_MADC_S(lo, hi, x, y)                                                            \
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"                \
+      : "+v"(lo), "+v"(hi)                                                                    \
+      : "v"(x), "s"(y)                                                                        \
+      : "vcc")
+
 // Montgomery product a*b*R^{-1} mod p, product-scanning (column by column) form, canonical out.
 // Per column k: acc += sum a[i]*b[k-i] + sum m[i]*p[k-i]; m[k] = acc * n0inv makes the low word 0;
 // the accumulator then shifts down one word.  2*N^2 + N word products, 2 instructions each.
@@ -137,17 +145,15 @@ template <int N>
 __device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
   u64 lo = 0;
   u32 hi = 0;
-  u32 m[N], t[N + 1], pw[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) pw[i] = fp.p[i];
+  u32 m[N], t[N + 1];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
 #pragma unroll
     for (int i = 0; i <= k; ++i) ZKGPU_MADC(lo, hi, a.w[i], b.w[k - i]);
 #pragma unroll
-    for (int i = 0; i < k; ++i) ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+    for (int i = 0; i < k; ++i) ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);   // the words of p stay in SGPRs
     m[k] = (u32)lo * fp.n0inv;
-    ZKGPU_MADC(lo, hi, m[k], pw[0]);
+    ZKGPU_MADC_S(lo, hi, m[k], fp.p[0]);
     lo = (lo >> 32) | ((u64)hi << 32);
     hi = 0;
   }
@@ -156,7 +162,7 @@ __device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const Fi
 #pragma unroll
     for (int i = k - N + 1; i < N; ++i) {
       ZKGPU_MADC(lo, hi, a.w[i], b.w[k - i]);
-      ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+      ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);
     }
     t[k - N] = (u32)lo;
     lo = (lo >> 32) | ((u64)hi << 32);
@@ -179,29 +185,43 @@ __device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const Fi
   return r;
 }
 
+// N wave-uniform words (a coefficient in Montgomery form) read on the scalar path into SGPRs
+template <int N>
+struct FpS {
+  u32 w[N];
+};
+template <int N>
+__device__ __forceinline__ FpS<N> fp_load_uniform(const u32* pool, u32 index) {
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* q = (cu32*)(unsigned long long)(pool + (size_t)__builtin_amdgcn_readfirstlane(index) * N);
+  FpS<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = q[i];
+  return r;
+}
+
 // sum_k v[k]*c[k]*R^{-1} mod p with ONE Montgomery reduction for the whole sum (lazy reduction): the K
 // double-width products are accumulated column by column next to the m*p products of the reduction.
-// K*N^2 + N^2 + N word products instead of K*(2*N^2 + N).  The unreduced result is below
-// K*p*p/R + p < (K+1)*p, hence up to K conditional subtractions.
+// K*N^2 + N^2 + N word products instead of K*(2*N^2 + N).  The coefficients c[k] are wave-uniform and stay in
+// SGPRs, as do the words of p.  The unreduced result is below K*p*p/R + p = (K*p/R + 1)*p: fp.dot_rounds[K-1] =
+// ceil(K*p/R) conditional subtractions make it canonical (one for K = 3 over BN254, where p/R = 0.19).
 template <int N, int K>
-__device__ __forceinline__ Fp<N> fp_dot(const Fp<N> (&v)[K], const Fp<N> (&c)[K], const FieldParams& fp) {
+__device__ __forceinline__ Fp<N> fp_dot(const Fp<N> (&v)[K], const FpS<N> (&c)[K], const FieldParams& fp) {
   static_assert(K >= 1 && K <= 4, "the 32-bit carry word of the accumulator holds 2*K*N carries");
   u64 lo = 0;
   u32 hi = 0;
-  u32 m[N], t[N + 1], pw[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) pw[i] = fp.p[i];
+  u32 m[N], t[N + 1];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
 #pragma unroll
     for (int q = 0; q < K; ++q) {
 #pragma unroll
-      for (int i = 0; i <= k; ++i) ZKGPU_MADC(lo, hi, v[q].w[i], c[q].w[k - i]);
+      for (int i = 0; i <= k; ++i) ZKGPU_MADC_S(lo, hi, v[q].w[i], c[q].w[k - i]);
     }
 #pragma unroll
-    for (int i = 0; i < k; ++i) ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+    for (int i = 0; i < k; ++i) ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);
     m[k] = (u32)lo * fp.n0inv;
-    ZKGPU_MADC(lo, hi, m[k], pw[0]);
+    ZKGPU_MADC_S(lo, hi, m[k], fp.p[0]);
     lo = (lo >> 32) | ((u64)hi << 32);
     hi = 0;
   }
@@ -210,17 +230,17 @@ __device__ __forceinline__ Fp<N> fp_dot(const Fp<N> (&v)[K], const Fp<N> (&c)[K]
 #pragma unroll
     for (int q = 0; q < K; ++q) {
 #pragma unroll
-      for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC(lo, hi, v[q].w[i], c[q].w[k - i]);
+      for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC_S(lo, hi, v[q].w[i], c[q].w[k - i]);
     }
 #pragma unroll
-    for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC(lo, hi, m[i], pw[k - i]);
+    for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);
     t[k - N] = (u32)lo;
     lo = (lo >> 32) | ((u64)hi << 32);
     hi = 0;
   }
   t[N] = (u32)lo;
-#pragma unroll
-  for (int round = 0; round < K; ++round) {
+  const u32 rounds = fp.dot_rounds[K - 1];   // wave-uniform, 1..K
+  for (u32 round = 0; round < rounds; ++round) {
     u32 d[N];
     u64 borrow = 0;
 #pragma unroll

@@ -10,6 +10,16 @@
 
 namespace zkgpu {
 
+// wave-uniform row / term descriptors on the scalar path
+__device__ __forceinline__ R1csTerm r1cs_load_term(const R1csTerm* terms, u32 t) {
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* q = (cu32*)(unsigned long long)(terms + __builtin_amdgcn_readfirstlane(t));
+  R1csTerm e;
+  e.slot = q[0];
+  e.coef = q[1];
+  return e;
+}
+
 template <int N>
 __device__ __forceinline__ Fp<N> r1cs_term_value(const R1csTerm term, const uint4* __restrict__ T,
                                                  const FieldParams& fp) {
@@ -22,51 +32,55 @@ __device__ __forceinline__ Fp<N> r1cs_term_value(const R1csTerm term, const uint
   }
   return v;
 }
-template <int N>
-__device__ __forceinline__ Fp<N> r1cs_term_coef(const R1csArgs& args, const R1csTerm term, const FieldParams& fp) {
-  if (term.coef == 0xFFFFFFFFu) {
-    Fp<N> c;
-#pragma unroll
-    for (int i = 0; i < N; ++i) c.w[i] = fp.one[i];
-    return c;
-  }
-  return fp_load_const<N>(args.coefs + (size_t)term.coef * N);
-}
 
-// A linear combination, three terms at a time: the three gathers are issued together and, when a
-// coefficient other than 1 is present, the three products share one Montgomery reduction (fp_dot).
+// A linear combination, three terms at a time: the three gathers are issued together and, when a coefficient other
+// than 1 is present, the three products share one Montgomery reduction (fp_dot) with the coefficients as scalar
+// operands.  The first chunk IS the accumulator (no add to zero); every chunk value is canonical.
 template <int N>
 __device__ __forceinline__ Fp<N> r1cs_lincomb(const R1csArgs& args, const uint4* __restrict__ T, u32 t0, u32 n,
                                               const FieldParams& fp) {
   Fp<N> acc;
+  if (n == 0) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) acc.w[i] = 0;
-  u32 t = t0;
+    for (int i = 0; i < N; ++i) acc.w[i] = 0;
+    return acc;
+  }
   const u32 end = t0 + n;
-  while (t < end) {
+  for (u32 t = t0; t < end;) {
     const u32 m = min(3u, end - t);
-    const R1csTerm e0 = args.terms[t];
-    const R1csTerm e1 = args.terms[t + (m > 1 ? 1 : 0)];
-    const R1csTerm e2 = args.terms[t + (m > 2 ? 2 : 0)];
+    const R1csTerm e0 = r1cs_load_term(args.terms, t);
+    const R1csTerm e1 = r1cs_load_term(args.terms, t + (m > 1 ? 1 : 0));
+    const R1csTerm e2 = r1cs_load_term(args.terms, t + (m > 2 ? 2 : 0));
     const bool plain = e0.coef == 0xFFFFFFFFu && (m < 2 || e1.coef == 0xFFFFFFFFu) && (m < 3 || e2.coef == 0xFFFFFFFFu);
-    Fp<N> v[3];
-    v[0] = r1cs_term_value<N>(e0, T, fp);
-    if (m > 1) v[1] = r1cs_term_value<N>(e1, T, fp);
-    if (m > 2) v[2] = r1cs_term_value<N>(e2, T, fp);
+    Fp<N> part;
     if (plain) {
-      acc = fp_add<N>(acc, v[0], fp);
-      if (m > 1) acc = fp_add<N>(acc, v[1], fp);
-      if (m > 2) acc = fp_add<N>(acc, v[2], fp);
-    } else if (m == 3) {
-      Fp<N> c[3] = {r1cs_term_coef<N>(args, e0, fp), r1cs_term_coef<N>(args, e1, fp), r1cs_term_coef<N>(args, e2, fp)};
-      acc = fp_add<N>(acc, fp_dot<N, 3>(v, c, fp), fp);
-    } else if (m == 2) {
-      Fp<N> v2[2] = {v[0], v[1]};
-      Fp<N> c2[2] = {r1cs_term_coef<N>(args, e0, fp), r1cs_term_coef<N>(args, e1, fp)};
-      acc = fp_add<N>(acc, fp_dot<N, 2>(v2, c2, fp), fp);
+      part = r1cs_term_value<N>(e0, T, fp);
+      if (m > 1) {
+        const Fp<N> v1 = r1cs_term_value<N>(e1, T, fp);
+        if (m > 2) {
+          const Fp<N> v2 = r1cs_term_value<N>(e2, T, fp);
+          part = fp_add<N>(fp_add<N>(part, v1, fp), v2, fp);
+        } else {
+          part = fp_add<N>(part, v1, fp);
+        }
+      }
     } else {
-      acc = fp_add<N>(acc, fp_mul<N>(v[0], r1cs_term_coef<N>(args, e0, fp), fp), fp);
+      auto coef = [&](const R1csTerm& e) { return fp_load_uniform<N>(args.coefs, e.coef == 0xFFFFFFFFu ? args.one_coef : e.coef); };
+      if (m == 3) {
+        const Fp<N> v[3] = {r1cs_term_value<N>(e0, T, fp), r1cs_term_value<N>(e1, T, fp), r1cs_term_value<N>(e2, T, fp)};
+        const FpS<N> c[3] = {coef(e0), coef(e1), coef(e2)};
+        part = fp_dot<N, 3>(v, c, fp);
+      } else if (m == 2) {
+        const Fp<N> v[2] = {r1cs_term_value<N>(e0, T, fp), r1cs_term_value<N>(e1, T, fp)};
+        const FpS<N> c[2] = {coef(e0), coef(e1)};
+        part = fp_dot<N, 2>(v, c, fp);
+      } else {
+        const Fp<N> v[1] = {r1cs_term_value<N>(e0, T, fp)};
+        const FpS<N> c[1] = {coef(e0)};
+        part = fp_dot<N, 1>(v, c, fp);
+      }
     }
+    acc = t == t0 ? part : fp_add<N>(acc, part, fp);
     t += m;
   }
   return acc;
@@ -82,7 +96,11 @@ __global__ __launch_bounds__(256) void r1cs_row_kernel(const R1csArgs args, cons
   const u32 r = blockIdx.x * (blockDim.x >> 6) + wave;
   if (r >= args.n_rows) return;
   const u32 row = args.first_row + r;
-  const R1csRow d = args.rows[row];
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* dq = (cu32*)(unsigned long long)(args.rows + __builtin_amdgcn_readfirstlane(row));
+  R1csRow d;
+  d.first = dq[0];
+  d.counts = dq[1];
   const u32 na = d.counts & 0xFF, nb = (d.counts >> 8) & 0xFF, nc = (d.counts >> 16) & 0xFF, flags = d.counts >> 24;
   const uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
   Fp<N> prod = r1cs_lincomb<N>(args, T, d.first, na, fp);
@@ -91,7 +109,7 @@ __global__ __launch_bounds__(256) void r1cs_row_kernel(const R1csArgs args, cons
     prod = fp_mul<N>(prod, b, fp);
   }
   if (ASSIGN) {
-    const R1csTerm out = args.terms[d.first + na + nb];
+    const R1csTerm out = r1cs_load_term(args.terms, d.first + na + nb);
     uint4* __restrict__ O = args.table_out + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
     wire_store<N>(O + (size_t)out.slot * Layout<N>::kRecord, prod);
   } else {

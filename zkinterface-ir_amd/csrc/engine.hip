@@ -222,6 +222,16 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   memcpy(fp.one, f.one, sizeof fp.one);
   fp.n0inv = f.n0inv;
   fp.nwords = f.nwords;
+  // lazily reduced sums of K Montgomery products are below (K * p / R + 1) * p: ceil(K * p / R) conditional
+  // subtractions make them canonical.  p / R from the top 64 bits of p, rounded up.
+  if (!f.is_two && f.nwords >= 2) {
+    const long double rho = ((long double)(((uint64_t)f.p[f.nwords - 1] << 32) | f.p[f.nwords - 2]) + 1.0L) / 18446744073709551616.0L;
+    for (int k = 1; k <= 4; ++k) {
+      uint32_t r = (uint32_t)(k * rho);
+      if ((long double)r < k * rho) ++r;
+      fp.dot_rounds[k - 1] = std::min<uint32_t>(std::max<uint32_t>(r, 1), (uint32_t)k);
+    }
+  }
   memset(field_params_, 0, sizeof field_params_);
   memcpy(field_params_, &fp, sizeof fp);
   validate_program(s, n_instance, n_witness);
@@ -740,10 +750,17 @@ void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<
   dfree(d_r1cs_coefs_);
   HIP_OK(hipMalloc(&d_r1cs_rows_, std::max<size_t>(rows.size() * sizeof(R1csRowDev), 64)));
   HIP_OK(hipMalloc(&d_r1cs_terms_, std::max<size_t>(terms.size() * sizeof(R1csTermDev), 64)));
-  HIP_OK(hipMalloc(&d_r1cs_coefs_, std::max<size_t>(coef_words.size() * 4, 64)));
+  // the pool ends with the Montgomery form of 1: the coefficient of a `1 * w` term inside a chunk that also holds
+  // real coefficients (R1csArgs::one_coef)
+  zkgpu::FieldParams fpar;
+  memcpy(&fpar, field_params_, sizeof fpar);
+  std::vector<uint32_t> pool(coef_words);
+  pool.insert(pool.end(), fpar.one, fpar.one + nwords_);
+  r1cs_one_coef_ = (uint32_t)n_coefs;
+  HIP_OK(hipMalloc(&d_r1cs_coefs_, std::max<size_t>(pool.size() * 4, 64)));
   if (!rows.empty()) HIP_OK(hipMemcpy(d_r1cs_rows_, rows.data(), rows.size() * sizeof(R1csRowDev), hipMemcpyHostToDevice));
   if (!terms.empty()) HIP_OK(hipMemcpy(d_r1cs_terms_, terms.data(), terms.size() * sizeof(R1csTermDev), hipMemcpyHostToDevice));
-  if (!coef_words.empty()) HIP_OK(hipMemcpy(d_r1cs_coefs_, coef_words.data(), coef_words.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_r1cs_coefs_, pool.data(), pool.size() * 4, hipMemcpyHostToDevice));
   r1cs_rows_ = (uint32_t)rows.size();
   if (!d_r1cs_counts_) HIP_OK(hipMalloc(&d_r1cs_counts_, 16));
   if (!ev_r1cs_begin_) {
@@ -782,6 +799,7 @@ void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
   a.n_slots = table_slots_;
   a.batch = batch_;
   a.first_fail = (zkgpu::u32*)d_r1cs_fail_;
+  a.one_coef = r1cs_one_coef_;
   const dim3 grid((n_rows + 3) / 4, lane_blocks_);
   launch_r1cs(nwords_, assign, grid, st, a, fp);
   HIP_OK(hipGetLastError());

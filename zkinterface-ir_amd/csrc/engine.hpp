@@ -142,7 +142,7 @@ class Engine {
   void* d_r1cs_counts_ = nullptr;
   void* ev_r1cs_begin_ = nullptr;
   void* ev_r1cs_end_ = nullptr;
-  uint32_t r1cs_rows_ = 0;
+  uint32_t r1cs_rows_ = 0, r1cs_one_coef_ = 0;
   uint32_t extra_slots_ = 0, table_slots_ = 0;
   float last_r1cs_ms_ = 0.f;
   void* d_lds_ops_ = nullptr;       // 8-byte program for the LDS-resident GF(2) kernel

@@ -129,7 +129,7 @@ TapeBackend::FieldElement TapeBackend::minus_one() const {  // evaluator.rs:881-
   return e;
 }
 
-TapeBackend::Wire TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
+uint32_t TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
   if (tape_.kind.size() >= max_ops_ || tape_.kind.size() >= 0xFFFFFFF0u)
     throw Error("GPU backend: the relation unrolls to more than " + std::to_string(max_ops_) +
                 " backend operations (option max_tape_ops)");
@@ -137,15 +137,17 @@ TapeBackend::Wire TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
   tape_.a.push_back(a);
   tape_.b.push_back(b);
   if (kind != TK_ASSERT) ++tape_.n_value_ops;
-  return (Wire)(tape_.kind.size() - 1);
+  const uint32_t h = (uint32_t)(tape_.kind.size() - 1);
+  maybe_cut();
+  return h;
 }
 
-TapeBackend::Wire TapeBackend::arith(uint8_t kind, uint32_t a, uint32_t b) {
+uint32_t TapeBackend::arith(uint8_t kind, uint32_t a, uint32_t b) {
   need_field();
   return push(kind, a, b);  // for p == 2 the scheduler lowers add/mul to xor/and on bit-packed wires
 }
 
-TapeBackend::Wire TapeBackend::bitwise(uint8_t kind, uint32_t a, uint32_t b) {
+uint32_t TapeBackend::bitwise(uint8_t kind, uint32_t a, uint32_t b) {
   need_field();
   // PlaintextBackend applies & ^ to the integers and then `% m`, and `not` is `is_zero ? 1 : 0`
   // (evaluator.rs:924-938); for p == 2 that is the bit-packed path, for an odd p the arithmetic kernels do the
@@ -162,7 +164,7 @@ uint32_t TapeBackend::intern(const Value& bytes) {
   return idx;
 }
 
-TapeBackend::Wire TapeBackend::constant(FieldElement val) {
+uint32_t TapeBackend::h_constant(FieldElement val) {
   need_field();
   if (val.kind != TapeElement::LITERAL) throw Error("GPU backend: constant() needs literal bytes");
   // constant() stores the integer unreduced in the reference (evaluator.rs:896-898);
@@ -172,24 +174,25 @@ TapeBackend::Wire TapeBackend::constant(FieldElement val) {
   return push(TK_CONST, intern(val.bytes), 0);
 }
 
-TapeBackend::Wire TapeBackend::add_constant(const Wire& x, FieldElement c) {
+uint32_t TapeBackend::h_add_constant(uint32_t x, FieldElement c) {
   need_field();
   if (c.kind != TapeElement::LITERAL) throw Error("GPU backend: add_constant() needs literal bytes");
   return push(TK_ADDC, x, intern(c.bytes));  // (a + c) % m: c may be reduced first
 }
 
-TapeBackend::Wire TapeBackend::mul_constant(const Wire& x, FieldElement c) {
+uint32_t TapeBackend::h_mul_constant(uint32_t x, FieldElement c) {
   need_field();
   if (c.kind != TapeElement::LITERAL) throw Error("GPU backend: mul_constant() needs literal bytes");
   return push(TK_MULC, x, intern(c.bytes));
 }
 
-void TapeBackend::assert_zero(const Wire& w) {
+void TapeBackend::h_assert_zero(uint32_t w) {
   need_field();
   const uint32_t seq = (uint32_t)tape_.assert_op.size();
-  const Wire op = push(TK_ASSERT, w, seq);
-  tape_.assert_op.push_back(op);
+  // the bookkeeping goes first: push() may close a window and hand the tape over
+  tape_.assert_op.push_back((uint32_t)tape_.size());
   tape_.assert_wire.push_back(pending_assert_wire_);
+  push(TK_ASSERT, w, seq);
 }
 
 TapeBackend::FieldElement TapeBackend::instance_ref(uint32_t position) {
@@ -213,14 +216,14 @@ TapeBackend::FieldElement TapeBackend::import_witness(const Value& v) {
   return witness_ref((uint32_t)lane0_witnesses_.size() - 1);
 }
 
-TapeBackend::Wire TapeBackend::instance(FieldElement val) {
+uint32_t TapeBackend::h_instance(FieldElement val) {
   need_field();
   if (val.kind != TapeElement::INSTANCE_REF) throw Error("GPU backend: instance() needs a stream position");
   if (val.position + 1 > tape_.n_instance) tape_.n_instance = val.position + 1;
   return push(TK_INSTANCE, val.position, 0);
 }
 
-TapeBackend::Wire TapeBackend::witness(const FieldElement* val) {
+uint32_t TapeBackend::h_witness(const FieldElement* val) {
   need_field();
   // PlaintextBackend panics on a missing witness (evaluator.rs:944-946)
   if (!val) throw Panic("Missing witness value for PlaintextBackend");

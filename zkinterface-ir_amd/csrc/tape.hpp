@@ -57,8 +57,20 @@ struct Tape {
     uint32_t first, result, base;
   };
   std::vector<Ladder> ladders;
+  uint32_t ladder_open = kNoWire;          // tape size at note_ladder_begin while a ladder is being recorded
   uint32_t n_instance = 0, n_witness = 0;  // input positions referenced (max + 1)
   uint64_t n_value_ops = 0;
+  // Dropped wires, in order: handle drop_handle[k] went out of the caller's reach when the tape held drop_pos[k]
+  // entries -- no call recorded at or after that position can name it.  The reference's evaluator owns its wires
+  // (`HashMap<WireId, B::Wire>`, temporaries in locals) and Rust drops them on `Free`, at scope exit and at the end
+  // of each expression (evaluator.rs:698-746, :775-797); the streaming scheduler needs exactly that signal to know
+  // that a value has seen its last reader before the rest of the relation has arrived.
+  std::vector<uint32_t> drop_pos, drop_handle;
+  // Window cuts for the streaming scheduler, decided while recording so that they depend on the tape alone (not on
+  // how the relation was split into messages): the first position >= the previous cut + window_ops at which no
+  // exponent ladder is open.
+  std::vector<uint32_t> cuts;
+  uint32_t window_ops = 0;                 // 0 = no cuts
 
   size_t size() const { return kind.size(); }
 };
@@ -71,9 +83,36 @@ struct TapeElement {
   Value bytes;
 };
 
+class TapeBackend;
+
+// The recording backend's `Wire`: owns one tape handle, move-only like the reference's `B::Wire` values.  Letting go of
+// it (scope erase on `Free`, a sub-circuit scope going away, a temporary dying) tells the backend that no later call
+// can read the value.
+struct TapeWire {
+  uint32_t h = kNoWire;
+  TapeBackend* owner = nullptr;
+  TapeWire() = default;
+  TapeWire(uint32_t handle, TapeBackend* o) : h(handle), owner(o) {}
+  TapeWire(TapeWire&& o) noexcept : h(o.h), owner(o.owner) { o.h = kNoWire; o.owner = nullptr; }
+  TapeWire& operator=(TapeWire&& o) noexcept {
+    if (this != &o) {
+      release();
+      h = o.h;
+      owner = o.owner;
+      o.h = kNoWire;
+      o.owner = nullptr;
+    }
+    return *this;
+  }
+  TapeWire(const TapeWire&) = delete;
+  TapeWire& operator=(const TapeWire&) = delete;
+  ~TapeWire() { release(); }
+  inline void release();
+};
+
 class TapeBackend {
  public:
-  using Wire = uint32_t;
+  using Wire = TapeWire;
   using FieldElement = TapeElement;
 
   static FieldElement from_bytes_le(const Value& v) {  // evaluator.rs:25
@@ -86,25 +125,58 @@ class TapeBackend {
   FieldElement minus_one() const;
   FieldElement zero() const { return literal(0); }
 
-  Wire copy(const Wire& w) { return push(TK_COPY, w, 0); }
-  Wire constant(FieldElement val);
-  void assert_zero(const Wire& w);
+  // ---- the trait, on owned wires (what Evaluator<TapeBackend> calls) ----
+  Wire copy(const Wire& w) { return own(h_copy(w.h)); }
+  Wire constant(FieldElement val) { return own(h_constant(std::move(val))); }
+  void assert_zero(const Wire& w) { h_assert_zero(w.h); }
+  Wire add(const Wire& x, const Wire& y) { return own(arith(TK_ADD, x.h, y.h)); }
+  Wire multiply(const Wire& x, const Wire& y) { return own(arith(TK_MUL, x.h, y.h)); }
+  Wire add_constant(const Wire& x, FieldElement c) { return own(h_add_constant(x.h, std::move(c))); }
+  Wire mul_constant(const Wire& x, FieldElement c) { return own(h_mul_constant(x.h, std::move(c))); }
+  Wire and_(const Wire& x, const Wire& y) { return own(bitwise(TK_AND, x.h, y.h)); }
+  Wire xor_(const Wire& x, const Wire& y) { return own(bitwise(TK_XOR, x.h, y.h)); }
+  Wire not_(const Wire& x) { return own(bitwise(TK_NOT, x.h, 0)); }
+  Wire instance(FieldElement val) { return own(h_instance(std::move(val))); }
+  Wire witness(const FieldElement* val) { return own(h_witness(val)); }
   void note_assert_wire(WireId local_id) { pending_assert_wire_ = local_id; }
-  size_t note_ladder_begin() const { return tape_.size(); }
-  void note_ladder_end(size_t first, const Wire& base, const Wire& result) {
+  size_t note_ladder_begin() {
+    tape_.ladder_open = (uint32_t)tape_.size();
+    return tape_.size();
+  }
+  void note_ladder_end(size_t first, const Wire& base, const Wire& result) { h_ladder(first, base.h, result.h); }
+
+  // ---- the same on plain handles (the C ABI: the caller owns the handles and reports drops itself) ----
+  uint32_t h_copy(uint32_t w) { return push(TK_COPY, w, 0); }
+  uint32_t h_constant(FieldElement val);
+  void h_assert_zero(uint32_t w);
+  uint32_t h_add(uint32_t x, uint32_t y) { return arith(TK_ADD, x, y); }
+  uint32_t h_multiply(uint32_t x, uint32_t y) { return arith(TK_MUL, x, y); }
+  uint32_t h_add_constant(uint32_t x, FieldElement c);
+  uint32_t h_mul_constant(uint32_t x, FieldElement c);
+  uint32_t h_and(uint32_t x, uint32_t y) { return bitwise(TK_AND, x, y); }
+  uint32_t h_xor(uint32_t x, uint32_t y) { return bitwise(TK_XOR, x, y); }
+  uint32_t h_not(uint32_t x) { return bitwise(TK_NOT, x, 0); }
+  uint32_t h_instance(FieldElement val);
+  uint32_t h_witness(const FieldElement* val);
+  void h_ladder(size_t first, uint32_t base, uint32_t result) {
+    tape_.ladder_open = kNoWire;
     // with is_boolean the "multiplies" of the ladder are `and` gates and Fermat says nothing about them
     // (evaluator.rs:86-93): no hint is kept
     if (!is_boolean_ && result >= first && base < first) tape_.ladders.push_back({(uint32_t)first, result, base});
+    maybe_cut();   // a cut that fell inside the ladder was put off until here
   }
-  Wire add(const Wire& x, const Wire& y) { return arith(TK_ADD, x, y); }
-  Wire multiply(const Wire& x, const Wire& y) { return arith(TK_MUL, x, y); }
-  Wire add_constant(const Wire& x, FieldElement c);
-  Wire mul_constant(const Wire& x, FieldElement c);
-  Wire and_(const Wire& x, const Wire& y) { return bitwise(TK_AND, x, y); }
-  Wire xor_(const Wire& x, const Wire& y) { return bitwise(TK_XOR, x, y); }
-  Wire not_(const Wire& x) { return bitwise(TK_NOT, x, 0); }
-  Wire instance(FieldElement val);
-  Wire witness(const FieldElement* val);
+  // no call recorded from now on reads `h` (TapeWire's destructor; zkgpu_backend_drop)
+  void drop_wire(uint32_t h) {
+    if (h >= tape_.size()) return;
+    tape_.drop_pos.push_back((uint32_t)tape_.size());
+    tape_.drop_handle.push_back(h);
+  }
+  // streaming: cut the tape into windows of about `ops` entries; `hook(arg)` runs on the recording thread at each cut
+  void set_window(uint32_t ops, void (*hook)(void*), void* arg) {
+    tape_.window_ops = ops;
+    cut_hook_ = hook;
+    cut_arg_ = arg;
+  }
 
   // Single-statement use (`evaluate <workspace>`): the values of an Instance /
   // Witness message become lane 0's input stream, referenced by position.
@@ -129,9 +201,19 @@ class TapeBackend {
     e.bytes.assign(1, v);
     return e;
   }
-  Wire push(uint8_t kind, uint32_t a, uint32_t b);
-  Wire arith(uint8_t kind, uint32_t a, uint32_t b);
-  Wire bitwise(uint8_t kind, uint32_t a, uint32_t b);
+  Wire own(uint32_t h) { return Wire(h, this); }
+  uint32_t push(uint8_t kind, uint32_t a, uint32_t b);
+  uint32_t arith(uint8_t kind, uint32_t a, uint32_t b);
+  uint32_t bitwise(uint8_t kind, uint32_t a, uint32_t b);
+  void maybe_cut() {
+    if (!tape_.window_ops || tape_.ladder_open != kNoWire) return;
+    const uint32_t last = tape_.cuts.empty() ? 0 : tape_.cuts.back();
+    if (tape_.size() - last < tape_.window_ops) return;
+    tape_.cuts.push_back((uint32_t)tape_.size());
+    if (cut_hook_) cut_hook_(cut_arg_);
+  }
+  void (*cut_hook_)(void*) = nullptr;
+  void* cut_arg_ = nullptr;
   uint32_t intern(const Value& bytes);
   void need_field() const;
 
@@ -144,5 +226,11 @@ class TapeBackend {
   uint64_t max_ops_ = 1ull << 30;
   std::vector<Value> lane0_instances_, lane0_witnesses_;
 };
+
+inline void TapeWire::release() {
+  if (owner && h != kNoWire) owner->drop_wire(h);
+  owner = nullptr;
+  h = kNoWire;
+}
 
 }  // namespace zki
