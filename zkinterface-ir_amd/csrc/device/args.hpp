@@ -24,6 +24,10 @@ struct FieldParams {
   // conditional subtractions that make the lazily reduced sum of K Montgomery products canonical: the sum is below
   // (K * p / R + 1) * p, so ceil(K * p / R) of them (host: Engine::load_program); index K - 1, K = 1..4
   u32 dot_rounds[4];
+  // != 0: the sum of 3 products may stay unreduced when it is an operand of a Montgomery product of two such sums:
+  // with a = 3 * p / R + 1 the sum is below a * p < R and the product below (a * a * p / R + 1) * p <= 2 * p, which
+  // the product's own conditional subtraction makes canonical (BN254: a = 1.57, a * a * p / R = 0.46)
+  u32 lazy_dot3;
 };
 
 enum OpKind : u32 {

@@ -138,36 +138,69 @@ __device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const Fi
       : "v"(x), "s"(y)                                                                        \
       : "vcc")
 
+// A run of K accumulations as ONE asm statement: hipcc's hazard recogniser treats every asm statement as if it could
+// be a wide store and puts an `s_nop 0` between two statements that touch the same VGPR -- one per word product when
+// each product is a statement of its own.  madc_run<K, SC>(lo, hi, x, y): (hi : lo) += sum_{j < K} x[j] * y[-j]
+// (y walks DOWN, as the operand of a column of a product does); SC: y is wave-uniform and goes in SGPRs.
+#define ZKGPU_MT(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+template <int K, bool SC>
+__device__ __forceinline__ void madc_run(u64& lo, u32& hi, const u32* x, const u32* y) {
+  static_assert(K >= 1 && K <= 12, "");
+#define ZKGPU_IN(j) "v"(x[j]), "v"(y[-(j)])
+#define ZKGPU_IS(j) "v"(x[j]), "s"(y[-(j)])
+  if constexpr (K == 1) { if constexpr (SC) asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0) : "vcc"); else asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0) : "vcc"); }
+  else if constexpr (K == 2) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1) : "vcc"); }
+  else if constexpr (K == 3) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2) : "vcc"); }
+  else if constexpr (K == 4) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3) : "vcc"); }
+  else {  // longer runs: four at a time
+    madc_run<4, SC>(lo, hi, x, y);
+    madc_run<K - 4, SC>(lo, hi, x + 4, y - 4);
+  }
+#undef ZKGPU_IN
+#undef ZKGPU_IS
+}
+
 // Montgomery product a*b*R^{-1} mod p, product-scanning (column by column) form, canonical out.
 // Per column k: acc += sum a[i]*b[k-i] + sum m[i]*p[k-i]; m[k] = acc * n0inv makes the low word 0;
 // the accumulator then shifts down one word.  2*N^2 + N word products, 2 instructions each.
+template <int N, int k, bool SC>
+__device__ __forceinline__ void mont_products(u64& lo, u32& hi, const u32* x, const u32* y) {
+  if constexpr (k < N) {
+    madc_run<k + 1, SC>(lo, hi, x, y + k);                       // x[i] * y[k - i], i = 0..k
+  } else if constexpr (k - N + 1 < N) {
+    madc_run<2 * N - 1 - k, SC>(lo, hi, x + (k - N + 1), y + (N - 1));   // i = k-N+1 .. N-1
+  }
+}
+template <int N, int k>
+__device__ __forceinline__ void mont_reduce_column(u64& lo, u32& hi, u32 (&m)[N], u32 (&t)[N + 1], const FieldParams& fp) {
+  if constexpr (k < N) {
+    if constexpr (k > 0) madc_run<k, true>(lo, hi, &m[0], &fp.p[k]);   // m[i] * p[k - i], i < k: the words of p stay in SGPRs
+    m[k] = (u32)lo * fp.n0inv;
+    madc_run<1, true>(lo, hi, &m[k], &fp.p[0]);
+  } else {
+    if constexpr (k - N + 1 < N) madc_run<2 * N - 1 - k, true>(lo, hi, &m[k - N + 1], &fp.p[N - 1]);
+    t[k - N] = (u32)lo;
+  }
+  lo = (lo >> 32) | ((u64)hi << 32);
+  hi = 0;
+}
+
+template <int N, int k>
+__device__ __forceinline__ void fp_mul_columns(u64& lo, u32& hi, const Fp<N>& a, const Fp<N>& b, u32 (&m)[N], u32 (&t)[N + 1],
+                                               const FieldParams& fp) {
+  if constexpr (k < 2 * N) {
+    mont_products<N, k, false>(lo, hi, a.w, b.w);
+    mont_reduce_column<N, k>(lo, hi, m, t, fp);
+    fp_mul_columns<N, k + 1>(lo, hi, a, b, m, t, fp);
+  }
+}
+
 template <int N>
 __device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
   u64 lo = 0;
   u32 hi = 0;
   u32 m[N], t[N + 1];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-#pragma unroll
-    for (int i = 0; i <= k; ++i) ZKGPU_MADC(lo, hi, a.w[i], b.w[k - i]);
-#pragma unroll
-    for (int i = 0; i < k; ++i) ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);   // the words of p stay in SGPRs
-    m[k] = (u32)lo * fp.n0inv;
-    ZKGPU_MADC_S(lo, hi, m[k], fp.p[0]);
-    lo = (lo >> 32) | ((u64)hi << 32);
-    hi = 0;
-  }
-#pragma unroll
-  for (int k = N; k < 2 * N; ++k) {
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) {
-      ZKGPU_MADC(lo, hi, a.w[i], b.w[k - i]);
-      ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);
-    }
-    t[k - N] = (u32)lo;
-    lo = (lo >> 32) | ((u64)hi << 32);
-    hi = 0;
-  }
+  fp_mul_columns<N, 0>(lo, hi, a, b, m, t, fp);
   t[N] = (u32)lo;
   // t < 2p here; one conditional subtraction.
   Fp<N> d;
@@ -205,41 +238,29 @@ __device__ __forceinline__ FpS<N> fp_load_uniform(const u32* pool, u32 index) {
 // K*N^2 + N^2 + N word products instead of K*(2*N^2 + N).  The coefficients c[k] are wave-uniform and stay in
 // SGPRs, as do the words of p.  The unreduced result is below K*p*p/R + p = (K*p/R + 1)*p: fp.dot_rounds[K-1] =
 // ceil(K*p/R) conditional subtractions make it canonical (one for K = 3 over BN254, where p/R = 0.19).
+template <int N, int K, int k>
+__device__ __forceinline__ void fp_dot_columns(u64& lo, u32& hi, const Fp<N> (&v)[K], const FpS<N> (&c)[K], u32 (&m)[N],
+                                               u32 (&t)[N + 1], const FieldParams& fp) {
+  if constexpr (k < 2 * N) {
+    mont_products<N, k, true>(lo, hi, v[0].w, c[0].w);
+    if constexpr (K > 1) mont_products<N, k, true>(lo, hi, v[1].w, c[1].w);
+    if constexpr (K > 2) mont_products<N, k, true>(lo, hi, v[2].w, c[2].w);
+    if constexpr (K > 3) mont_products<N, k, true>(lo, hi, v[3].w, c[3].w);
+    mont_reduce_column<N, k>(lo, hi, m, t, fp);
+    fp_dot_columns<N, K, k + 1>(lo, hi, v, c, m, t, fp);
+  }
+}
+
+// `rounds`: conditional subtractions applied to the lazily reduced sum; fp.dot_rounds[K - 1] makes it canonical,
+// 0 leaves it below (K * p / R + 1) * p (the caller must know that this fits N words and what may consume it).
 template <int N, int K>
-__device__ __forceinline__ Fp<N> fp_dot(const Fp<N> (&v)[K], const FpS<N> (&c)[K], const FieldParams& fp) {
+__device__ __forceinline__ Fp<N> fp_dot(const Fp<N> (&v)[K], const FpS<N> (&c)[K], const FieldParams& fp, u32 rounds) {
   static_assert(K >= 1 && K <= 4, "the 32-bit carry word of the accumulator holds 2*K*N carries");
   u64 lo = 0;
   u32 hi = 0;
   u32 m[N], t[N + 1];
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-#pragma unroll
-      for (int i = 0; i <= k; ++i) ZKGPU_MADC_S(lo, hi, v[q].w[i], c[q].w[k - i]);
-    }
-#pragma unroll
-    for (int i = 0; i < k; ++i) ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);
-    m[k] = (u32)lo * fp.n0inv;
-    ZKGPU_MADC_S(lo, hi, m[k], fp.p[0]);
-    lo = (lo >> 32) | ((u64)hi << 32);
-    hi = 0;
-  }
-#pragma unroll
-  for (int k = N; k < 2 * N; ++k) {
-#pragma unroll
-    for (int q = 0; q < K; ++q) {
-#pragma unroll
-      for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC_S(lo, hi, v[q].w[i], c[q].w[k - i]);
-    }
-#pragma unroll
-    for (int i = k - N + 1; i < N; ++i) ZKGPU_MADC_S(lo, hi, m[i], fp.p[k - i]);
-    t[k - N] = (u32)lo;
-    lo = (lo >> 32) | ((u64)hi << 32);
-    hi = 0;
-  }
+  fp_dot_columns<N, K, 0>(lo, hi, v, c, m, t, fp);
   t[N] = (u32)lo;
-  const u32 rounds = fp.dot_rounds[K - 1];   // wave-uniform, 1..K
   for (u32 round = 0; round < rounds; ++round) {
     u32 d[N];
     u64 borrow = 0;

@@ -36,9 +36,11 @@ __device__ __forceinline__ Fp<N> r1cs_term_value(const R1csTerm term, const uint
 // A linear combination, three terms at a time: the three gathers are issued together and, when a coefficient other
 // than 1 is present, the three products share one Montgomery reduction (fp_dot) with the coefficients as scalar
 // operands.  The first chunk IS the accumulator (no add to zero); every chunk value is canonical.
+// lazy: the caller multiplies the result by another such sum (see FieldParams::lazy_dot3): a combination that is one
+// chunk of three products then skips its conditional subtraction.
 template <int N>
 __device__ __forceinline__ Fp<N> r1cs_lincomb(const R1csArgs& args, const uint4* __restrict__ T, u32 t0, u32 n,
-                                              const FieldParams& fp) {
+                                              const FieldParams& fp, bool lazy = false) {
   Fp<N> acc;
   if (n == 0) {
 #pragma unroll
@@ -69,15 +71,15 @@ __device__ __forceinline__ Fp<N> r1cs_lincomb(const R1csArgs& args, const uint4*
       if (m == 3) {
         const Fp<N> v[3] = {r1cs_term_value<N>(e0, T, fp), r1cs_term_value<N>(e1, T, fp), r1cs_term_value<N>(e2, T, fp)};
         const FpS<N> c[3] = {coef(e0), coef(e1), coef(e2)};
-        part = fp_dot<N, 3>(v, c, fp);
+        part = fp_dot<N, 3>(v, c, fp, (lazy && n == 3) ? 0u : fp.dot_rounds[2]);
       } else if (m == 2) {
         const Fp<N> v[2] = {r1cs_term_value<N>(e0, T, fp), r1cs_term_value<N>(e1, T, fp)};
         const FpS<N> c[2] = {coef(e0), coef(e1)};
-        part = fp_dot<N, 2>(v, c, fp);
+        part = fp_dot<N, 2>(v, c, fp, fp.dot_rounds[1]);
       } else {
         const Fp<N> v[1] = {r1cs_term_value<N>(e0, T, fp)};
         const FpS<N> c[1] = {coef(e0)};
-        part = fp_dot<N, 1>(v, c, fp);
+        part = fp_dot<N, 1>(v, c, fp, fp.dot_rounds[0]);
       }
     }
     acc = t == t0 ? part : fp_add<N>(acc, part, fp);
@@ -103,9 +105,10 @@ __global__ __launch_bounds__(256) void r1cs_row_kernel(const R1csArgs args, cons
   d.counts = dq[1];
   const u32 na = d.counts & 0xFF, nb = (d.counts >> 8) & 0xFF, nc = (d.counts >> 16) & 0xFF, flags = d.counts >> 24;
   const uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
-  Fp<N> prod = r1cs_lincomb<N>(args, T, d.first, na, fp);
+  const bool lazy = fp.lazy_dot3 != 0 && !(flags & kR1csBIsOne);   // both sums feed the product below
+  Fp<N> prod = r1cs_lincomb<N>(args, T, d.first, na, fp, lazy);
   if (!(flags & kR1csBIsOne)) {
-    const Fp<N> b = r1cs_lincomb<N>(args, T, d.first + na, nb, fp);
+    const Fp<N> b = r1cs_lincomb<N>(args, T, d.first + na, nb, fp, lazy);
     prod = fp_mul<N>(prod, b, fp);
   }
   if (ASSIGN) {

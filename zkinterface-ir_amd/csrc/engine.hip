@@ -231,6 +231,8 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
       if ((long double)r < k * rho) ++r;
       fp.dot_rounds[k - 1] = std::min<uint32_t>(std::max<uint32_t>(r, 1), (uint32_t)k);
     }
+    const long double a3 = 3 * rho + 1;
+    fp.lazy_dot3 = (a3 * rho < 0.999L && a3 * a3 * rho < 0.999L) ? 1 : 0;
   }
   memset(field_params_, 0, sizeof field_params_);
   memcpy(field_params_, &fp, sizeof fp);

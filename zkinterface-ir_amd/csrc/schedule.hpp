@@ -2,10 +2,15 @@
 // (rust/src/consumers/evaluator.rs:288-301); the calls only depend on each
 // other through wires, so the tape is re-ordered into dependency levels
 // (every op of a level is independent -> one wide kernel launch), operand
-// handles are renamed to wire-table slots with liveness-based reuse (the
-// reference's only liveness signal, `Free`, never reaches a backend:
-// flattening.rs:10-11), and runs of very narrow levels are fused into
-// sequential launches walked by one wavefront per lane block.
+// handles are renamed to wire-table slots with liveness-based reuse, and runs
+// of very narrow levels are fused into sequential launches walked by one
+// wavefront per lane block.
+//
+// The scheduler works on WINDOWS of the tape (StreamScheduler): the reference consumes a relation as a stream of
+// <= 100k-gate messages (evaluator.rs:286-301, producers/builder.rs:46-74), and a window of the tape can be scheduled --
+// and its part of the program sent to the GPU -- while later messages are still being parsed.  What a window needs to
+// know about the future is which of its values can still get readers: that is what the drop records of the tape say
+// (tape.hpp).  build_schedule() is the one-window case (the whole tape, everything but the pinned wires closed).
 #pragma once
 #include <stdint.h>
 #include <vector>
@@ -32,6 +37,7 @@ struct Launch {
   uint32_t ops_per_wave = 1;  // count => one wave walks the whole launch in order
   bool sequential = false;    // ops depend on each other: no operand prefetch
   uint32_t level_begin = 0, level_end = 0;
+  uint32_t window = 0;        // tape window the launch belongs to (its entries were uploaded with that window)
   uint32_t hot_count = 0;     // a level of the fused program: its first hot_count entries are the Add/Mul ones
   bool has_bitops = false;    // holds and / xor over an odd field (the kernels' cold instantiation)
 };
@@ -45,6 +51,7 @@ struct ScheduleOptions {
   bool pair = true;                 // one entry for the two same-level readers of a producer nobody else reads (never with retain_all)
   bool propagate_copies = true;     // readers use a copy's source; unobserved copies are not materialised (never with retain_all)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
+  uint32_t threads = 0;             // worker threads for the per-level ordering (0 = min(8, hardware threads))
 };
 
 struct Schedule {
@@ -58,6 +65,7 @@ struct Schedule {
   std::vector<Launch> launches;
   std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)
   std::vector<uint32_t> level_of;   // per tape op
+  std::vector<uint64_t> window_first_op;   // per window: index of its first program entry (+ a final end marker)
   uint32_t n_slots = 0;
   uint32_t n_levels = 0;
   uint32_t max_level_width = 0;
@@ -70,6 +78,44 @@ struct Schedule {
   uint32_t words_per_const = 0;
 };
 
+// Ops [lo, hi) of a tape.  Arrays are indexed by (tape index - lo); operands are tape indices and may lie below lo.
+struct TapeWindow {
+  uint32_t lo = 0, hi = 0;
+  const uint8_t* kind = nullptr;
+  const uint32_t* a = nullptr;
+  const uint32_t* b = nullptr;
+  const uint32_t* drops = nullptr;        // handles dropped since the previous window, up to tape position hi
+  size_t n_drops = 0;
+  const Tape::Ladder* ladders = nullptr;  // ladder hints that end inside the window
+  size_t n_ladders = 0;
+  bool final = false;                     // last window: every value not in `pinned` has seen its last reader
+  const std::vector<uint32_t>* pinned = nullptr;
+};
+
+struct WindowResult {  // what add_window() appended to the schedule
+  uint64_t first_op = 0, n_ops = 0;
+  uint32_t first_launch = 0, n_launches = 0;
+};
+
+class StreamScheduler {
+ public:
+  StreamScheduler(const FieldHost& field, const ScheduleOptions& opt);
+  ~StreamScheduler();
+  StreamScheduler(const StreamScheduler&) = delete;
+  StreamScheduler& operator=(const StreamScheduler&) = delete;
+  WindowResult add_window(const TapeWindow& w);
+  // after the final window: the constant pool in device form; returns the finished schedule
+  Schedule finish(const std::vector<Value>& consts);
+  const Schedule& partial() const;   // the program so far (ops / launches of the windows already added)
+
+ private:
+  struct Impl;
+  Impl* impl_;
+};
+
+// the whole tape as one final window
 Schedule build_schedule(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt);
+// the tape cut at tape.cuts (what a streamed ingest produces window by window), for tests and tools
+Schedule build_schedule_windowed(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt);
 
 }  // namespace zki
