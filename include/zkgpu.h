@@ -106,6 +106,9 @@ size_t zkgpu_constant_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out
  * by zkgpu_set_inputs*).
  * retain_all != 0 keeps every wire value readable afterwards (parity dumps). */
 int zkgpu_finalize(zkgpu_session* s, int retain_all);
+/* Streaming ingest (option "stream"): out[0] = tape windows of the program, out[1] = windows that were scheduled (and,
+ * with a GPU, uploaded) by the worker thread while messages were still coming in, out[2] = seconds that thread worked. */
+int zkgpu_stream_info(const zkgpu_session* s, double out[3]);
 uint32_t zkgpu_elem_bytes(const zkgpu_session* s);   /* bytes per input value: 8*limbs, or 1 for GF(2) */
 uint32_t zkgpu_n_instance(const zkgpu_session* s);   /* values per lane the tape consumes */
 uint32_t zkgpu_n_witness(const zkgpu_session* s);
@@ -138,6 +141,14 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "xcd_map" = 0|1 (launches over a multiple of 8 lane blocks give each XCD its own lane blocks; default 1),
  * "level_ops_per_wave" = 1..8 (program entries of a wide level walked by one wave, interleaved over the 4 waves
  * of a workgroup; default 1: with the Add/Mul kernel at 60 VGPRs = 8 waves per SIMD one entry per wave measured fastest),
+ * "stream" = 0 | 1 | N (streaming ingest, rust/src/consumers/evaluator.rs:286-301: the reference consumes a relation
+ * as a stream of <= 100k-gate messages; with N > 0 the tape is cut into windows of about N recorded calls ("1" = 131072),
+ * and a worker thread schedules each window -- and sends its program entries to the GPU -- as soon as it is complete,
+ * while the caller is still ingesting the following messages; zkgpu_finalize then only schedules the tail.  The cuts
+ * depend on the tape alone, so the program is the same however the relation was split into messages.  What a window
+ * may fuse or recycle rests on the drop records of the wires (the bundled Evaluator gives them; zkgpu_backend_drop).
+ * Set before the first Relation message; ignored for GF(2) and with retain_all.  Default 0),
+ * "schedule_threads" = N (threads ordering the levels of a window, default min(8, hardware threads)),
  * "hot_waves" = 0 | 3..7 (cap on the resident waves per SIMD of the Add/Mul kernel, by an unused LDS allocation;
  * 0 = no cap, the default -- a tuning handle, every cap measured slower on C2),
  * "fuse" = 0|1 (single-reader Add/Mul gates evaluated inside their reader; never with retain_all),

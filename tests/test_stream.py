@@ -1,0 +1,206 @@
+"""Streaming ingest (rust/src/consumers/evaluator.rs:286-301: the reference consumes a relation as a
+stream of <= 100k-gate messages).  With option "stream" the tape is cut into windows while it is recorded and a worker
+thread schedules every window as soon as it is complete; what a window may fuse, elide or recycle rests on the drop
+records of the wires.  CPU tier: the streamed program interpreted by program_sim against the oracle, and program
+identity however the relation is split into messages.  GPU tier: the same through the kernels."""
+import numpy as np
+import pytest
+
+import circuits
+import program_sim
+from helpers import batch_arrays, oracle_lane
+from random_circuits import Gen
+from test_fuzz_host import FIELDS, expected_product_violations
+import zkinterface_ir_amd as zk
+from zkinterface_ir_amd import workloads
+
+
+def _streamed(rel_msgs, n_inst, n_wit, window, **options):
+    ev = zk.Evaluator()
+    ev.set_option('stream', str(window))
+    for k, v in options.items():
+        ev.set_option(k, str(v))
+    ev.declare_inputs(n_inst, n_wit)
+    for m in rel_msgs:
+        ev.ingest_message(m)
+    return ev
+
+
+@pytest.mark.parametrize('seed', range(40))
+def test_streamed_random_relations_against_oracle(seed):
+    """functions / for / switch / frees cut into windows of 24 recorded calls: a value that a later window may still
+    read keeps its slot, everything else is fused / elided / recycled as in the one-window schedule; every lane's
+    verdict and violation text is the oracle's, and a level never overwrites what it reads (program_sim asserts)."""
+    p, boolean = FIELDS[seed % len(FIELDS)]
+    g = Gen(seed, p, boolean)
+    rel, mod_le = g.relation(n_top=14)
+    rows_i, rows_w = g.lane_inputs(3, seed + 1000)
+    ev = _streamed([rel], g.n_inst, g.n_wit, 24)
+    if not ev.n_value_ops and ev.host_violations():
+        return
+    ev.finalize()
+    info, sinfo = ev.schedule_info(), ev.stream_info()
+    if p != 2:
+        assert sinfo['windows'] >= 2 or len(ev.tape()[0]) < 24 + 400       # (a cut waits for the end of a Switch ladder)
+        assert sinfo['streamed_windows'] == sinfo['windows']          # all of them went through the worker thread
+    else:
+        assert sinfo['windows'] == 1                                   # GF(2) programs are scheduled as a whole
+    ops, launches, consts, slot_of = ev.schedule_dump()
+    for lane in range(3):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32, trace=False)
+        _, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p,
+                                               rows_i[lane], rows_w[lane], shuffle_seed=seed)
+        assert not noncanon
+        assert expected_product_violations(ev, ff) == ref.violations, (seed, lane)
+    # the one-window schedule of the same relation is at most as large, and uses at most as many slots
+    whole = zk.Evaluator()
+    whole.declare_inputs(g.n_inst, g.n_wit)
+    whole.ingest_message(rel)
+    whole.finalize()
+    assert whole.schedule_info()['device_ops'] <= info['device_ops']
+
+
+def test_program_does_not_depend_on_how_the_relation_is_split_into_messages():
+    """The cuts are a property of the tape (every `stream` recorded calls, put off while a Switch ladder is open), so
+    3 messages, one concatenated buffer, and a non-streamed ingest scheduled with the same windows at finalize give
+    the same program, entry by entry."""
+    wl = workloads.ArithLayered(W=1024, D=230, n_instance0=16, n_out=8)
+    msgs = wl.relation_messages()
+    assert len(msgs) == 3
+    dumps = []
+    for parts in (msgs, [b''.join(msgs)]):
+        ev = _streamed(parts, wl.n_instance, wl.n_witness, 40000)
+        ev.finalize()
+        assert ev.stream_info()['windows'] == len(ev.tape()[0]) // 40000 + 1
+        assert ev.stream_info()['streamed_windows'] == ev.stream_info()['windows']
+        dumps.append(ev.schedule_dump())
+    for x, y in zip(*dumps):
+        assert np.array_equal(x, y)
+    # scheduled at finalize with retain_all the stream is ignored: every value keeps its own slot
+    ev = _streamed(msgs, wl.n_instance, wl.n_witness, 40000)
+    ev.finalize(retain_all=True)
+    assert ev.stream_info()['windows'] == 1 and ev.schedule_info()['slots'] == ev.n_value_ops
+    # and the streamed program computes what the oracle computes
+    ev = _streamed(msgs, wl.n_instance, wl.n_witness, 40000)
+    ev.finalize()
+    ops, launches, consts, _ = ev.schedule_dump()
+    info = ev.schedule_info()
+    inst, wit = wl.inputs(1)
+    iv = [int.from_bytes(inst[0, k].tobytes(), 'little') for k in range(wl.n_instance)]
+    wv = [int.from_bytes(wit[0, k].tobytes(), 'little') for k in range(wl.n_witness)]
+    ref = oracle_lane(wl.mod_le, iv, wv, msgs, wl.width, trace=False)
+    _, ff, _ = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], wl.p, iv, wv)
+    assert expected_product_violations(ev, ff) == ref.violations and ff is not None   # expected outputs are all 0 here
+    assert info['slots'] < 4 * wl.W        # slots are recycled across windows (three live layers at most)
+
+
+def test_switch_ladders_are_never_cut_and_still_become_one_entry():
+    """a window boundary that falls inside the 352-call exponent ladder of a Switch weight is put off to the ladder's
+    end, so the Fermat rewrite (one `x != 0` entry) works window by window"""
+    _i, _w, rel = circuits.arith_example(circuits.BN254_R)
+    sizes = {}
+    for window in (0, 100):
+        ev = zk.Evaluator()
+        ev.set_option('stream', str(window))
+        ev.declare_inputs(3, 4)
+        ev.ingest_message(rel)
+        ev.finalize()
+        sizes[window] = ev.schedule_info()['device_ops']
+        if window:
+            assert ev.stream_info()['windows'] >= 3
+    assert sizes[100] < 200 and sizes[0] < 120       # 965 recorded calls either way
+
+
+def test_trait_level_recording_with_drops_streams_too():
+    """a caller that drives the ZKBackend entry points itself (the Rust Evaluator of INTEGRATION.md) reports dropped
+    wires with zkgpu_backend_drop (`impl Drop` of its Wire type); without drops every value stays materialised until
+    finalize, with them the windows fuse and recycle"""
+    p = circuits.BN254_R
+    results = {}
+    for drops in (False, True):
+        ev = zk.Evaluator()
+        ev.set_option('stream', '64')
+        ev.backend_set_field(p.to_bytes(32, 'little'))
+        x = ev.backend_witness(0)
+        acc = ev.backend_witness(1)
+        for k in range(400):                   # acc = (acc * x + acc) chained: every intermediate has one reader
+            t = ev.backend_multiply(acc, x)
+            nxt = ev.backend_add(t, acc)
+            if drops:
+                ev.backend_drop(t)
+                ev.backend_drop(acc)
+            acc = nxt
+        out = ev.backend_add_constant(acc, (p - 5).to_bytes(32, 'little'))
+        ev.backend_assert_zero(out, 7)
+        ev.finalize()
+        info = ev.schedule_info()
+        ops, launches, consts, _ = ev.schedule_dump()
+        want = 3
+        for k in range(400):
+            want = (want * 2 + want) % p
+        _, ff, _ = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, [], [2, 3])
+        assert (ff is None) == ((want + p - 5) % p == 0)
+        _, ff, _ = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, [], [0, 5])
+        assert ff is None                      # x = 0: acc stays 5, 5 + (p - 5) = 0
+        results[drops] = info
+    assert results[True]['slots'] < 20 < results[False]['slots']
+    assert results[True]['device_ops'] < results[False]['device_ops']
+
+
+# ---------------------------------------------------------------- GPU tier
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(25, 45))
+def test_streamed_random_relations_on_gpu(seed):
+    """the fuzz of test_gpu_parity through a streamed ingest (windows of 32 calls, program uploaded window by window):
+    violation strings, counts and the surviving top-level wires against the oracle"""
+    p, boolean = FIELDS[seed % len(FIELDS)]
+    g = Gen(seed, p, boolean)
+    rel, mod_le = g.relation(n_top=14)
+    lanes = 70
+    rows_i, rows_w = g.lane_inputs(lanes, seed + 1000)
+    ev = _streamed([rel], g.n_inst, g.n_wit, 32)
+    ev.finalize()
+    inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+    ev.set_inputs(inst if g.n_inst else None, wit if g.n_wit else None, lanes)
+    ev.replay()
+    ev.synchronize()
+    n_ok = 0
+    for lane in range(0, lanes, 3):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32, trace=False)
+        assert ev.get_violations(lane) == ref.violations, (seed, lane)
+    first, _ = ev.lane_results(lanes)
+    n_ok = int((first == zk.NO_FAIL).sum())
+    assert ev.counts() == (n_ok, lanes - n_ok)
+    ref = oracle_lane(mod_le, rows_i[0], rows_w[0], [rel], 32, trace=False)
+    if not ref.violations:
+        for wid in range(0, 60):
+            want = ref.get(wid)
+            got = ev.get(wid, lanes)
+            assert (want is None) == (got is None), (seed, wid)
+            if want is not None:
+                assert got[0] == want, (seed, wid)
+
+
+@pytest.mark.gpu
+def test_full_size_c2_streamed_matches_the_committed_oracle_digests():
+    """BASELINE configs[1] ingested as a stream (11 messages, windows of 131072 recorded calls scheduled and uploaded
+    while the next messages are parsed): the 64 output wires of the six digest lanes are the oracle's, bit for bit."""
+    import hashlib
+    import json
+    import os
+    from helpers import ROOT
+    fx = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'c2_digests.json')))
+    wl = workloads.ArithLayered()
+    batch = 1024
+    inst, wit = wl.inputs(batch)
+    ev = _streamed(wl.relation_messages(with_epilogue=False, free_last=False), wl.n_instance0, wl.n_witness, 1)
+    ev.finalize()
+    sinfo = ev.stream_info()
+    assert sinfo['windows'] == 9 and sinfo['streamed_windows'] == 9
+    ev.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), batch)
+    ev.replay()
+    ev.synchronize()
+    cols = [ev.get(w, batch) for w in wl.output_wire_ids()]
+    for lane, want in fx['lanes'].items():
+        vals = [col[int(lane)] for col in cols]
+        assert hashlib.sha256('\n'.join(str(v) for v in vals).encode()).hexdigest() == want['sha256'], lane

@@ -63,6 +63,7 @@ def lib():
         'zkgpu_backend_instance': (ci, [vp, u32, u32p]),
         'zkgpu_backend_witness': (ci, [vp, u32, u32p]),
         'zkgpu_backend_drop': (ci, [vp, u32]),
+        'zkgpu_stream_info': (ci, [vp, ctypes.POINTER(ctypes.c_double)]),
         'zkgpu_backend_ladder': (ci, [vp, u64, u32, u32]),
         'zkgpu_ingest_messages': (ci, [vp, u8p, sz]),
         'zkgpu_ingest_paths': (ci, [vp, ctypes.POINTER(ctypes.c_char_p), sz]),
@@ -340,6 +341,11 @@ class Evaluator:
     @property
     def n_witness(self):
         return self.L.zkgpu_n_witness(self.h)
+
+    def stream_info(self):
+        out = (ctypes.c_double * 3)()
+        self._ck(self.L.zkgpu_stream_info(self.h, out))
+        return {'windows': int(out[0]), 'streamed_windows': int(out[1]), 'worker_busy_s': float(out[2])}
 
     def schedule_info(self):
         out = (ctypes.c_uint64 * 8)()

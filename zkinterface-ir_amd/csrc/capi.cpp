@@ -3,7 +3,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -18,12 +23,41 @@
 
 using namespace zki;
 
+// One tape window handed from the recording thread to the scheduling thread: its own copy of the ops (the tape's
+// vectors keep growing -- and moving -- while the window is scheduled).
+struct WindowJob {
+  uint32_t lo = 0, hi = 0;
+  std::vector<uint8_t> kind;
+  std::vector<uint32_t> a, b, drops, pinned;
+  std::vector<Tape::Ladder> ladders;
+  bool final = false;
+};
+
+// Streaming ingest (option "stream"): the recording thread cuts the tape into windows (tape.hpp `cuts`); a worker
+// schedules each window as soon as it is complete and sends its program entries to the GPU, while the caller is still
+// parsing the following messages (the reference consumes a relation message by message too, evaluator.rs:286-301).
+struct StreamState {
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<WindowJob> jobs;
+  bool quit = false, idle = true;
+  std::string error;
+  std::unique_ptr<StreamScheduler> sched;
+  uint32_t next_lo = 0;
+  size_t drop_at = 0, ladder_at = 0;
+  uint32_t windows_done = 0;
+  double busy_s = 0;     // time the worker spent scheduling + uploading
+  bool upload = true;    // send finished windows to the GPU (switched off when no GPU can be opened)
+};
+
 struct zkgpu_session {
   TapeBackend backend;
   Evaluator<TapeBackend> ev;
   std::unique_ptr<Engine> engine;
   Schedule sched;
   bool finalized = false;
+  bool engine_loaded = false;   // the engine holds the finished program (a streamed ingest opens the engine earlier)
   bool used_evaluator = false;  // messages went through the bundled Evaluator (zkgpu_ingest_* / declare_inputs)
   bool retain_all = false;
   uint32_t declared_inst = 0, declared_wit = 0;
@@ -39,6 +73,11 @@ struct zkgpu_session {
   int graph_mode = 0;
   uint32_t level_ops_per_wave = 1;
   uint32_t hot_waves = 0;
+  uint32_t stream_window = 0;        // option "stream": tape entries per window, 0 = schedule everything at finalize
+  uint32_t sched_threads = 0;
+  std::unique_ptr<StreamState> stream;
+  double stream_busy_s = 0;
+  uint32_t stream_windows = 0;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
   bool r1cs_ready = false, r1cs_on_device = false, r1cs_loaded_csr = false;
@@ -53,7 +92,19 @@ struct zkgpu_session {
   std::vector<uint32_t> first_fail, flags;
   std::vector<uint32_t> value_op_index;  // k-th value-returning call -> tape index
   bool results_fresh = false;
+  ~zkgpu_session();
 };
+
+zkgpu_session::~zkgpu_session() {
+  if (stream) {
+    {
+      std::lock_guard<std::mutex> g(stream->mu);
+      stream->quit = true;
+    }
+    stream->cv.notify_all();
+    if (stream->worker.joinable()) stream->worker.join();
+  }
+}
 
 namespace {
 
@@ -78,23 +129,140 @@ uint32_t lane_inputs(const zkgpu_session* s, bool instance) {
                   : std::max<uint32_t>(t.n_witness, std::max<uint32_t>(s->declared_wit, (uint32_t)s->backend.lane0_witnesses().size()));
 }
 
+ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
+  ScheduleOptions opt;
+  opt.retain_all = retain_all;
+  opt.sort_by_operand = s->sort_by_operand;
+  opt.pair = s->pair;
+  opt.fermat = s->fermat;
+  opt.fuse = s->fuse;
+  opt.propagate_copies = s->propagate_copies;
+  opt.threads = s->sched_threads;
+  return opt;
+}
+
+void configure_engine(zkgpu_session* s, Engine* e) {
+  e->set_bool_path(s->bool_path);
+  e->set_lane_group(s->lane_group);
+  e->set_streams(s->n_streams);
+  e->set_xcd_map(s->xcd_map);
+  e->set_graph_mode(s->graph_mode);
+  e->set_level_ops_per_wave(s->level_ops_per_wave);
+  e->set_hot_waves(s->hot_waves);
+}
+
+// ---- streaming ingest ------------------------------------------------------------------------------
+void stream_worker(zkgpu_session* s) {
+  StreamState& st = *s->stream;
+  for (;;) {
+    WindowJob job;
+    {
+      std::unique_lock<std::mutex> lk(st.mu);
+      st.idle = st.jobs.empty();
+      if (st.idle) st.cv.notify_all();
+      st.cv.wait(lk, [&] { return st.quit || !st.jobs.empty(); });
+      if (st.jobs.empty()) return;  // quit
+      job = std::move(st.jobs.front());
+      st.jobs.pop_front();
+      st.idle = false;
+    }
+    if (!st.error.empty()) continue;  // an earlier window failed: drain
+    const auto t0 = std::chrono::steady_clock::now();
+    try {
+      TapeWindow w;
+      w.lo = job.lo;
+      w.hi = job.hi;
+      w.kind = job.kind.data();
+      w.a = job.a.data();
+      w.b = job.b.data();
+      w.drops = job.drops.data();
+      w.n_drops = job.drops.size();
+      w.ladders = job.ladders.data();
+      w.n_ladders = job.ladders.size();
+      w.final = job.final;
+      w.pinned = &job.pinned;
+      const WindowResult r = st.sched->add_window(w);
+      if (st.upload) {
+        // the window's entries go to HBM now; without a GPU (the CPU test tier) they are sent by the first replay call
+        try {
+          if (!s->engine) s->engine.reset(new Engine());
+        } catch (const std::exception&) {
+          st.upload = false;
+        }
+        if (st.upload) {
+          const Schedule& p = st.sched->partial();
+          if (p.fused) s->engine->upload_window(p.ops2.data() + r.first_op, r.n_ops, sizeof(DevOp2));
+          else s->engine->upload_window(p.ops.data() + r.first_op, r.n_ops, sizeof(DevOp));
+        }
+      }
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> g(st.mu);
+      st.error = e.what();
+    }
+    st.busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ++st.windows_done;
+  }
+}
+
+// the tape ops [next_lo, hi) as a job of their own (runs on the recording thread)
+void stream_enqueue(zkgpu_session* s, uint32_t hi, bool final) {
+  StreamState& st = *s->stream;
+  const Tape& t = s->backend.tape();
+  WindowJob job;
+  job.lo = st.next_lo;
+  job.hi = hi;
+  job.final = final;
+  job.kind.assign(t.kind.begin() + job.lo, t.kind.begin() + hi);
+  job.a.assign(t.a.begin() + job.lo, t.a.begin() + hi);
+  job.b.assign(t.b.begin() + job.lo, t.b.begin() + hi);
+  size_t d1 = st.drop_at;
+  while (d1 < t.drop_pos.size() && t.drop_pos[d1] <= hi) ++d1;
+  job.drops.assign(t.drop_handle.begin() + st.drop_at, t.drop_handle.begin() + d1);
+  st.drop_at = d1;
+  size_t l1 = st.ladder_at;
+  while (l1 < t.ladders.size() && t.ladders[l1].result < hi) ++l1;
+  job.ladders.assign(t.ladders.begin() + st.ladder_at, t.ladders.begin() + l1);
+  st.ladder_at = l1;
+  if (final) s->ev.values().for_each([&](WireId, const TapeWire& w) { job.pinned.push_back(w.h); });
+  st.next_lo = hi;
+  {
+    std::lock_guard<std::mutex> g(st.mu);
+    st.jobs.push_back(std::move(job));
+    st.idle = false;
+  }
+  st.cv.notify_all();
+}
+
+// TapeBackend's cut hook: a window of the tape is complete
+void stream_cut(void* arg) {
+  zkgpu_session* s = (zkgpu_session*)arg;
+  if (s->backend.field().is_two) return;  // GF(2) programs are scheduled and encoded as a whole (LDS-resident kernel)
+  if (!s->stream) {
+    s->stream.reset(new StreamState());
+    s->stream->sched.reset(new StreamScheduler(s->backend.field(), schedule_options(s, false)));
+    s->stream->worker = std::thread(stream_worker, s);
+  }
+  stream_enqueue(s, s->backend.tape().cuts.back(), false);
+}
+
+void stream_wait(zkgpu_session* s) {
+  StreamState& st = *s->stream;
+  std::unique_lock<std::mutex> lk(st.mu);
+  st.cv.wait(lk, [&] { return st.jobs.empty() && st.idle; });
+}
+
 // The engine (and with it the HIP runtime / a GPU) is only touched by the
 // replay entry points; recording and scheduling are host work.
 void need_engine(zkgpu_session* s) {
   if (!s->finalized) throw std::runtime_error("zkgpu_finalize() has not been called");
-  if (!s->engine) {
-    std::unique_ptr<Engine> e(new Engine());
-    e->set_bool_path(s->bool_path);
+  if (!s->engine || !s->engine_loaded) {
+    std::unique_ptr<Engine> e = s->engine ? std::move(s->engine) : std::unique_ptr<Engine>(new Engine());  // a streamed ingest opened it already
+    configure_engine(s, e.get());
     e->set_writeback(s->n_pinned != 0);
     e->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
-    e->set_lane_group(s->lane_group);
-    e->set_streams(s->n_streams);
-    e->set_xcd_map(s->xcd_map);
-    e->set_graph_mode(s->graph_mode);
-    e->set_level_ops_per_wave(s->level_ops_per_wave);
-    e->set_hot_waves(s->hot_waves);
     if (s->r1cs_extra_vars) e->reserve_extra_slots(s->r1cs_extra_vars);
     s->engine = std::move(e);
+    s->engine_loaded = true;
   }
 }
 
@@ -414,26 +582,59 @@ size_t zkgpu_constant_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out
 int zkgpu_finalize(zkgpu_session* s, int retain_all) {
   return guarded(s, [&] {
     if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
-    ScheduleOptions opt;
-    opt.retain_all = retain_all != 0;
-    opt.sort_by_operand = s->sort_by_operand;
-    opt.pair = s->pair;
-    opt.fermat = s->fermat;
-    opt.fuse = s->fuse;
-    opt.propagate_copies = s->propagate_copies;
+    ScheduleOptions opt = schedule_options(s, retain_all != 0);
     s->ev.values().for_each([&](WireId, const TapeWire& w) { opt.pinned.push_back(w.h); });
     s->n_pinned = opt.pinned.size();
-    s->sched = build_schedule(s->backend.tape(), s->backend.field(), opt);
-    s->retain_all = opt.retain_all;
     const Tape& t = s->backend.tape();
+    if (s->stream && !opt.retain_all && !s->finalized) {
+      // the windows scheduled while the messages were coming in + the rest of the tape as the final window
+      stream_enqueue(s, (uint32_t)t.size(), true);
+      stream_wait(s);
+      if (!s->stream->error.empty()) throw std::runtime_error("streamed scheduling failed: " + s->stream->error);
+      s->sched = s->stream->sched->finish(t.consts);
+      s->stream_busy_s = s->stream->busy_s;
+      s->stream_windows = s->stream->windows_done;
+      {
+        std::lock_guard<std::mutex> g(s->stream->mu);
+        s->stream->quit = true;
+      }
+      s->stream->cv.notify_all();
+      s->stream->worker.join();
+      s->stream.reset();
+    } else {
+      if (s->stream) {  // retain_all (or a second finalize): the streamed program is of no use, schedule the tape again
+        stream_wait(s);
+        {
+          std::lock_guard<std::mutex> g(s->stream->mu);
+          s->stream->quit = true;
+        }
+        s->stream->cv.notify_all();
+        s->stream->worker.join();
+        s->stream.reset();
+      }
+      s->engine.reset();
+      // "stream" set: the same windows a streamed ingest would have scheduled (the cuts are a property of the tape)
+      s->sched = s->stream_window && !opt.retain_all ? build_schedule_windowed(t, s->backend.field(), opt)
+                                                     : build_schedule(t, s->backend.field(), opt);
+    }
+    s->backend.set_window(0, nullptr, nullptr);
+    s->retain_all = opt.retain_all;
     s->value_op_index.clear();
     for (size_t i = 0; i < t.size(); ++i)
       if (t.kind[i] != TK_ASSERT) s->value_op_index.push_back((uint32_t)i);
-    s->engine.reset();
+    s->engine_loaded = false;
     Engine::validate_program(s->sched, lane_inputs(s, true), lane_inputs(s, false));  // host check of every index the kernels use
     s->finalized = true;
     s->results_fresh = false;
   });
+}
+
+int zkgpu_stream_info(const zkgpu_session* s, double out[3]) {
+  if (!s || !s->finalized) return 1;
+  out[0] = (double)(s->sched.window_first_op.empty() ? 0 : s->sched.window_first_op.size() - 1);
+  out[1] = (double)s->stream_windows;
+  out[2] = s->stream_busy_s;
+  return 0;
 }
 
 uint32_t zkgpu_elem_bytes(const zkgpu_session* s) {
@@ -537,7 +738,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       else if (v == "hbm") s->bool_path = 1;
       else if (v == "lds") s->bool_path = 2;
       else throw std::runtime_error("bool_path must be auto, hbm or lds");
-      if (s->engine) s->engine.reset();  // re-created with the new choice on the next replay call
+      if (s->engine) { s->engine.reset(); s->engine_loaded = false; }  // re-created with the new choice on the next replay call
     } else if (k == "max_tape_ops") {
       s->backend.set_max_ops(strtoull(v.c_str(), nullptr, 10));
     } else if (k == "streams") {
@@ -546,6 +747,14 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "level_ops_per_wave") {
       s->level_ops_per_wave = (uint32_t)std::max(1, atoi(v.c_str()));
       if (s->engine) s->engine->set_level_ops_per_wave(s->level_ops_per_wave);
+    } else if (k == "stream") {
+      // tape entries per window; "1" = the default window of 131072 entries; before the first Relation message
+      if (s->backend.tape().size() || s->finalized) throw std::runtime_error("stream must be set before the first Relation message");
+      const long n = atol(v.c_str());
+      s->stream_window = n <= 0 ? 0 : n == 1 ? 131072u : (uint32_t)std::max<long>(n, 16);
+      s->backend.set_window(s->stream_window, s->stream_window ? stream_cut : nullptr, s);
+    } else if (k == "schedule_threads") {
+      s->sched_threads = (uint32_t)std::max(0, atoi(v.c_str()));
     } else if (k == "hot_waves") {
       s->hot_waves = (uint32_t)std::max(0, atoi(v.c_str()));
       if (s->engine) s->engine->set_hot_waves(s->hot_waves);
@@ -788,7 +997,7 @@ int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_p
                         uint32_t n_extra_vars) {
   return guarded(s, [&] {
     if (!s->finalized || !s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) first: variables are tape values");
-    if (s->engine) throw std::runtime_error("load the CSR before the first zkgpu_set_inputs* call (the table is sized once)");
+    if (s->engine_loaded) throw std::runtime_error("load the CSR before the first zkgpu_set_inputs* call (the table is sized once)");
     if (!row_ptr || (n_coefs && (!coef_bytes || coef_width == 0)))
       throw std::runtime_error("zkgpu_r1cs_load_csr: row_ptr / coefficient bytes missing or coef_width is 0");
     R1cs r;

@@ -103,7 +103,7 @@ Engine::Engine() {
 Engine::~Engine() {
   if (graph_exec_) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec_);
   free_batch();
-  dfree(d_ops_);
+  free_windows();
   dfree(d_consts_);
   dfree(d_counts_);
   dfree(d_lds_ops_);
@@ -202,9 +202,25 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
     if ((uint64_t)L.first + L.count > n_ops) throw std::runtime_error("Engine: a launch reaches past the program");
 }
 
+void Engine::free_windows() {
+  for (void*& p : d_windows_) dfree(p);
+  d_windows_.clear();
+  window_entries_.clear();
+  window_entry_bytes_ = 0;
+}
+
+void Engine::upload_window(const void* entries, uint64_t n_entries, size_t entry_bytes) {
+  if (!d_windows_.empty() && entry_bytes != window_entry_bytes_) throw std::runtime_error("Engine: program windows of two entry formats");
+  window_entry_bytes_ = entry_bytes;
+  void* d = nullptr;
+  HIP_OK(hipMalloc(&d, std::max<size_t>(n_entries * entry_bytes, 64)));
+  if (n_entries) HIP_OK(hipMemcpy(d, entries, n_entries * entry_bytes, hipMemcpyHostToDevice));
+  d_windows_.push_back(d);
+  window_entries_.push_back(n_entries);
+}
+
 void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness) {
   free_batch();
-  dfree(d_ops_);
   dfree(d_consts_);
   dfree(d_lds_ops_);
   dfree(d_launches_);
@@ -237,12 +253,17 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   memset(field_params_, 0, sizeof field_params_);
   memcpy(field_params_, &fp, sizeof fp);
   validate_program(s, n_instance, n_witness);
-  if (s.fused) {
-    HIP_OK(hipMalloc(&d_ops_, s.ops2.size() * sizeof(DevOp2)));
-    HIP_OK(hipMemcpy(d_ops_, s.ops2.data(), s.ops2.size() * sizeof(DevOp2), hipMemcpyHostToDevice));
-  } else if (!s.ops.empty()) {
-    HIP_OK(hipMalloc(&d_ops_, s.ops.size() * sizeof(DevOp)));
-    HIP_OK(hipMemcpy(d_ops_, s.ops.data(), s.ops.size() * sizeof(DevOp), hipMemcpyHostToDevice));
+  {
+    // program entries window by window; windows a streamed ingest has already sent stay where they are
+    const size_t eb = s.fused ? sizeof(DevOp2) : sizeof(DevOp);
+    const uint8_t* host = s.fused ? (const uint8_t*)s.ops2.data() : (const uint8_t*)s.ops.data();
+    const size_t n_win = s.window_first_op.empty() ? 0 : s.window_first_op.size() - 1;
+    bool keep = !d_windows_.empty() && d_windows_.size() <= n_win && window_entry_bytes_ == eb;
+    for (size_t w = 0; keep && w < d_windows_.size(); ++w)
+      keep = window_entries_[w] == s.window_first_op[w + 1] - s.window_first_op[w];
+    if (!keep) free_windows();
+    for (size_t w = d_windows_.size(); w < n_win; ++w)
+      upload_window(host + s.window_first_op[w] * eb, s.window_first_op[w + 1] - s.window_first_op[w], eb);
   }
   const size_t cbytes = std::max<size_t>(s.const_words.size() * 4, 64);
   HIP_OK(hipMalloc(&d_consts_, cbytes));
@@ -473,10 +494,13 @@ void Engine::use_device_inputs(const void* d_inst, const void* d_wit) {
 
 void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const DevOp* ops = (const DevOp*)d_ops_;
   zkgpu::FieldParams fp;
   memcpy(&fp, field_params_, sizeof fp);
   const Launch& L = sched_.launches[li];
+  // entries of the launch: in the device buffer of its tape window
+  const uint64_t in_window = L.first - sched_.window_first_op[L.window];
+  const zkgpu::TapeOp* ops1 = (const zkgpu::TapeOp*)d_windows_[L.window] + in_window;
+  const zkgpu::TapeOp2* ops2 = (const zkgpu::TapeOp2*)d_windows_[L.window] + in_window;
   // Wide levels of the fused program walk two ops per wave: half as many waves to dispatch, same registers
   // (measured on C2: 9.83 -> 9.48 ms; three or more per wave lose again to the shorter grid).
   const uint32_t opw = (sched_.fused && !boolean_ && !L.sequential && L.count >= 1024 * level_ops_per_wave_) ? level_ops_per_wave_ : L.ops_per_wave;
@@ -489,7 +513,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   if (boolean_) {
     zkgpu::BoolReplayArgs a;
     memset(&a, 0, sizeof a);
-    a.ops = (const zkgpu::TapeOp*)(ops + L.first);
+    a.ops = ops1;
     a.n_ops = L.count;
     a.ops_per_wave = L.ops_per_wave;
     a.table = (zkgpu::u64*)d_table_;
@@ -507,7 +531,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   if (sched_.fused) {
     zkgpu::ReplayArgs2 a;
     memset(&a, 0, sizeof a);
-    a.ops = (const zkgpu::TapeOp2*)d_ops_ + L.first;
+    a.ops = ops2;
     a.n_ops = L.count;
     a.ops_per_wave = opw;
     a.table = (uint4*)d_table_;
@@ -533,7 +557,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
       if (!count) return;
       const uint32_t w = (wide && count >= 1024 * level_ops_per_wave_) ? level_ops_per_wave_ : 1;
       const uint32_t nchunks = ((count + w - 1) / w + 3) / 4;
-      a.ops = (const zkgpu::TapeOp2*)d_ops_ + L.first + first;
+      a.ops = ops2 + first;
       a.n_ops = count;
       a.ops_per_wave = w;
       a.op_stride = w == 1 ? 1 : 4;
@@ -548,7 +572,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   }
   zkgpu::ReplayArgs a;
   memset(&a, 0, sizeof a);
-  a.ops = (const zkgpu::TapeOp*)(ops + L.first);
+  a.ops = ops1;
   a.n_ops = L.count;
   a.ops_per_wave = L.ops_per_wave;
   a.table = (uint4*)d_table_;

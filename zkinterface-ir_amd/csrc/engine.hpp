@@ -25,6 +25,11 @@ class Engine {
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
 
+  // Streaming ingest: the program entries of one tape window, sent to HBM while later windows are still being
+  // parsed and scheduled.  `entries` = DevOp2 (fused format) or DevOp records; windows arrive in order.  A following
+  // load_program() of the finished schedule keeps what was sent (it must be the same windows) and sends the rest.
+  void upload_window(const void* entries, uint64_t n_entries, size_t entry_bytes);
+  size_t windows_uploaded() const { return d_windows_.size(); }
   // Upload the program.  n_instance / n_witness = values per witness stream.
   static void validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness);
   void load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness);
@@ -111,7 +116,10 @@ class Engine {
   void* ev_begin_ = nullptr;
   void* ev_end_ = nullptr;
   std::vector<void*> launch_events_;
-  void* d_ops_ = nullptr;
+  std::vector<void*> d_windows_;            // program entries, one device buffer per tape window
+  std::vector<uint64_t> window_entries_;    // entries in each
+  size_t window_entry_bytes_ = 0;
+  void free_windows();
   void* d_consts_ = nullptr;
   void* d_table_ = nullptr;
   void* d_first_fail_ = nullptr;

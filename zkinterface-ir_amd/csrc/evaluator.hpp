@@ -260,7 +260,7 @@ class Evaluator {
     if (e.exponent.zero) throw Panic("exponent 0 never reaches 1 (modulus 1)");  // unbounded recursion in the reference
     const size_t mark = ladder_begin(e.backend, 0);
     Wire base_to_exp = exp(e, base, 0);
-    if (!e.is_boolean) ladder_end(e.backend, mark, base, base_to_exp, 0);  // base_to_exp = base^(modulus - 1)
+    ladder_end(e.backend, mark, base, base_to_exp, 0);  // base_to_exp = base^(modulus - 1) -- by `and`s under is_boolean: the backend's call what to make of it
     Wire right = as_negate(e, base_to_exp);
     return as_add_one(e, right);
   }

@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 namespace zki {
 namespace {
@@ -19,10 +21,6 @@ inline int n_inputs(uint8_t k) {
 
 constexpr uint32_t kInf = 0xFFFFFFFFu;
 
-}  // namespace
-
-namespace {
-
 // Depth-first walk of the "reads the same wire" graph of one level: ops become neighbours of an op they
 // share an operand with, so the second reader of a wire runs while the first reader's fetch is still in
 // the XCD's L2 (device/replay_kernels.hpp block_coords keeps the ops of a lane block on one XCD).  On the
@@ -34,7 +32,6 @@ void locality_order(uint32_t* ops, size_t cnt, Gathered&& gathered) {
   };
   std::vector<Edge> edges;
   edges.reserve(cnt * 2);
-  std::vector<uint32_t> first_edge(cnt + 1, 0);
   for (size_t p = 0; p < cnt; ++p) {
     uint32_t w[4];
     const int k = gathered(ops[p], w);
@@ -79,22 +76,109 @@ void locality_order(uint32_t* ops, size_t cnt, Gathered&& gathered) {
   for (size_t p = 0; p < cnt; ++p) ops[p] = out[p];
 }
 
+// run f(l) for l in [0, n) on up to `threads` threads
+template <class F>
+void parallel_levels(uint32_t n, uint32_t threads, F&& f) {
+  if (threads <= 1 || n <= 1) {
+    for (uint32_t l = 0; l < n; ++l) f(l);
+    return;
+  }
+  std::atomic<uint32_t> next(0);
+  auto work = [&] {
+    for (;;) {
+      const uint32_t l = next.fetch_add(1);
+      if (l >= n) return;
+      f(l);
+    }
+  };
+  std::vector<std::thread> pool;
+  const uint32_t extra = std::min(threads, n) - 1;
+  for (uint32_t t = 0; t < extra; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+}
+
+enum : uint8_t {  // per-op state inside a window
+  ST_ENTRY = 0,        // own program entry
+  ST_FUSED = 1,        // evaluated inside its only reader
+  ST_ELIDED = 2,       // no entry, no slot: propagated copy, dropped ladder op
+  ST_PAIR_SHARED = 3,  // shared producer of a pair entry
+  ST_PAIR_SECOND = 4,  // second value of a pair entry (has a slot, no entry of its own)
+};
+enum : uint8_t { FL_DROPPED = 1, FL_PINNED = 2 };
+
 }  // namespace
 
-namespace {
+struct StreamScheduler::Impl {
+  FieldHost field;
+  ScheduleOptions opt;
+  Schedule s;
+  uint32_t threads = 1;
+  int prime = -1;  // primality of the characteristic: -1 not tested yet
+
+  // per handle, over the whole tape seen so far
+  std::vector<uint32_t> root;      // source of the copy chain a propagated copy belongs to (itself otherwise)
+  std::vector<uint32_t> last_use;  // global level of the last reader known so far
+  std::vector<uint8_t> flags;
+  std::vector<uint32_t> open_list;   // values with a slot that may still get readers
+  std::vector<uint32_t> free_slots;
+  uint32_t n_slots = 0;
+  uint32_t n_windows = 0;
+
+  // the window being scheduled (arrays indexed by handle - lo)
+  uint32_t lo = 0, hi = 0, base = 0;
+  bool final = false;
+  std::vector<uint8_t> kind, state;
+  std::vector<uint32_t> ra, rb;          // operands resolved through copy chains (handles)
+  std::vector<uint32_t> pair_second;     // first gate of a pair entry -> second gate
+  std::vector<uint32_t> order;           // live entries in program order
+  std::vector<uint64_t> level_start;
+  uint32_t n_wlevels = 0;
+
+  bool closed(uint32_t h) const { return (flags[h] & FL_DROPPED) || (final && !(flags[h] & FL_PINNED)); }
+  uint8_t& st(uint32_t h) { return state[h - lo]; }
+  uint8_t st(uint32_t h) const { return state[h - lo]; }
+  bool inner(uint32_t h) const { return h >= lo && (state[h - lo] == ST_FUSED || state[h - lo] == ST_PAIR_SHARED); }
+
+  void grow(uint32_t n);
+  void rewrite_ladders(const TapeWindow& w);
+  void propagate_copies();
+  void levelise();
+  void fuse_and_pair();
+  void order_by_level();
+  void assign_slots();
+  void order_levels();
+  int gathered(uint32_t i, uint32_t out[4]) const;
+  void emit_entries();
+  void emit_launches();
+};
+
+void StreamScheduler::Impl::grow(uint32_t n) {
+  const uint32_t old = (uint32_t)root.size();
+  if (n <= old) return;
+  root.resize(n);
+  for (uint32_t i = old; i < n; ++i) root[i] = i;
+  last_use.resize(n, 0);
+  flags.resize(n, 0);
+  s.slot_of.resize(n, kNoWire);
+  s.level_of.resize(n, 0);
+}
 
 // Switch weights are 1 - (case - cond)^(p-1) (evaluator.rs:823-839); the reference computes the power with a
 // square-and-multiply ladder (bits(p) squarings + popcount(p-1) multiplies: 352 dependent products at BN254, each of
 // them a level of its own).  For a prime p Fermat gives x^(p-1) = 1 for x != 0 and 0 for x = 0, so in the production
 // schedule the ladder's result becomes one entry `x != 0` and the ladder's own ops are dropped.  Only done when the
-// characteristic passes the primality test (sieve/bignum.cpp) and nothing outside a ladder reads its intermediates.
-bool rewrite_ladders(const Tape& in, const FieldHost& field, Tape* out, uint64_t* n_done) {
-  if (in.ladders.empty()) return false;
-  Value p_le;
-  for (uint32_t i = 0; i < field.nwords; ++i)
-    for (int b = 0; b < 4; ++b) p_le.push_back((uint8_t)(field.p[i] >> (8 * b)));
-  if (!is_probably_prime(p_le)) return false;
-  const size_t n = in.size();
+// characteristic passes the primality test (sieve/bignum.cpp), the range IS the reference's recursion, and nothing
+// outside the ladder reads or can still read its intermediates.
+void StreamScheduler::Impl::rewrite_ladders(const TapeWindow& w) {
+  if (!w.n_ladders || !opt.fermat || opt.retain_all || field.is_two) return;
+  if (prime < 0) {
+    Value p_le;
+    for (uint32_t i = 0; i < field.nwords; ++i)
+      for (int b = 0; b < 4; ++b) p_le.push_back((uint8_t)(field.p[i] >> (8 * b)));
+    prime = is_probably_prime(p_le) ? 1 : 0;
+  }
+  if (!prime) return;
   // bits of the exponent p - 1 (p is odd: clear bit 0)
   uint32_t e[kFieldWords];
   for (int i = 0; i < kFieldWords; ++i) e[i] = i < (int)field.nwords ? field.p[i] : 0;
@@ -102,531 +186,594 @@ bool rewrite_ladders(const Tape& in, const FieldHost& field, Tape* out, uint64_t
   int top_bit = -1;
   for (int i = 32 * kFieldWords - 1; i >= 0 && top_bit < 0; --i)
     if ((e[i / 32] >> (i % 32)) & 1) top_bit = i;
-  if (top_bit < 0) return false;
+  if (top_bit < 0) return;
+  auto K = [&](uint32_t h) { return w.kind[h - lo]; };
+  auto A = [&](uint32_t h) { return w.a[h - lo]; };
+  auto B = [&](uint32_t h) { return w.b[h - lo]; };
   // A hint is only a hint (zkgpu_backend_ladder is a public entry): the range must BE the reference's
   // square-and-multiply recursion over p - 1 (evaluator.rs:801-820) -- copy(base), then from the second highest bit
   // down a squaring of the running value and, where the bit is set, a multiply by the base -- or it stays as recorded.
   auto is_ladder = [&](const Tape::Ladder& L) {
-    if (L.result >= n || L.first > L.result || L.base >= L.first) return false;
+    if (L.first < lo || L.result >= hi || L.first > L.result || L.base >= L.first) return false;
     uint32_t cur = L.first;
-    if (in.kind[cur] != TK_COPY || in.a[cur] != L.base) return false;
+    if (K(cur) != TK_COPY || A(cur) != L.base) return false;
     for (int shift = top_bit - 1; shift >= 0; --shift) {
-      if (++cur > L.result || in.kind[cur] != TK_MUL || in.a[cur] != cur - 1 || in.b[cur] != cur - 1) return false;
+      if (++cur > L.result || K(cur) != TK_MUL || A(cur) != cur - 1 || B(cur) != cur - 1) return false;
       if ((e[shift / 32] >> (shift % 32)) & 1) {
-        if (++cur > L.result || in.kind[cur] != TK_MUL) return false;
-        const bool ab = in.a[cur] == cur - 1 && in.b[cur] == L.base, ba = in.a[cur] == L.base && in.b[cur] == cur - 1;
+        if (++cur > L.result || K(cur) != TK_MUL) return false;
+        const bool ab = A(cur) == cur - 1 && B(cur) == L.base, ba = A(cur) == L.base && B(cur) == cur - 1;
         if (!ab && !ba) return false;
       }
     }
     return cur == L.result;
   };
+  const uint32_t n = hi - lo;
   std::vector<uint32_t> owner(n, kInf);  // ladder whose intermediate this op is
-  std::vector<uint8_t> ok(in.ladders.size(), 1);
-  for (size_t l = 0; l < in.ladders.size(); ++l) {
-    const Tape::Ladder& L = in.ladders[l];
+  std::vector<uint8_t> ok(w.n_ladders, 1);
+  for (size_t l = 0; l < w.n_ladders; ++l) {
+    const Tape::Ladder& L = w.ladders[l];
     if (!is_ladder(L)) { ok[l] = 0; continue; }
     for (uint32_t i = L.first; i <= L.result; ++i) {
-      if (owner[i] != kInf) {  // two hints over one op: neither is trusted, the first keeps the op
+      if (owner[i - lo] != kInf) {  // two hints over one op: neither is trusted, the first keeps the op
         ok[l] = 0;
-        ok[owner[i]] = 0;
+        ok[owner[i - lo]] = 0;
       } else {
-        owner[i] = (uint32_t)l;
+        owner[i - lo] = (uint32_t)l;
       }
+      if (i < L.result && !closed(i)) ok[l] = 0;  // a later window could still read the intermediate
     }
   }
   // the result is the one value others may read
-  for (size_t l = 0; l < in.ladders.size(); ++l)
-    if (in.ladders[l].result < n && owner[in.ladders[l].result] == l) owner[in.ladders[l].result] = kInf;
-  for (size_t j = 0; j < n; ++j) {
-    const int ni = n_inputs(in.kind[j]);
+  for (size_t l = 0; l < w.n_ladders; ++l) {
+    const uint32_t r = w.ladders[l].result;
+    if (r >= lo && r < hi && owner[r - lo] == l) owner[r - lo] = kInf;
+  }
+  for (uint32_t j = lo; j < hi; ++j) {
+    const int ni = n_inputs(K(j));
     for (int k = 0; k < ni; ++k) {
-      const uint32_t src = k == 0 ? in.a[j] : in.b[j];
-      if (src >= n || owner[src] == kInf) continue;
-      const Tape::Ladder& L = in.ladders[owner[src]];
-      if (j < L.first || j > L.result) ok[owner[src]] = 0;  // read from outside the ladder
+      const uint32_t src = k == 0 ? A(j) : B(j);
+      if (src < lo || src >= hi || owner[src - lo] == kInf) continue;
+      const Tape::Ladder& L = w.ladders[owner[src - lo]];
+      if (j < L.first || j > L.result) ok[owner[src - lo]] = 0;  // read from outside the ladder
     }
   }
-  bool any = false;
-  for (size_t l = 0; l < in.ladders.size(); ++l) any = any || ok[l];
-  if (!any) return false;
-  out->kind = in.kind;
-  out->a = in.a;
-  out->b = in.b;
-  out->assert_op = in.assert_op;
-  out->assert_wire = in.assert_wire;
-  out->consts = in.consts;
-  out->n_instance = in.n_instance;
-  out->n_witness = in.n_witness;
-  out->n_value_ops = in.n_value_ops;
-  for (size_t l = 0; l < in.ladders.size(); ++l) {
+  for (size_t l = 0; l < w.n_ladders; ++l) {
     if (!ok[l]) continue;
-    const Tape::Ladder& L = in.ladders[l];
-    for (uint32_t i = L.first; i < L.result; ++i) out->kind[i] = TK_NOP;
-    out->kind[L.result] = TK_NZ;
-    out->a[L.result] = L.base;
-    out->b[L.result] = 0;
-    ++*n_done;
-  }
-  return true;
-}
-
-}  // namespace
-
-namespace {
-
-// The stages of build_schedule(): one object holds the working arrays, one method per stage, run in this order.
-struct ScheduleBuilder {
-  const Tape& tape;
-  const FieldHost& field;
-  const ScheduleOptions& opt;
-  Schedule s;
-  size_t n = 0;
-  std::vector<uint8_t> const_odd;       // GF(2): parity of every constant
-  uint32_t bool_zero_const = 0;         // GF(2): index of the synthetic constant 0
-  std::vector<uint32_t> opa, opb;       // operands resolved through copy chains
-  std::vector<uint8_t> absorbed;        // 0 = own entry; 1 = evaluated inside its reader (fusion); 2 = elided (copy, dropped
-                                        // ladder op); 3 = shared producer of a pair entry; 4 = second value of a pair entry
-  std::vector<uint32_t> first_use, last_use;
-  uint32_t n_levels = 0;
-  std::vector<uint32_t> pair_second;    // first gate of a pair entry -> second gate (allocated when pairing runs)
-  std::vector<uint32_t> order;          // entries in program order
-  std::vector<uint64_t> level_start;    // level l = order[level_start[l] .. level_start[l + 1])
-  size_t n_live = 0;
-
-  ScheduleBuilder(const Tape& t, const FieldHost& f, const ScheduleOptions& o) : tape(t), field(f), opt(o) {}
-
-  void device_constants();
-  void propagate_copies();
-  void levelise();
-  void fuse_and_pair();
-  void order_by_level();
-  int gathered(uint32_t i, uint32_t out[4]) const;
-  void assign_slots();
-  void emit_entries();
-  void emit_launches();
-};
-
-void ScheduleBuilder::device_constants() {
-  // ---- constant pool in device form -------------------------------------
-  const uint32_t n_consts = (uint32_t)tape.consts.size();
-  const_odd.assign(n_consts, 0);
-  bool_zero_const = 0;
-  if (s.boolean_path) {
-    s.words_per_const = 1;
-    s.const_words.resize(n_consts + 1);
-    for (uint32_t i = 0; i < n_consts; ++i) {
-      const Value& v = tape.consts[i];
-      const_odd[i] = !v.empty() && (v[0] & 1);  // value mod 2
-      s.const_words[i] = const_odd[i];
-    }
-    bool_zero_const = n_consts;  // synthetic 0 for mul_constant by an even constant
-    s.const_words[n_consts] = 0;
-  } else {
-    s.words_per_const = field.nwords;
-    s.const_words.assign((size_t)n_consts * field.nwords, 0);
-    for (uint32_t i = 0; i < n_consts; ++i) {
-      uint32_t r[kFieldWords], m[kFieldWords];
-      field.reduce(tape.consts[i], r);
-      field.to_mont(r, m);
-      memcpy(&s.const_words[(size_t)i * field.nwords], m, 4 * field.nwords);
-    }
+    const Tape::Ladder& L = w.ladders[l];
+    for (uint32_t i = L.first; i < L.result; ++i) kind[i - lo] = TK_NOP;
+    kind[L.result - lo] = TK_NZ;
+    ra[L.result - lo] = L.base;  // resolved through copy chains below, like any operand
+    rb[L.result - lo] = 0;
+    ++s.n_ladders;
   }
 }
 
-void ScheduleBuilder::propagate_copies() {
-  // ---- copy propagation ------------------------------------------------------
+void StreamScheduler::Impl::propagate_copies() {
   // The reference's scoping (ingest_subcircuit, evaluator.rs:698-746) copies every input into and every
   // output out of a call / loop body / switch branch: about half of the backend calls of a structured
   // relation are copies.  A copy has the value of its source, so readers are pointed at the source and a
   // copy nobody can observe any more is not materialised.  Copies that must stay
-  // readable (retain_all dumps, wires alive at the end) are kept.
-  opa = tape.a;
-  opb = tape.b;
-  absorbed.assign(n, 0);
-  for (size_t i = 0; i < n; ++i)
-    if (tape.kind[i] == TK_NOP) absorbed[i] = 2;  // dropped ladder ops: no entry, no slot, read nothing
+  // readable (retain_all dumps, wires alive at the end, wires that later windows may still read) are kept.
   const bool propagate = opt.propagate_copies && !opt.retain_all;
-  if (propagate) {
-    std::vector<uint8_t> is_pinned(n, 0);
-    for (uint32_t h : opt.pinned)
-      if (h < n) is_pinned[h] = 1;
-    std::vector<uint32_t> root(n);
-    for (size_t i = 0; i < n; ++i) {
-      root[i] = (uint32_t)i;
-      if (tape.kind[i] == TK_COPY) root[i] = root[tape.a[i]];  // source of the whole copy chain
-    }
-    for (size_t i = 0; i < n; ++i) {
-      const int ni = n_inputs(tape.kind[i]);
-      if (ni >= 1) opa[i] = root[tape.a[i]];
-      if (ni == 2) opb[i] = root[tape.b[i]];
-      if (tape.kind[i] == TK_COPY && !is_pinned[i]) {
-        absorbed[i] = 2;
-        ++s.n_copies_elided;
-      }
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint8_t k = kind[i - lo];
+    if (k == TK_NOP) { st(i) = ST_ELIDED; continue; }  // dropped ladder ops: no entry, no slot, read nothing
+    const int ni = n_inputs(k);
+    if (ni >= 1) ra[i - lo] = root[ra[i - lo]];
+    if (ni == 2) rb[i - lo] = root[rb[i - lo]];
+    if (k == TK_COPY && propagate && closed(i)) {
+      st(i) = ST_ELIDED;
+      root[i] = ra[i - lo];  // source of the whole copy chain
+      ++s.n_copies_elided;
     }
   }
 }
 
-void ScheduleBuilder::levelise() {
-  // ---- dependency levels (ASAP for ops with inputs) ----------------------
+void StreamScheduler::Impl::levelise() {
+  // ---- dependency levels (ASAP), numbered on from the previous window's last level -----------------
+  // values of earlier windows are all available before this window's first level
   std::vector<uint32_t>& level = s.level_of;
-  first_use.assign(n, kInf);
-  last_use.assign(n, 0);
+  auto lvl = [&](uint32_t h) -> int64_t { return h < lo ? (int64_t)base - 1 : (int64_t)level[h]; };
+  const uint32_t n = hi - lo;
+  std::vector<uint32_t> first_use(n, kInf);
   std::vector<uint8_t> used(n, 0);
-  for (size_t i = 0; i < n; ++i) {
-    const int ni = n_inputs(tape.kind[i]);
-    uint32_t lv = 0;
-    if (ni >= 1) lv = level[opa[i]] + 1;
-    if (ni == 2) lv = std::max(lv, level[opb[i]] + 1);
-    level[i] = lv;
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (st(i) == ST_ELIDED) continue;
+    const int ni = n_inputs(kind[i - lo]);
+    int64_t lv = base;  // sources: provisional, moved below
+    if (ni >= 1) lv = lvl(ra[i - lo]) + 1;
+    if (ni == 2) lv = std::max(lv, lvl(rb[i - lo]) + 1);
+    level[i] = (uint32_t)lv;
   }
-  // sources (constant / instance / witness) are produced as late as possible:
-  // one level before their first reader, so they do not occupy a slot early.
-  for (size_t i = 0; i < n; ++i) {
-    if (absorbed[i]) continue;  // an elided copy reads nothing
-    const int ni = n_inputs(tape.kind[i]);
-    if (ni >= 1) first_use[opa[i]] = std::min(first_use[opa[i]], level[i]);
-    if (ni == 2) first_use[opb[i]] = std::min(first_use[opb[i]], level[i]);
+  // sources (constant / instance / witness) are produced as late as possible: one level before their first
+  // reader in the window, so they do not occupy a slot early
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (st(i) == ST_ELIDED) continue;
+    const int ni = n_inputs(kind[i - lo]);
+    const uint32_t x = ra[i - lo], y = rb[i - lo];
+    if (ni >= 1 && x >= lo) first_use[x - lo] = std::min(first_use[x - lo], level[i]);
+    if (ni == 2 && y >= lo) first_use[y - lo] = std::min(first_use[y - lo], level[i]);
   }
-  for (size_t i = 0; i < n; ++i)
-    if (n_inputs(tape.kind[i]) == 0 && tape.kind[i] != TK_NOP)
-      level[i] = first_use[i] == kInf ? 0 : first_use[i] - 1;
-  n_levels = 0;
-  for (size_t i = 0; i < n; ++i) {
-    if (absorbed[i]) continue;
-    const int ni = n_inputs(tape.kind[i]);
-    if (ni >= 1) { last_use[opa[i]] = std::max(last_use[opa[i]], level[i]); used[opa[i]] = 1; }
-    if (ni == 2) { last_use[opb[i]] = std::max(last_use[opb[i]], level[i]); used[opb[i]] = 1; }
-    n_levels = std::max(n_levels, level[i] + 1);
+  for (uint32_t i = lo; i < hi; ++i)
+    if (st(i) != ST_ELIDED && n_inputs(kind[i - lo]) == 0)
+      level[i] = first_use[i - lo] == kInf ? base : first_use[i - lo] - 1;
+  uint32_t top = base;
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (st(i) == ST_ELIDED) continue;
+    const int ni = n_inputs(kind[i - lo]);
+    const uint32_t x = ra[i - lo], y = rb[i - lo];
+    if (ni >= 1) { last_use[x] = std::max(last_use[x], level[i]); if (x >= lo) used[x - lo] = 1; }
+    if (ni == 2) { last_use[y] = std::max(last_use[y], level[i]); if (y >= lo) used[y - lo] = 1; }
+    top = std::max(top, level[i] + 1);
   }
-  for (size_t i = 0; i < n; ++i)
-    if (!used[i]) last_use[i] = level[i];
-  for (uint32_t h : opt.pinned)
-    if (h < n) last_use[h] = kInf;
-  s.n_levels = n_levels;
+  for (uint32_t i = lo; i < hi; ++i)
+    if (!used[i - lo]) last_use[i] = std::max(last_use[i], level[i]);
+  n_wlevels = top - base;
 }
 
-void ScheduleBuilder::fuse_and_pair() {
+void StreamScheduler::Impl::fuse_and_pair() {
   // ---- gate fusion ---------------------------------------------------------
   // An Add/Mul whose value has exactly one reader, itself an Add/Mul, is evaluated inside that reader
   // (depth 1: an op that absorbs cannot be absorbed, an absorbed op has absorbed nothing).  The value is
-  // then never materialised, so this is only done when nobody can ask for it afterwards.
-  std::vector<uint32_t>& level = s.level_of;
-  const bool fuse = opt.fuse && !opt.retain_all && !s.boolean_path;
+  // then never materialised, so this is only done when nobody can ask for it afterwards: the value is closed
+  // (dropped by its owner, or the tape has ended and it is not pinned) -- its readers are then all in this window.
+  const std::vector<uint32_t>& level = s.level_of;
+  const uint32_t n = hi - lo;
   pair_second.clear();
-  if (fuse) {
-    std::vector<uint32_t> reads(n, 0), reader(n, 0), reader0(n, 0);
-    std::vector<uint8_t> has_absorbed(n, 0);
-    auto note_read = [&](uint32_t p, size_t i) {
-      if (reads[p]++ == 0) reader0[p] = (uint32_t)i;
-      reader[p] = (uint32_t)i;
-    };
-    for (size_t i = 0; i < n; ++i) {
-      if (absorbed[i]) continue;
-      const int ni = n_inputs(tape.kind[i]);
-      if (ni >= 1) note_read(opa[i], i);
-      if (ni == 2) note_read(opb[i], i);
-    }
-    auto arith = [&](size_t i) { return tape.kind[i] == TK_ADD || tape.kind[i] == TK_MUL; };
-    for (size_t i = 0; i < n; ++i) {
-      if (absorbed[i] || !arith(i) || reads[i] != 1 || last_use[i] == kInf || has_absorbed[i]) continue;
-      const uint32_t c = reader[i];
-      if (!arith(c) || absorbed[c]) continue;
-      absorbed[i] = 1;
-      has_absorbed[c] = 1;
+  if (!(opt.fuse && !opt.retain_all && !s.boolean_path)) return;
+  std::vector<uint32_t> reads(n, 0), reader(n, 0), reader0(n, 0);
+  std::vector<uint8_t> has_absorbed(n, 0);
+  auto note_read = [&](uint32_t p, uint32_t i) {
+    if (p < lo) return;
+    if (reads[p - lo]++ == 0) reader0[p - lo] = i;
+    reader[p - lo] = i;
+  };
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (st(i) != ST_ENTRY) continue;
+    const int ni = n_inputs(kind[i - lo]);
+    if (ni >= 1) note_read(ra[i - lo], i);
+    if (ni == 2) note_read(rb[i - lo], i);
+  }
+  auto arith = [&](uint32_t i) { return kind[i - lo] == TK_ADD || kind[i - lo] == TK_MUL; };
+  auto extend = [&](uint32_t h, uint32_t lv) { last_use[h] = std::max(last_use[h], lv); };
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (st(i) != ST_ENTRY || !arith(i) || reads[i - lo] != 1 || !closed(i) || has_absorbed[i - lo]) continue;
+    const uint32_t c = reader[i - lo];
+    if (!arith(c) || st(c) != ST_ENTRY) continue;
+    st(i) = ST_FUSED;
+    has_absorbed[c - lo] = 1;
+    ++s.n_absorbed;
+    // the producer's operands are now read at the consumer's level
+    extend(ra[i - lo], level[c]);
+    extend(rb[i - lo], level[c]);
+  }
+  // Shared producers: an Add/Mul read by exactly two Add/Mul gates of one level is evaluated once inside a
+  // *pair entry* that produces both readers' values (X = producer; r1 = X o Y -> dst, r2 = X o Z -> dst2).
+  // X is never materialised: one store and two loads less.  Y may itself be a fused producer, Z is a plain wire.
+  if (opt.pair) {
+    pair_second.assign(n, kInf);
+    std::vector<uint8_t> in_pair(n, 0);
+    for (uint32_t i = lo; i < hi; ++i) {
+      if (st(i) != ST_ENTRY || !arith(i) || reads[i - lo] != 2 || !closed(i) || has_absorbed[i - lo] || in_pair[i - lo]) continue;
+      uint32_t c1 = reader0[i - lo], c2 = reader[i - lo];
+      if (c1 == c2 || !arith(c1) || !arith(c2) || st(c1) != ST_ENTRY || st(c2) != ST_ENTRY || in_pair[c1 - lo] ||
+          in_pair[c2 - lo] || level[c1] != level[c2])
+        continue;
+      if (has_absorbed[c2 - lo]) std::swap(c1, c2);  // the second gate's other operand must be a plain wire
+      if (has_absorbed[c2 - lo]) continue;
+      st(i) = ST_PAIR_SHARED;
+      st(c2) = ST_PAIR_SECOND;
+      pair_second[c1 - lo] = c2;
+      has_absorbed[c1 - lo] = 1;
+      in_pair[c1 - lo] = in_pair[c2 - lo] = 1;
       ++s.n_absorbed;
-      // the producer's operands are now read at the consumer's level
-      last_use[opa[i]] = std::max(last_use[opa[i]] == kInf ? kInf : last_use[opa[i]], level[c]);
-      last_use[opb[i]] = std::max(last_use[opb[i]] == kInf ? kInf : last_use[opb[i]], level[c]);
+      ++s.n_paired;
+      extend(ra[i - lo], level[c1]);
+      extend(rb[i - lo], level[c1]);
     }
-    // Shared producers: an Add/Mul read by exactly two Add/Mul gates of one level is evaluated once inside a
-    // *pair entry* that produces both readers' values (X = producer; r1 = X o Y -> dst, r2 = X o Z -> dst2).
-    // X is never materialised: one store and two loads less.  Y may itself be a fused producer, Z is a plain wire.
-    if (opt.pair) {
-      pair_second.assign(n, kInf);
-      std::vector<uint8_t> in_pair(n, 0);
-      for (size_t i = 0; i < n; ++i) {
-        if (absorbed[i] || !arith(i) || reads[i] != 2 || last_use[i] == kInf || has_absorbed[i] || in_pair[i]) continue;
-        uint32_t c1 = reader0[i], c2 = reader[i];
-        if (c1 == c2 || !arith(c1) || !arith(c2) || absorbed[c1] || absorbed[c2] || in_pair[c1] || in_pair[c2] ||
-            level[c1] != level[c2])
-          continue;
-        if (has_absorbed[c2]) std::swap(c1, c2);  // the second gate's other operand must be a plain wire
-        if (has_absorbed[c2]) continue;
-        absorbed[i] = 3;
-        absorbed[c2] = 4;
-        pair_second[c1] = c2;
-        has_absorbed[c1] = 1;
-        in_pair[c1] = in_pair[c2] = 1;
-        ++s.n_absorbed;
-        ++s.n_paired;
-        last_use[opa[i]] = std::max(last_use[opa[i]] == kInf ? kInf : last_use[opa[i]], level[c1]);
-        last_use[opb[i]] = std::max(last_use[opb[i]] == kInf ? kInf : last_use[opb[i]], level[c1]);
-      }
-    }
-    s.fused = s.n_absorbed != 0;
   }
 }
 
-void ScheduleBuilder::order_by_level() {
+void StreamScheduler::Impl::order_by_level() {
   // ---- order ops by (level, kind): counting sort ------------------------
   constexpr uint32_t kKinds = TK_NZ + 1;
-  std::vector<uint64_t> bucket((size_t)n_levels * kKinds + 1, 0);
+  std::vector<uint64_t> bucket((size_t)n_wlevels * kKinds + 1, 0);
   const std::vector<uint32_t>& level = s.level_of;
-  n_live = 0;
-  for (size_t i = 0; i < n; ++i)
-    if (!absorbed[i]) { ++bucket[(size_t)level[i] * kKinds + tape.kind[i] + 1]; ++n_live; }
+  size_t n_live = 0;
+  for (uint32_t i = lo; i < hi; ++i)
+    if (st(i) == ST_ENTRY) { ++bucket[(size_t)(level[i] - base) * kKinds + kind[i - lo] + 1]; ++n_live; }
   for (size_t k = 1; k < bucket.size(); ++k) bucket[k] += bucket[k - 1];
   order.assign(n_live, 0);
   {
     std::vector<uint64_t> cursor(bucket.begin(), bucket.end() - 1);
-    for (size_t i = 0; i < n; ++i)
-      if (!absorbed[i]) order[cursor[(size_t)level[i] * kKinds + tape.kind[i]]++] = (uint32_t)i;
+    for (uint32_t i = lo; i < hi; ++i)
+      if (st(i) == ST_ENTRY) order[cursor[(size_t)(level[i] - base) * kKinds + kind[i - lo]]++] = i;
   }
-  level_start.assign(n_levels + 1, 0);
-  for (uint32_t l = 0; l <= n_levels; ++l) level_start[l] = bucket[(size_t)l * kKinds];
+  level_start.assign(n_wlevels + 1, 0);
+  for (uint32_t l = 0; l <= n_wlevels; ++l) level_start[l] = bucket[(size_t)l * kKinds];
 }
 
 // wires an op gathers from the table (resolved through elided copies and fused producers)
-int ScheduleBuilder::gathered(uint32_t i, uint32_t out[4]) const {
-    int k = 0;
-    const int ni = n_inputs(tape.kind[i]);
-    auto push = [&](uint32_t p) {
-      if (absorbed[p] == 1 || absorbed[p] == 3) {
-        if (k + 2 <= 4) {
-          out[k++] = opa[p];
-          out[k++] = opb[p];
-        }
-      } else if (k < 4) {
-        out[k++] = p;
+int StreamScheduler::Impl::gathered(uint32_t i, uint32_t out[4]) const {
+  int k = 0;
+  const int ni = n_inputs(kind[i - lo]);
+  auto push = [&](uint32_t p) {
+    if (inner(p)) {
+      if (k + 2 <= 4) {
+        out[k++] = ra[p - lo];
+        out[k++] = rb[p - lo];
       }
-    };
-    if (ni >= 1) push(opa[i]);
-    if (ni == 2) push(opb[i]);
-    return k;  // (a pair entry's fifth wire, the second gate's own operand, is left out of the locality graph)
+    } else if (k < 4) {
+      out[k++] = p;
+    }
+  };
+  if (ni >= 1) push(ra[i - lo]);
+  if (ni == 2) push(rb[i - lo]);
+  return k;  // (a pair entry's fifth wire, the second gate's own operand, is left out of the locality graph)
 }
 
-void ScheduleBuilder::assign_slots() {
+void StreamScheduler::Impl::assign_slots() {
   // ---- slots: liveness-based reuse, level by level ----------------------
-  std::vector<uint32_t> free_slots;
-  std::vector<uint32_t> expire_head(n_levels + 1, kInf), expire_next(n, kInf);  // intrusive lists per last_use level
-  uint32_t n_slots = 0;
-  for (uint32_t l = 0; l < n_levels; ++l) {
-    if (!opt.retain_all && l > 0) {
-      for (uint32_t h = expire_head[l - 1]; h != kInf; h = expire_next[h]) free_slots.push_back(s.slot_of[h]);
-    }
-    if (opt.sort_by_operand) {
-      // inside a (level, kind) run, order the ops by the slot of their first operand: gates that read
-      // the same wire become neighbours (same workgroup), so the repeat read is an L1/L2 hit
-      uint64_t k = level_start[l];
-      while (k < level_start[l + 1]) {
-        uint64_t e = k;
-        const uint8_t kind = tape.kind[order[k]];
-        while (e < level_start[l + 1] && tape.kind[order[e]] == kind) ++e;
-        if (n_inputs(kind) >= 1 && e - k > 1)
-          std::stable_sort(order.begin() + k, order.begin() + e, [&](uint32_t x, uint32_t y) {
-            auto inner = [&](uint32_t h) { return absorbed[h] == 1 || absorbed[h] == 3; };
-            const uint32_t ax = inner(opa[x]) ? opa[opa[x]] : opa[x];
-            const uint32_t ay = inner(opa[y]) ? opa[opa[y]] : opa[y];
-            return s.slot_of[ax] < s.slot_of[ay];
-          });
-        k = e;
+  // A slot is reused only by a strictly later level than its last reader, so a level never overwrites what it reads.
+  // A value keeps its slot while it is open (its owner has not dropped it): later windows may read it.
+  std::vector<uint32_t> expire_head(n_wlevels + 1, kInf);
+  std::vector<uint32_t> expire_next(hi - lo, kInf);  // intrusive lists per last_use level, this window's values
+  struct Ext {
+    uint32_t h, next;
+  };
+  std::vector<Ext> ext;                               // the same for values of earlier windows
+  std::vector<uint32_t> ext_head(n_wlevels + 1, kInf);
+  if (!opt.retain_all) {
+    // values of earlier windows that were still open: closed now?
+    size_t keep = 0;
+    for (uint32_t h : open_list) {
+      if (!closed(h)) { open_list[keep++] = h; continue; }
+      if (last_use[h] < base || n_wlevels == 0) {
+        free_slots.push_back(s.slot_of[h]);
+      } else {
+        ext.push_back({h, ext_head[last_use[h] - base]});
+        ext_head[last_use[h] - base] = (uint32_t)ext.size() - 1;
       }
+    }
+    open_list.resize(keep);
+  }
+  auto take_slot = [&]() {
+    if (!free_slots.empty()) {
+      const uint32_t slot = free_slots.back();
+      free_slots.pop_back();
+      return slot;
+    }
+    return n_slots++;
+  };
+  auto place = [&](uint32_t i) {
+    s.slot_of[i] = take_slot();
+    if (opt.retain_all) return;
+    if (closed(i)) {
+      const uint32_t lu = std::max(last_use[i], s.level_of[i]) - base;
+      expire_next[i - lo] = expire_head[lu];
+      expire_head[lu] = i;
+    } else {
+      open_list.push_back(i);
+    }
+  };
+  auto release_level = [&](uint32_t l) {
+    for (uint32_t h = expire_head[l]; h != kInf; h = expire_next[h - lo]) free_slots.push_back(s.slot_of[h]);
+    for (uint32_t e = ext_head[l]; e != kInf; e = ext[e].next) free_slots.push_back(s.slot_of[ext[e].h]);
+  };
+  for (uint32_t l = 0; l < n_wlevels; ++l) {
+    if (!opt.retain_all && l > 0) release_level(l - 1);
+    for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
+      const uint32_t i = order[k];
+      if (kind[i - lo] == TK_ASSERT || kind[i - lo] == TK_NOP) continue;
+      place(i);
+      if (!pair_second.empty() && pair_second[i - lo] != kInf) place(pair_second[i - lo]);  // the second value of a pair entry
+    }
+  }
+  // what expires at the window's last level is free for the next window
+  if (!opt.retain_all && n_wlevels) release_level(n_wlevels - 1);
+}
+
+void StreamScheduler::Impl::order_levels() {
+  // ---- order of the entries inside a level (independent per level: done on `threads` threads) ----
+  if (!opt.sort_by_operand) return;
+  parallel_levels(n_wlevels, threads, [&](uint32_t l) {
+    // inside a (level, kind) run, order the ops by the slot of their first operand: gates that read
+    // the same wire become neighbours (same workgroup), so the repeat read is an L1/L2 hit
+    uint64_t k = level_start[l];
+    while (k < level_start[l + 1]) {
+      uint64_t e = k;
+      const uint8_t kd = kind[order[k] - lo];
+      while (e < level_start[l + 1] && kind[order[e] - lo] == kd) ++e;
+      if (n_inputs(kd) >= 1 && e - k > 1)
+        std::stable_sort(order.begin() + k, order.begin() + e, [&](uint32_t x, uint32_t y) {
+          const uint32_t ax = inner(ra[x - lo]) ? ra[ra[x - lo] - lo] : ra[x - lo];
+          const uint32_t ay = inner(ra[y - lo]) ? ra[ra[y - lo] - lo] : ra[y - lo];
+          return s.slot_of[ax] < s.slot_of[ay];
+        });
+      k = e;
     }
     if (opt.sort_by_operand >= 2 && !s.boolean_path) {
       // the Add/Mul entries of a level come first (counting sort by kind) and run in a kernel instantiation of
       // their own (engine.hip launch_one): the shared-operand walk orders the two parts separately
       uint64_t mid = level_start[l];
-      while (mid < level_start[l + 1] && (tape.kind[order[mid]] == TK_ADD || tape.kind[order[mid]] == TK_MUL)) ++mid;
+      while (mid < level_start[l + 1] && (kind[order[mid] - lo] == TK_ADD || kind[order[mid] - lo] == TK_MUL)) ++mid;
       const uint64_t cut[3] = {level_start[l], mid, level_start[l + 1]};
       for (int part = 0; part < 2; ++part)
         if (cut[part + 1] - cut[part] > 8)
           locality_order(order.data() + cut[part], cut[part + 1] - cut[part],
                          [&](uint32_t i, uint32_t* out) { return gathered(i, out); });
     }
-    for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
-      const uint32_t i = order[k];
-      if (tape.kind[i] == TK_ASSERT || tape.kind[i] == TK_NOP) continue;
-      uint32_t slot;
-      if (!free_slots.empty()) {
-        slot = free_slots.back();
-        free_slots.pop_back();
-      } else {
-        slot = n_slots++;
-      }
-      s.slot_of[i] = slot;
-      if (last_use[i] != kInf) {
-        expire_next[i] = expire_head[last_use[i]];
-        expire_head[last_use[i]] = i;
-      }
-      if (!pair_second.empty() && pair_second[i] != kInf) {  // the second value of a pair entry needs a slot too
-        const uint32_t j = pair_second[i];
-        if (!free_slots.empty()) {
-          slot = free_slots.back();
-          free_slots.pop_back();
-        } else {
-          slot = n_slots++;
-        }
-        s.slot_of[j] = slot;
-        if (last_use[j] != kInf) {
-          expire_next[j] = expire_head[last_use[j]];
-          expire_head[last_use[j]] = j;
-        }
-      }
-    }
-  }
-  s.n_slots = std::max<uint32_t>(n_slots, 1);
+  });
 }
 
-void ScheduleBuilder::emit_entries() {
+void StreamScheduler::Impl::emit_entries() {
   // ---- device ops ----------------------------------------------------------
+  const size_t n_live = order.size();
   if (s.fused) {
-    s.ops2.resize(n_live);
+    const size_t at = s.ops2.size();
+    s.ops2.resize(at + n_live);
     for (size_t k = 0; k < n_live; ++k) {
       const uint32_t i = order[k];
-      const uint8_t kind = tape.kind[i];
-      DevOp2 d{0, kind, 0, 0, 0, 0, 0, 0};
+      const uint8_t kd = kind[i - lo];
+      DevOp2 d{0, kd, 0, 0, 0, 0, 0, 0};
       d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
       auto operand = [&](uint32_t h, uint32_t* x0, uint32_t* x1, int shift) {
-        if (absorbed[h] == 1 || absorbed[h] == 3) {  // evaluated inside this entry (4 = second value of a pair entry: has a slot)
-          *x0 = s.slot_of[opa[h]];
-          *x1 = s.slot_of[opb[h]];
-          d.kind |= (tape.kind[h] == TK_ADD ? 1u : 2u) << shift;
+        if (inner(h)) {  // evaluated inside this entry (ST_PAIR_SECOND has a slot of its own)
+          *x0 = s.slot_of[ra[h - lo]];
+          *x1 = s.slot_of[rb[h - lo]];
+          d.kind |= (kind[h - lo] == TK_ADD ? 1u : 2u) << shift;
         } else {
           *x0 = s.slot_of[h];
         }
       };
-      switch (kind) {
+      const uint32_t x = ra[i - lo], y = rb[i - lo];
+      switch (kd) {
         case TK_ADD: case TK_MUL:
-          if (!pair_second.empty() && pair_second[i] != kInf) {
+          if (!pair_second.empty() && pair_second[i - lo] != kInf) {
             // pair entry: the shared producer goes first (Add/Mul commute), then the second gate's result slot
             // and its own operand
-            const uint32_t j = pair_second[i];
-            const uint32_t x = absorbed[opa[i]] == 3 ? opa[i] : opb[i];
-            const uint32_t y = absorbed[opa[i]] == 3 ? opb[i] : opa[i];
+            const uint32_t j = pair_second[i - lo];
+            const bool shared_is_a = x >= lo && st(x) == ST_PAIR_SHARED;
+            const uint32_t sh = shared_is_a ? x : y, other = shared_is_a ? y : x;
+            operand(sh, &d.a0, &d.a1, 8);
+            operand(other, &d.b0, &d.b1, 10);
+            d.kind |= (kind[j - lo] == TK_ADD ? 1u : 2u) << 12;
+            d.pad0 = s.slot_of[j];
+            d.pad1 = s.slot_of[ra[j - lo] == sh ? rb[j - lo] : ra[j - lo]];
+          } else {
             operand(x, &d.a0, &d.a1, 8);
             operand(y, &d.b0, &d.b1, 10);
-            d.kind |= (tape.kind[j] == TK_ADD ? 1u : 2u) << 12;
-            d.pad0 = s.slot_of[j];
-            d.pad1 = s.slot_of[opa[j] == x ? opb[j] : opa[j]];
-          } else {
-            operand(opa[i], &d.a0, &d.a1, 8);
-            operand(opb[i], &d.b0, &d.b1, 10);
           }
           break;
         case TK_AND: case TK_XOR:
-          d.a0 = s.slot_of[opa[i]];
-          d.b0 = s.slot_of[opb[i]];
+          d.a0 = s.slot_of[x];
+          d.b0 = s.slot_of[y];
           break;
         case TK_ADDC: case TK_MULC:
-          d.a0 = s.slot_of[opa[i]];
-          d.b0 = opb[i];
+          d.a0 = s.slot_of[x];
+          d.b0 = y;
           break;
-        case TK_COPY: case TK_NOT: case TK_NZ: d.a0 = s.slot_of[opa[i]]; break;
-        case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a0 = opa[i]; break;
+        case TK_COPY: case TK_NOT: case TK_NZ: d.a0 = s.slot_of[x]; break;
+        case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a0 = x; break;
         case TK_ASSERT:
-          d.a0 = s.slot_of[opa[i]];
-          d.b0 = opb[i];
+          d.a0 = s.slot_of[x];
+          d.b0 = y;
           break;
         default: break;
       }
-      s.ops2[k] = d;
+      s.ops2[at + k] = d;
     }
+    return;
   }
-  s.ops.resize(s.fused ? 0 : n_live);
-  for (size_t k = 0; k < n_live && !s.fused; ++k) {
+  const size_t at = s.ops.size();
+  s.ops.resize(at + n_live);
+  for (size_t k = 0; k < n_live; ++k) {
     const uint32_t i = order[k];
-    DevOp d{0, 0, 0, tape.kind[i]};
-    const uint8_t kind = tape.kind[i];
+    const uint8_t kd = kind[i - lo];
+    DevOp d{0, 0, 0, kd};
     d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
-    switch (kind) {
+    const uint32_t x = ra[i - lo], y = rb[i - lo];
+    switch (kd) {
       case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR:
-        d.a = s.slot_of[opa[i]];
-        d.b = s.slot_of[opb[i]];
+        d.a = s.slot_of[x];
+        d.b = s.slot_of[y];
         break;
       case TK_ADDC: case TK_MULC:
-        d.a = s.slot_of[opa[i]];
-        d.b = opb[i];
+        d.a = s.slot_of[x];
+        d.b = y;
         break;
-      case TK_COPY: case TK_NOT: case TK_NZ: d.a = s.slot_of[opa[i]]; break;
-      case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a = opa[i]; break;
+      case TK_COPY: case TK_NOT: case TK_NZ: d.a = s.slot_of[x]; break;
+      case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a = x; break;
       case TK_ASSERT:
-        d.a = s.slot_of[opa[i]];
-        d.b = opb[i];
+        d.a = s.slot_of[x];
+        d.b = y;
         break;
       default: break;
     }
-    if (s.boolean_path) {  // arithmetic mod 2 on {0,1}: (a+b)%2 = xor, (a*b)%2 = and
-      if (kind == TK_ADD) d.kind = TK_XOR;
-      else if (kind == TK_MUL) d.kind = TK_AND;
-      else if (kind == TK_ADDC) d.kind = const_odd[opb[i]] ? TK_NOT : TK_COPY;
-      else if (kind == TK_MULC) {
-        if (const_odd[opb[i]]) d.kind = TK_COPY;
-        else { d.kind = TK_CONST; d.a = bool_zero_const; }
-      }
-    }
-    s.ops[k] = d;
+    s.ops[at + k] = d;
   }
 }
 
-void ScheduleBuilder::emit_launches() {
+void StreamScheduler::Impl::emit_launches() {
   // ---- launches -------------------------------------------------------------
+  const uint64_t at = (s.fused ? s.ops2.size() : s.ops.size()) - order.size();
   uint32_t l = 0;
-  while (l < n_levels) {
+  while (l < n_wlevels) {
     const uint64_t width = level_start[l + 1] - level_start[l];
     s.max_level_width = std::max<uint32_t>(s.max_level_width, (uint32_t)width);
     Launch L;
-    L.first = (uint32_t)level_start[l];
-    L.level_begin = l;
+    L.first = (uint32_t)(at + level_start[l]);
+    L.level_begin = base + l;
+    L.window = n_windows;
+    const uint64_t k0 = level_start[l];
+    uint64_t k1;
     if (width >= opt.narrow_width) {
       L.count = (uint32_t)width;
       L.ops_per_wave = 1;
-      L.level_end = l + 1;
+      L.level_end = base + l + 1;
+      k1 = level_start[l + 1];
       ++l;
     } else {
       uint32_t e = l;
-      while (e < n_levels && level_start[e + 1] - level_start[e] < opt.narrow_width) ++e;
+      while (e < n_wlevels && level_start[e + 1] - level_start[e] < opt.narrow_width) ++e;
       L.count = (uint32_t)(level_start[e] - level_start[l]);
       L.ops_per_wave = std::max<uint32_t>(L.count, 1);
       L.sequential = true;
-      L.level_end = e;
+      L.level_end = base + e;
+      k1 = level_start[e];
       l = e;
     }
-    for (uint64_t k = L.first; k < (uint64_t)L.first + L.count; ++k) {
-      const uint8_t kind = tape.kind[order[k]];
-      if (!L.sequential && k == (uint64_t)L.first + L.hot_count && (kind == TK_ADD || kind == TK_MUL)) ++L.hot_count;
-      if (!s.boolean_path && (kind == TK_AND || kind == TK_XOR)) L.has_bitops = true;
+    for (uint64_t k = k0; k < k1; ++k) {
+      const uint8_t kd = kind[order[k] - lo];
+      if (!L.sequential && k == k0 + L.hot_count && (kd == TK_ADD || kd == TK_MUL)) ++L.hot_count;
+      if (!s.boolean_path && (kd == TK_AND || kd == TK_XOR)) L.has_bitops = true;
     }
     s.has_bitops = s.has_bitops || L.has_bitops;
     if (L.count) s.launches.push_back(L);
   }
 }
 
+StreamScheduler::StreamScheduler(const FieldHost& field, const ScheduleOptions& opt) : impl_(new Impl()) {
+  Impl& m = *impl_;
+  m.field = field;
+  m.opt = opt;
+  m.threads = opt.threads ? opt.threads : std::min<uint32_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+  m.s.retain_all = opt.retain_all;
+  m.s.boolean_path = field.is_two;
+  // fused entry format whenever fusion may happen: a window cannot know whether a later one will absorb a gate
+  m.s.fused = opt.fuse && !opt.retain_all && !field.is_two;
+  m.s.window_first_op.push_back(0);
+}
+
+StreamScheduler::~StreamScheduler() { delete impl_; }
+
+const Schedule& StreamScheduler::partial() const { return impl_->s; }
+
+WindowResult StreamScheduler::add_window(const TapeWindow& w) {
+  Impl& m = *impl_;
+  WindowResult r;
+  r.first_op = m.s.fused ? m.s.ops2.size() : m.s.ops.size();
+  r.first_launch = (uint32_t)m.s.launches.size();
+  m.lo = w.lo;
+  m.hi = w.hi;
+  m.final = w.final;
+  m.base = m.s.n_levels;
+  m.grow(w.hi);
+  for (size_t k = 0; k < w.n_drops; ++k)
+    if (w.drops[k] < w.hi) m.flags[w.drops[k]] |= FL_DROPPED;
+  if (w.final && w.pinned)
+    for (uint32_t h : *w.pinned)
+      if (h < w.hi) m.flags[h] = (uint8_t)((m.flags[h] | FL_PINNED) & ~FL_DROPPED);
+  const uint32_t n = w.hi - w.lo;
+  m.n_wlevels = 0;
+  m.order.clear();
+  if (n) {
+    m.kind.assign(w.kind, w.kind + n);
+    m.state.assign(n, ST_ENTRY);
+    m.ra.assign(w.a, w.a + n);
+    m.rb.assign(w.b, w.b + n);
+    m.rewrite_ladders(w);
+    m.propagate_copies();
+    m.levelise();
+    m.fuse_and_pair();
+    m.order_by_level();
+  } else {
+    m.kind.clear();
+    m.state.clear();
+    m.level_start.assign(1, 0);
+    m.pair_second.clear();
+  }
+  m.assign_slots();  // also with no ops of its own: values the last window left open may have been closed since
+  if (n) {
+    m.order_levels();
+    m.emit_entries();
+    m.emit_launches();
+    m.s.n_levels = m.base + m.n_wlevels;
+  }
+  ++m.n_windows;
+  m.s.n_slots = std::max<uint32_t>(m.n_slots, 1);
+  r.n_ops = (m.s.fused ? m.s.ops2.size() : m.s.ops.size()) - r.first_op;
+  r.n_launches = (uint32_t)m.s.launches.size() - r.first_launch;
+  m.s.window_first_op.push_back(r.first_op + r.n_ops);
+  return r;
+}
+
+Schedule StreamScheduler::finish(const std::vector<Value>& consts) {
+  Impl& m = *impl_;
+  Schedule& s = m.s;
+  // ---- constant pool in device form -------------------------------------
+  const uint32_t n_consts = (uint32_t)consts.size();
+  if (s.boolean_path) {
+    s.words_per_const = 1;
+    s.const_words.resize(n_consts + 1);
+    for (uint32_t i = 0; i < n_consts; ++i) s.const_words[i] = !consts[i].empty() && (consts[i][0] & 1);  // value mod 2
+    s.const_words[n_consts] = 0;  // synthetic 0 for mul_constant by an even constant
+    // arithmetic mod 2 on {0,1}: (a+b)%2 = xor, (a*b)%2 = and
+    for (DevOp& d : s.ops) {
+      if (d.kind == TK_ADD) d.kind = TK_XOR;
+      else if (d.kind == TK_MUL) d.kind = TK_AND;
+      else if (d.kind == TK_ADDC) d.kind = s.const_words[d.b] ? TK_NOT : TK_COPY;
+      else if (d.kind == TK_MULC) {
+        if (s.const_words[d.b]) d.kind = TK_COPY;
+        else { d.kind = TK_CONST; d.a = n_consts; }
+      }
+    }
+  } else {
+    s.words_per_const = m.field.nwords;
+    s.const_words.assign((size_t)n_consts * m.field.nwords, 0);
+    for (uint32_t i = 0; i < n_consts; ++i) {
+      uint32_t r[kFieldWords], mont[kFieldWords];
+      m.field.reduce(consts[i], r);
+      m.field.to_mont(r, mont);
+      memcpy(&s.const_words[(size_t)i * m.field.nwords], mont, 4 * m.field.nwords);
+    }
+  }
+  return std::move(s);
+}
+
+namespace {
+
+Schedule schedule_windows(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt, const std::vector<uint32_t>& cuts) {
+  StreamScheduler sch(field, opt);
+  size_t drop_at = 0, ladder_at = 0;
+  uint32_t lo = 0;
+  const uint32_t n = (uint32_t)tape.size();
+  for (size_t c = 0; c <= cuts.size(); ++c) {
+    const bool final = c == cuts.size();
+    const uint32_t hi = final ? n : std::min(cuts[c], n);
+    TapeWindow w;
+    w.lo = lo;
+    w.hi = hi;
+    w.kind = tape.kind.data() + lo;
+    w.a = tape.a.data() + lo;
+    w.b = tape.b.data() + lo;
+    size_t d1 = drop_at;
+    while (d1 < tape.drop_pos.size() && tape.drop_pos[d1] <= hi) ++d1;
+    w.drops = tape.drop_handle.data() + drop_at;
+    w.n_drops = d1 - drop_at;
+    drop_at = d1;
+    size_t l1 = ladder_at;
+    while (l1 < tape.ladders.size() && tape.ladders[l1].result < hi) ++l1;
+    w.ladders = tape.ladders.data() + ladder_at;
+    w.n_ladders = l1 - ladder_at;
+    ladder_at = l1;
+    w.final = final;
+    w.pinned = &opt.pinned;
+    sch.add_window(w);
+    lo = hi;
+  }
+  return sch.finish(tape.consts);
+}
+
 }  // namespace
 
-Schedule build_schedule(const Tape& recorded, const FieldHost& field, const ScheduleOptions& opt) {
-  Tape rewritten;
-  uint64_t n_ladders = 0;
-  const bool use_rewritten = opt.fermat && !opt.retain_all && !field.is_two && rewrite_ladders(recorded, field, &rewritten, &n_ladders);
-  const Tape& tape = use_rewritten ? rewritten : recorded;
-  ScheduleBuilder b(tape, field, opt);
-  Schedule& s = b.s;
-  b.n = tape.size();
-  s.retain_all = opt.retain_all;
-  s.n_ladders = n_ladders;
-  s.boolean_path = field.is_two;
-  s.slot_of.assign(b.n, kNoWire);
-  s.level_of.assign(b.n, 0);
-  if (b.n == 0) return s;
-  b.device_constants();
-  b.propagate_copies();
-  b.levelise();
-  b.fuse_and_pair();
-  b.order_by_level();
-  b.assign_slots();
-  b.emit_entries();
-  b.emit_launches();
-  return std::move(b.s);
+Schedule build_schedule(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt) {
+  return schedule_windows(tape, field, opt, {});
+}
+
+Schedule build_schedule_windowed(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt) {
+  // GF(2) programs are re-encoded as a whole for the LDS-resident kernel: one window
+  return schedule_windows(tape, field, opt, field.is_two ? std::vector<uint32_t>() : tape.cuts);
 }
 
 }  // namespace zki
