@@ -56,6 +56,15 @@ def pmc_traffic(width, batch, nwords_bytes, workload='c2'):
     return d['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)
 
 
+def binding_evidence(workload):
+    """Which resource binds the dominant kernel and the counters that say so: profiles/binding_<workload>.json, written
+    by tools/collect_profiles.sh from the --pmc passes of this same command (None before the first collection)."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'binding_%s.json' % workload)))
+    except (OSError, ValueError):
+        return None
+
+
 class _DevU64x2:
     """torch view of the engine's device counters {satisfied, failed}"""
 
@@ -99,6 +108,9 @@ def first_verdict_seconds(zk, wl, msgs, inst, wit, batch, stream, pinned):
 def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, streams=2):
     """probe pass for the expected outputs, then the real session with resident inputs"""
     t0 = time.time()
+    if hasattr(wl, 'N'):   # StructuredArith: the expected values are a closed form, no probe pass
+        inst, wit, n_bad = wl.inputs(batch, lane_offset)
+        return finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, time.time())
     inst, wit = wl.inputs(batch, lane_offset)
     probe = zk.Evaluator()
     if bool_path:
@@ -119,7 +131,10 @@ def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, stream
         outs = outs[:, :, 0]
     probe.close()
     n_bad = wl.set_expected_outputs(inst, outs, lane_offset)
-    t1 = time.time()
+    return finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, time.time())
+
+
+def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, t1):
     msgs = wl.relation_messages()
     t2 = time.time()
     ev = zk.Evaluator()
@@ -138,6 +153,8 @@ def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, stream
         ev.set_option('xcd_map', os.environ['ZKI_XCD_MAP'])
     if os.environ.get('ZKI_SORT_BY_OPERAND'):
         ev.set_option('sort_by_operand', os.environ['ZKI_SORT_BY_OPERAND'])
+    if os.environ.get('ZKI_FERMAT'):
+        ev.set_option('fermat', os.environ['ZKI_FERMAT'])
     ev.declare_inputs(wl.n_instance, wl.n_witness)
     for m in msgs:
         ev.ingest_message(m)
@@ -273,10 +290,17 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
                        'host_seconds': {'build_s': round(t1 - t0, 2), 'witness_generation_s': round(t2 - t1, 2)}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(M, batch, wl.width, 'c5')[0],
-                         'traffic_source': pmc_traffic(M, batch, wl.width, 'c5')[1], 'kernel': 'r1cs_row_kernel<8,false>',
+                         'traffic_source': pmc_traffic(M, batch, wl.width, 'c5')[1], 'kernel': 'r1cs_row_kernel<8, false>',
                          'launches_per_step': 1, 'avg_launch_ms': kernel_ms,
                          'algorithmic_bytes_per_launch': bytes_per_launch},
         }
+        tr = out['roofline']['traffic']
+        if tr is not None:
+            out['roofline']['frac_traffic'] = tr / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        be = binding_evidence('c5')
+        if be:
+            out['roofline']['binding'] = be.get('binding')
+            out['roofline']['binding_evidence'] = be.get('evidence')
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             # the row check on the host cores for a bounded sample of the same lanes (oracle/cpu_opt.cpp:
             # the mathematical definition -- the reference itself holds no row checker)
@@ -329,8 +353,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', choices=['c2', 'c4', 'c5'], default='c2',
-                    help='c2 = BASELINE configs[1] (headline); c4 = GF(2) 10M-gate relation, batch 4096')
+    ap.add_argument('--workload', choices=['c2', 'c4', 'c5', 'structured'], default='c2',
+                    help='c2 = BASELINE configs[1] (headline); c4 = GF(2) 10M-gate relation, batch 4096; c5 = R1CS rows; '
+                         'structured = For / Call / Switch relation of ~1M backend calls (--width = loop iterations)')
     ap.add_argument('--batch-per-gpu', type=int, default=0)
     ap.add_argument('--width', type=int, default=0)
     ap.add_argument('--depth', type=int, default=0)
@@ -338,6 +363,7 @@ def main():
     ap.add_argument('--streams', type=int, default=2, help='lane halves replayed concurrently on this many HIP streams')
     ap.add_argument('--lane-group', type=int, default=0, help='replay lane groups of this size one after the other')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hbm-variant', action='store_true', help='c2: skip the 4096-witnesses-in-flight variant')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -379,6 +405,10 @@ def main():
         wl = workloads.ArithLayered(W=args.width or 4096, D=args.depth or 256, mul_percent=int(mp) if mp else None)
         batch = args.batch_per_gpu or 1024
         bytes_table, bool_path = BYTES_PER_OP, None
+    elif args.workload == 'structured':
+        wl = workloads.StructuredArith(N=args.width or 1408)
+        batch = args.batch_per_gpu or 1024
+        bytes_table, bool_path = BYTES_PER_OP, None
     else:
         wl = workloads.BoolLayered(W=args.width or 16384, D=args.depth or 640,
                                    wiring=os.environ.get('ZKI_C4_WIRING', 'random'))
@@ -387,8 +417,10 @@ def main():
     lane_offset = rank * batch
     ev, inst, wit, n_bad, msgs, host = build_session(zk, wl, batch, lane_offset, args.lane_group, bool_path,
                                                      args.streams)
-    gates = wl.n_gates
     kinds, _, _ = ev.tape()
+    # structured: the unit of work is one backend call of the reference's evaluator (every value-returning call it
+    # makes for one witness, ladders and scope copies included) -- what the CPU baseline executes call by call
+    gates = wl.n_gates if hasattr(wl, 'n_gates') else int((kinds != 9).sum())
     algo_bytes_per_lane = float(sum(bytes_table.get(int(k), 0) * int(c) for k, c in zip(*np.unique(kinds, return_counts=True))))
     info = ev.schedule_info()
     lds = args.workload == 'c4' and ev.uses_lds_path()
@@ -432,7 +464,7 @@ def main():
         total = list(ev.counts())
     # PCIe-inclusive figure (never `value`): the boundary hands over host buffers every step
     pcie_ms = None
-    if world == 1:
+    if world == 1 and args.workload != 'structured':
         # page-locked host buffers (what a streaming caller would use): the DMA engine reads them directly
         pin_i = torch.from_numpy(np.ascontiguousarray(inst).reshape(-1)).pin_memory()
         pin_w = torch.from_numpy(np.ascontiguousarray(wit).reshape(-1)).pin_memory()
@@ -458,6 +490,31 @@ def main():
             assert best['satisfied'] == exp_sat
             first_verdict[name] = best
 
+    hbm_variant = None
+    if world == 1 and args.workload == 'c2' and not args.no_hbm_variant and not args.width and not args.batch_per_gpu:
+        # the same relation with 4096 witnesses replayed at once: a 1.05 GB wire table cannot sit in the 256 MiB
+        # Infinity Cache, so here the algorithmic-bytes roofline is an HBM figure (the headline batch of 1024 keeps its
+        # 263 MB table on-die)
+        hb = 4096
+        hev, _, _, hbad, _, _ = build_session(zk, wl, hb, 0, hb, None, args.streams)
+        for _ in range(2):
+            hev.replay()
+        hev.synchronize()
+        t0h = time.perf_counter()
+        hms = []
+        for _ in range(8):
+            hev.replay()
+            hev.synchronize()
+            hms.append(hev.last_replay_ms)
+        helapsed = (time.perf_counter() - t0h) / 8
+        assert list(hev.counts()) == [workloads.expected_satisfied(hb), hbad]
+        hach = algo_bytes_per_lane * hb / (float(np.mean(hms)) * 1e-3) / 1e9
+        hbm_variant = {'batch': hb, 'lane_group': hb, 'wire_table_MB': round(hev.table_bytes / 1e6, 1),
+                       'ms_per_step': helapsed * 1e3, 'value': gates * hb / helapsed, 'achieved': hach,
+                       'frac': hach / HBM_PEAK_GBS, 'what': 'same program, all 4096 witnesses in flight: working set 4x the '
+                                                            'Infinity Cache, so achieved / frac are against HBM'}
+        hev.close()
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = gates * batch * world / (elapsed / args.steps)
@@ -466,45 +523,75 @@ def main():
         kernel_ms = float(np.mean(ev_ms)) / max(wide_launches, 1)
         bytes_per_launch = algo_bytes_per_lane * batch / max(wide_launches, 1)
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(wl.W, batch, wl.width, args.workload)
+        structured = args.workload == 'structured'
+        traffic, traffic_src = (None, None) if structured else pmc_traffic(wl.W, batch, wl.width, args.workload)
+        fused = info['device_ops'] < len(kinds)
         if args.workload == 'c2':
             metric = 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses'
             dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
             wl_name = ('BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
                        'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
-            kernel = 'replay_fused_kernel<8>' if info['device_ops'] < len(kinds) else 'replay_kernel<8,false>'
+            kernel = 'replay_fused_kernel<8, 0>' if fused else 'replay_kernel<8, false, false>'
+        elif structured:
+            metric = ('backend-ops/sec (whole node), 256-bit field, For/Call/Switch relation of ~1M backend calls, batched '
+                      'witnesses (one unit = one value-returning ZKBackend call of the reference evaluator)')
+            dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
+            wl_name = ('structured: For over a named function with a nested call and a 2-case Switch, %d iterations, '
+                       'BN254 (shape of producers/examples.rs:72-212), witness batch=%d per GPU, %d GPU(s)' % (wl.N, batch, world))
+            kernel = 'replay_fused_kernel<8, 0> + <8, 1>' if fused else 'replay_kernel<8, false, false>'
         else:
             metric = 'gate-ops/sec (whole node), GF(2), 10M-gate And/Xor/Not relation, bit-packed batched witnesses'
             dtype = 'u1 (GF(2), %d witnesses per word)' % (32 if lds else 64)
             wl_name = ('BASELINE configs[3]: GF(2), %d-gate And/Xor/Not relation (W=%d x D=%d), witness batch=%d '
                        'per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
             kernel = 'bool_lds_kernel (wire table resident in LDS)' if lds else 'bool_replay_kernel'
+        step_kernel_ms = float(np.mean(ev_ms))
+        roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                    'kernel': kernel, 'launches_per_step': wide_launches,
+                    'concurrent_streams': 1 if lds else args.streams,
+                    'note': 'achieved / frac = algorithmic bytes (SURVEY.md 8d: 96 B per Add/Mul gate and witness ...) of the '
+                            'timed replay / its HIP-event time on the engine stream / the HBM spec peak.  The program moves '
+                            'fewer bytes than that accounting (gates evaluated inside their reader never touch memory, shared '
+                            'operands hit in L2): frac_traffic = measured L2<->fabric bytes (traffic x launches) / the same time '
+                            '/ the same peak, and `binding` names the resource that actually limits the kernel.  A level is one '
+                            'kernel per stream (lane shares run concurrently), so rocprofv3 lists launches_per_step x '
+                            'concurrent_streams kernels whose durations overlap',
+                    'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch}
+        if traffic is not None:
+            roofline['traffic_bytes_per_step'] = traffic * max(wide_launches, 1)
+            roofline['frac_traffic'] = traffic * max(wide_launches, 1) / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        be = binding_evidence(args.workload)
+        if be:
+            roofline['binding'] = be.get('binding')
+            roofline['binding_evidence'] = be.get('evidence')
+        elif structured:
+            roofline['binding'] = 'launch latency'
+            roofline['binding_evidence'] = ('%d launches of a few thousand entries per replay: the kernels are shorter than the '
+                                            'dependent-launch boundary' % info['launches'])
+        if hbm_variant is not None:
+            roofline['hbm_variant'] = hbm_variant
         out = {
             'metric': metric,
-            'value': value, 'unit': 'gate-ops/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': value, 'unit': 'backend-ops/s' if structured else 'gate-ops/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': dtype, 'data': 'synthetic',
             'config': {'workload': wl_name,
                        'relation_messages': host['messages'], 'relation_bytes': host['relation_bytes'],
                        'backend_ops_per_witness': int(len(kinds)), 'levels': info['levels'],
-                       'launches_per_step': info['launches'], 'wire_table_slots': info['slots'],
+                       'launches_per_step': info['launches'], 'sequential_launches': info['sequential_launches'],
+                       'wire_table_slots': info['slots'],
                        'program_entries': info['device_ops'],
-                       'gates_evaluated_inside_their_reader': int(len(kinds)) - info['device_ops'],
+                       'backend_ops_without_an_entry_of_their_own': int(len(kinds)) - info['device_ops'],
                        'wire_table_MB': round(ev.table_bytes / 1e6, 1), 'lane_group': args.lane_group,
                        'parallelism': 'witness lanes sharded over %d rank(s) on %d device(s); one all-reduce of 2 x u64 (%s)'
                                       % (world, min(world, n_dev), 'none' if world == 1 else 'RCCL' if backend == 'nccl' else backend + ' rehearsal'),
                        'pcie_inclusive_ms_per_step': None if pcie_ms is None else round(pcie_ms, 3),
                        'satisfied': total[0], 'failed': total[1], 'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')},
+                       'flatten_backend_ops_per_s': round(len(kinds) / max(host['ingest_and_record_s'], 1e-9)),
                        'relation_in_to_first_verdict': first_verdict, 'tape_windows': ev.stream_info()['windows']},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': kernel, 'launches_per_step': wide_launches,
-                         'concurrent_streams': 1 if lds else args.streams,
-                         'note': 'achieved = algorithmic bytes of the timed replay / its HIP-event time on the engine '
-                                 'stream; a level launch is issued as one kernel per stream (lane shares run '
-                                 'concurrently), so rocprofv3 lists launches_per_step x concurrent_streams kernels '
-                                 'whose durations overlap',
-                         'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch},
+            'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates, ev)

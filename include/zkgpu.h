@@ -134,8 +134,11 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 
 /* options: "max_tape_ops" = N (default 2^30: loops are unrolled, this bounds a corrupt loop bound),
  * "streams" = 1..4 (lane shares replayed concurrently, default 2),
- * "sort_by_operand" = 0|1|2 (order of the ops inside a level: tape order, by first operand, or a depth-first
- * walk over shared operands so that the readers of a wire run back to back; default 2),
+ * "sort_by_operand" = 0|1|2|3 (order of the ops inside a level: tape order, by first operand, that followed by a
+ * depth-first walk over shared operands so that the readers of a wire run back to back, or the walk alone; default 3:
+ * the pre-sort buys nothing measurable on C2 and costs a third of the scheduling time),
+ * "bank_aware" = 0|1 (GF(2): order the ops of a level and number the wire-table slots so that the 32 lanes one LDS
+ * instruction serves read and write 32 different banks -- and / xor operands are swapped where that helps; default 1),
  * "graph" = 0|1 (replay the captured hipGraph of the whole launch sequence instead of issuing it launch by launch;
  * default 0: measured slower on ROCm 7.2),
  * "xcd_map" = 0|1 (launches over a multiple of 8 lane blocks give each XCD its own lane blocks; default 1),

@@ -63,7 +63,7 @@ struct zkgpu_session {
   uint32_t declared_inst = 0, declared_wit = 0;
   uint32_t lane_group = 0;
   int bool_path = 0;      // 0 auto, 1 HBM-table kernel, 2 LDS-resident kernel
-  int sort_by_operand = 2;
+  int sort_by_operand = 3;
   bool fuse = true;
   bool propagate_copies = true;
   bool pair = true;
@@ -75,6 +75,7 @@ struct zkgpu_session {
   uint32_t hot_waves = 0;
   uint32_t stream_window = 0;        // option "stream": tape entries per window, 0 = schedule everything at finalize
   uint32_t sched_threads = 0;
+  bool bank_aware = true;
   std::unique_ptr<StreamState> stream;
   double stream_busy_s = 0;
   uint32_t stream_windows = 0;
@@ -129,6 +130,15 @@ uint32_t lane_inputs(const zkgpu_session* s, bool instance) {
                   : std::max<uint32_t>(t.n_witness, std::max<uint32_t>(s->declared_wit, (uint32_t)s->backend.lane0_witnesses().size()));
 }
 
+// k-th value-returning backend call -> tape index (flattened wire k of IRFlattener's numbering)
+void need_value_index(zkgpu_session* s) {
+  const Tape& t = s->backend.tape();
+  if (!s->value_op_index.empty() || !t.size()) return;
+  s->value_op_index.reserve(t.n_value_ops);
+  for (size_t i = 0; i < t.size(); ++i)
+    if (t.kind[i] != TK_ASSERT) s->value_op_index.push_back((uint32_t)i);
+}
+
 ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
   ScheduleOptions opt;
   opt.retain_all = retain_all;
@@ -138,6 +148,7 @@ ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
   opt.fuse = s->fuse;
   opt.propagate_copies = s->propagate_copies;
   opt.threads = s->sched_threads;
+  opt.bank_aware = s->bank_aware;
   return opt;
 }
 
@@ -619,9 +630,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     }
     s->backend.set_window(0, nullptr, nullptr);
     s->retain_all = opt.retain_all;
-    s->value_op_index.clear();
-    for (size_t i = 0; i < t.size(); ++i)
-      if (t.kind[i] != TK_ASSERT) s->value_op_index.push_back((uint32_t)i);
+    s->value_op_index.clear();  // built on first use (need_value_index): only trace dumps and the R1CS entry points read it
     s->engine_loaded = false;
     Engine::validate_program(s->sched, lane_inputs(s, true), lane_inputs(s, false));  // host check of every index the kernels use
     s->finalized = true;
@@ -753,6 +762,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       const long n = atol(v.c_str());
       s->stream_window = n <= 0 ? 0 : n == 1 ? 131072u : (uint32_t)std::max<long>(n, 16);
       s->backend.set_window(s->stream_window, s->stream_window ? stream_cut : nullptr, s);
+    } else if (k == "bank_aware") {
+      s->bank_aware = v != "0";
     } else if (k == "schedule_threads") {
       s->sched_threads = (uint32_t)std::max(0, atoi(v.c_str()));
     } else if (k == "hot_waves") {
@@ -774,7 +785,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     } else if (k == "fuse") {
       s->fuse = v != "0";
     } else if (k == "sort_by_operand") {
-      s->sort_by_operand = std::max(0, std::min(2, atoi(v.c_str())));
+      s->sort_by_operand = std::max(0, std::min(3, atoi(v.c_str())));
     } else if (k == "validate") {
       if (v == "prover") s->validator.reset(new Validator(Validator::new_as_prover()));
       else if (v == "verifier") s->validator.reset(new Validator(Validator::new_as_verifier()));
@@ -919,6 +930,7 @@ int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, ui
   return guarded(s, [&] {
     need_engine(s);
     if (!s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) is required for trace dumps");
+    need_value_index(s);
     if (first + count > s->value_op_index.size()) throw std::runtime_error("trace range out of bounds");
     std::vector<uint32_t> slots(count);
     for (uint64_t k = 0; k < count; ++k) slots[k] = s->sched.slot_of[s->value_op_index[first + k]];
@@ -1019,6 +1031,7 @@ int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_p
     }
     for (uint32_t i = 0; i < n_coefs; ++i)
       r.coefs.emplace_back(coef_bytes + (size_t)i * coef_width, coef_bytes + (size_t)(i + 1) * coef_width);
+    need_value_index(s);
     const uint64_t n_ops = s->value_op_index.size();
     r.n_vars = n_ops + n_extra_vars;
     s->r1cs = std::move(r);
@@ -1065,6 +1078,7 @@ int zkgpu_r1cs_get_vars(zkgpu_session* s, const uint64_t* vars, uint32_t n_vars,
   return guarded(s, [&] {
     need_engine(s);
     if (!s->r1cs_ready || !s->r1cs_loaded_csr) throw std::runtime_error("zkgpu_r1cs_get_vars needs a CSR loaded with zkgpu_r1cs_load_csr");
+    need_value_index(s);
     const uint64_t n_ops = s->value_op_index.size();
     std::vector<uint32_t> slots(n_vars);
     for (uint32_t k = 0; k < n_vars; ++k) {

@@ -187,16 +187,37 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
       default: fail(i, "an unknown kind");
     }
   };
-  for (size_t i = 0; i < s.ops2.size() && s.fused; ++i) {
-    const DevOp2& d = s.ops2[i];
-    const uint32_t kind = d.kind & 0xFF, ea = (d.kind >> 8) & 3, eb = (d.kind >> 10) & 3, second = (d.kind >> 12) & 3;
-    if ((d.kind >> 14) != 0 || ((ea || eb || second) && kind != TK_ADD && kind != TK_MUL)) fail(i, "its kind word");
-    check(i, kind, d.dst, d.a0, d.a1, d.b0, d.b1, ea, eb, second, d.pad0, d.pad1);
+  // (a million entries: checked in slices on a few threads, the first complaint wins)
+  const size_t total = s.fused ? s.ops2.size() : s.ops.size();
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t parts = total < (1u << 17) ? 1 : std::min<size_t>(8, hw ? hw : 1);
+  std::vector<std::string> complaint(parts);
+  auto slice = [&](size_t part) {
+    try {
+      const size_t lo = total * part / parts, hi = total * (part + 1) / parts;
+      for (size_t i = lo; i < hi; ++i) {
+        if (s.fused) {
+          const DevOp2& d = s.ops2[i];
+          const uint32_t kind = d.kind & 0xFF, ea = (d.kind >> 8) & 3, eb = (d.kind >> 10) & 3, second = (d.kind >> 12) & 3;
+          if ((d.kind >> 14) != 0 || ((ea || eb || second) && kind != TK_ADD && kind != TK_MUL)) fail(i, "its kind word");
+          check(i, kind, d.dst, d.a0, d.a1, d.b0, d.b1, ea, eb, second, d.pad0, d.pad1);
+        } else {
+          const DevOp& d = s.ops[i];
+          check(i, d.kind, d.dst, d.a, 0, d.b, 0, 0, 0, 0, 0, 0);
+        }
+      }
+    } catch (const std::exception& e) {
+      complaint[part] = e.what();
+    }
+  };
+  {
+    std::vector<std::thread> pool;
+    for (size_t part = 1; part < parts; ++part) pool.emplace_back(slice, part);
+    slice(0);
+    for (auto& th : pool) th.join();
   }
-  for (size_t i = 0; i < s.ops.size() && !s.fused; ++i) {
-    const DevOp& d = s.ops[i];
-    check(i, d.kind, d.dst, d.a, 0, d.b, 0, 0, 0, 0, 0, 0);
-  }
+  for (const std::string& c : complaint)
+    if (!c.empty()) throw std::runtime_error(c);
   size_t n_ops = s.fused ? s.ops2.size() : s.ops.size();
   for (const Launch& L : s.launches)
     if ((uint64_t)L.first + L.count > n_ops) throw std::runtime_error("Engine: a launch reaches past the program");

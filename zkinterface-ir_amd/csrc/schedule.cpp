@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 namespace zki {
@@ -122,6 +125,8 @@ struct StreamScheduler::Impl {
   std::vector<uint8_t> flags;
   std::vector<uint32_t> open_list;   // values with a slot that may still get readers
   std::vector<uint32_t> free_slots;
+  std::vector<std::vector<uint32_t>> free_by_bank;  // GF(2), bank-aware slots: free slots per LDS bank
+  std::vector<uint32_t> next_fresh;                 // smallest never-used slot of each bank
   uint32_t n_slots = 0;
   uint32_t n_windows = 0;
 
@@ -429,7 +434,7 @@ void StreamScheduler::Impl::assign_slots() {
     for (uint32_t h : open_list) {
       if (!closed(h)) { open_list[keep++] = h; continue; }
       if (last_use[h] < base || n_wlevels == 0) {
-        free_slots.push_back(s.slot_of[h]);
+        free_slots.push_back(s.slot_of[h]);   // (never taken with bank-aware slots: GF(2) is one window)
       } else {
         ext.push_back({h, ext_head[last_use[h] - base]});
         ext_head[last_use[h] - base] = (uint32_t)ext.size() - 1;
@@ -437,7 +442,36 @@ void StreamScheduler::Impl::assign_slots() {
     }
     open_list.resize(keep);
   }
-  auto take_slot = [&]() {
+  // GF(2): the LDS-resident kernel keeps a slice's wire table in LDS (device/bool_kernels.hpp), where what costs is
+  // bank conflicts -- 32 lanes gathering random slots hit some bank 3 to 4 times.  The scheduler owns both the order
+  // of a level's ops and the slot numbering, so it can make the accesses of one LDS instruction hit 32 different
+  // banks: `banked` (below) orders the ops of a (level, kind) run so that the 32 ops one `ds_read_b32` group serves
+  // read operands from different banks, and gives the op at lane k a result slot in bank k mod 32.
+  const bool banked = s.boolean_path && opt.bank_aware && !opt.retain_all;
+  constexpr uint32_t kBanks = 32;
+  auto take_slot = [&](uint32_t bank) {
+    if (banked && bank == kInf) {
+      // no bank wanted (ops of narrow levels, pair seconds): any free slot, else the smallest slot never used
+      uint32_t best = kInf;
+      for (uint32_t b = 0; b < kBanks; ++b)
+        if (!free_by_bank[b].empty() && (best == kInf || free_by_bank[b].size() > free_by_bank[best].size())) best = b;
+      if (best == kInf)
+        for (uint32_t b = 0; b < kBanks; ++b)
+          if (best == kInf || next_fresh[b] < next_fresh[best]) best = b;
+      bank = best;
+    }
+    if (banked) {
+      std::vector<uint32_t>& f = free_by_bank[bank];
+      if (!f.empty()) {
+        const uint32_t slot = f.back();
+        f.pop_back();
+        return slot;
+      }
+      const uint32_t slot = next_fresh[bank];
+      next_fresh[bank] += kBanks;
+      n_slots = std::max(n_slots, slot + 1);
+      return slot;
+    }
     if (!free_slots.empty()) {
       const uint32_t slot = free_slots.back();
       free_slots.pop_back();
@@ -445,8 +479,108 @@ void StreamScheduler::Impl::assign_slots() {
     }
     return n_slots++;
   };
-  auto place = [&](uint32_t i) {
-    s.slot_of[i] = take_slot();
+  auto give_back = [&](uint32_t slot) {
+    if (banked) free_by_bank[slot % kBanks].push_back(slot);
+    else free_slots.push_back(slot);
+  };
+  if (banked && free_by_bank.empty()) {
+    free_by_bank.resize(kBanks);
+    next_fresh.resize(kBanks);
+    for (uint32_t b = 0; b < kBanks; ++b) next_fresh[b] = b;
+  }
+  // Order the ops of one (level, kind) run [k0, k1) of `order` for the LDS kernel.  Thread t of the workgroup executes
+  // ops 2t and 2t + 1 of a 2048-op row, so one LDS instruction of a wave serves the even (or the odd) ops of a
+  // 128-op block, in two groups of 32 lanes: positions q and q' of the run conflict when q / 64 == q' / 64, q % 2 == q' % 2
+  // and their operands (or their results) share a bank.  Greedy: fill group after group, taking for each lane an op
+  // whose operand banks are still unused in the group; what cannot be placed conflict-free fills the holes.
+  auto bank_order = [&](uint64_t k0, uint64_t k1) {
+    const size_t cnt = k1 - k0;
+    if (cnt < 2 * kBanks) return;
+    const bool two = n_inputs(kind[order[k0] - lo]) == 2;
+    std::vector<uint32_t> run(order.begin() + k0, order.begin() + k1);
+    std::vector<std::vector<uint32_t>> by_a(kBanks);
+    for (uint32_t i : run) {
+      // and / xor commute: take as operand a the one whose bank has fewer ops so far (two choices per op keep the 32
+      // buckets within a few ops of each other, so the groups stay conflict-free until the run is almost used up)
+      if (two) {
+        const uint32_t A = s.slot_of[ra[i - lo]] % kBanks, B = s.slot_of[rb[i - lo]] % kBanks;
+        if (by_a[A].size() > by_a[B].size()) std::swap(ra[i - lo], rb[i - lo]);
+      }
+      by_a[s.slot_of[ra[i - lo]] % kBanks].push_back(i);
+    }
+    std::vector<uint32_t> out(cnt, kInf);
+    const size_t n_groups = (cnt + 2 * kBanks - 1) / (2 * kBanks) * 2;
+    // groups in run order: block g / 2, parity g % 2 -> positions (g / 2) * 64 + (g % 2) + 2 * lane
+    auto pos_of = [&](size_t g, uint32_t lane) { return (g / 2) * 64 + (g % 2) + 2 * (size_t)lane; };
+    std::vector<uint32_t> used_a(n_groups, 0), used_b(n_groups, 0);
+    // ops left per operand-b bank: a lane prefers the candidate whose b bank has most ops left, so that the banks
+    // are used up evenly and the last groups of the run still find 32 different ones
+    uint32_t left_b[kBanks] = {0};
+    if (two)
+      for (uint32_t i : run) ++left_b[s.slot_of[rb[i - lo]] % kBanks];
+    // take from bucket `bank` an op whose operand-b bank is free in the group (looking at the last `look` ops)
+    auto take = [&](uint32_t bank, uint32_t ub, size_t look) {
+      std::vector<uint32_t>& bucket = by_a[bank];
+      look = std::min(look, bucket.size());
+      size_t best = (size_t)-1;
+      uint32_t best_left = 0;
+      for (size_t c = 0; c < look; ++c) {
+        const uint32_t i = bucket[bucket.size() - 1 - c];
+        if (!two) { best = c; break; }
+        const uint32_t bb = s.slot_of[rb[i - lo]] % kBanks;
+        if (!((ub >> bb) & 1) && left_b[bb] > best_left) {
+          best = c;
+          best_left = left_b[bb];
+        }
+      }
+      if (best == (size_t)-1) return kInf;
+      const uint32_t i = bucket[bucket.size() - 1 - best];
+      std::swap(bucket[bucket.size() - 1 - best], bucket.back());
+      bucket.pop_back();
+      if (two) --left_b[s.slot_of[rb[i - lo]] % kBanks];
+      return i;
+    };
+    auto put = [&](size_t g, uint32_t lane, uint32_t i) {
+      out[pos_of(g, lane)] = i;
+      used_a[g] |= 1u << (s.slot_of[ra[i - lo]] % kBanks);
+      if (two) used_b[g] |= 1u << (s.slot_of[rb[i - lo]] % kBanks);
+    };
+    for (size_t g = 0; g < n_groups; ++g) {
+      uint32_t holes[kBanks], n_holes = 0;
+      for (uint32_t lane = 0; lane < kBanks; ++lane) {
+        if (pos_of(g, lane) >= cnt) continue;
+        // the operand-a bank of this lane: rotate with the group so that no bank's bucket is always served last
+        const uint32_t i = take((lane + (uint32_t)g) % kBanks, used_b[g], 24);
+        if (i != kInf) put(g, lane, i);
+        else holes[n_holes++] = lane;
+      }
+      // lanes still empty: any bucket whose bank the group does not read yet, looking deeper for a free b bank
+      for (uint32_t h = 0; h < n_holes; ++h) {
+        for (uint32_t bank = 0; bank < kBanks; ++bank) {
+          if ((used_a[g] >> bank) & 1) continue;
+          const uint32_t i = take(bank, used_b[g], 512);
+          if (i != kInf) { put(g, holes[h], i); break; }
+        }
+      }
+    }
+    // what is left cannot be placed without a conflict: fill the remaining holes, a free operand-a bank first
+    for (size_t g = 0; g < n_groups; ++g)
+      for (uint32_t lane = 0; lane < kBanks; ++lane) {
+        const size_t q = pos_of(g, lane);
+        if (q >= cnt || out[q] != kInf) continue;
+        uint32_t pick_bank = kInf;
+        for (uint32_t bank = 0; bank < kBanks && pick_bank == kInf; ++bank)
+          if (!by_a[bank].empty() && !((used_a[g] >> bank) & 1)) pick_bank = bank;
+        for (uint32_t bank = 0; bank < kBanks && pick_bank == kInf; ++bank)
+          if (!by_a[bank].empty()) pick_bank = bank;
+        const uint32_t i = by_a[pick_bank].back();
+        by_a[pick_bank].pop_back();
+        put(g, lane, i);
+      }
+    for (size_t q = 0; q < cnt; ++q) order[k0 + q] = out[q];
+  };
+  auto place = [&](uint32_t i, uint32_t bank = kInf) {
+    s.slot_of[i] = take_slot(bank);
     if (opt.retain_all) return;
     if (closed(i)) {
       const uint32_t lu = std::max(last_use[i], s.level_of[i]) - base;
@@ -457,15 +591,24 @@ void StreamScheduler::Impl::assign_slots() {
     }
   };
   auto release_level = [&](uint32_t l) {
-    for (uint32_t h = expire_head[l]; h != kInf; h = expire_next[h - lo]) free_slots.push_back(s.slot_of[h]);
-    for (uint32_t e = ext_head[l]; e != kInf; e = ext[e].next) free_slots.push_back(s.slot_of[ext[e].h]);
+    for (uint32_t h = expire_head[l]; h != kInf; h = expire_next[h - lo]) give_back(s.slot_of[h]);
+    for (uint32_t e = ext_head[l]; e != kInf; e = ext[e].next) give_back(s.slot_of[ext[e].h]);
   };
   for (uint32_t l = 0; l < n_wlevels; ++l) {
     if (!opt.retain_all && l > 0) release_level(l - 1);
+    uint64_t run0 = level_start[l];   // start of the current (level, kind) run
+    bool wide_run = false;            // long enough for whole groups of 32 lanes
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
+      if (banked && (k == level_start[l] || kind[order[k] - lo] != kind[order[k - 1] - lo])) {
+        run0 = k;
+        uint64_t e = k;
+        while (e < level_start[l + 1] && kind[order[e] - lo] == kind[order[k] - lo]) ++e;
+        wide_run = e - k >= 2 * kBanks;
+        if (wide_run && n_inputs(kind[order[k] - lo]) >= 1 && kind[order[k] - lo] != TK_ASSERT) bank_order(k, e);
+      }
       const uint32_t i = order[k];
       if (kind[i - lo] == TK_ASSERT || kind[i - lo] == TK_NOP) continue;
-      place(i);
+      place(i, (banked && wide_run) ? (uint32_t)(((k - run0) / 2) % kBanks) : kInf);   // lane of the op's thread, modulo the banks
       if (!pair_second.empty() && pair_second[i - lo] != kInf) place(pair_second[i - lo]);  // the second value of a pair entry
     }
   }
@@ -476,6 +619,7 @@ void StreamScheduler::Impl::assign_slots() {
 void StreamScheduler::Impl::order_levels() {
   // ---- order of the entries inside a level (independent per level: done on `threads` threads) ----
   if (!opt.sort_by_operand) return;
+  if (s.boolean_path && opt.bank_aware && !opt.retain_all) return;   // ordered for the LDS banks while the slots were assigned
   parallel_levels(n_wlevels, threads, [&](uint32_t l) {
     // inside a (level, kind) run, order the ops by the slot of their first operand: gates that read
     // the same wire become neighbours (same workgroup), so the repeat read is an L1/L2 hit
@@ -484,7 +628,7 @@ void StreamScheduler::Impl::order_levels() {
       uint64_t e = k;
       const uint8_t kd = kind[order[k] - lo];
       while (e < level_start[l + 1] && kind[order[e] - lo] == kd) ++e;
-      if (n_inputs(kd) >= 1 && e - k > 1)
+      if (n_inputs(kd) >= 1 && e - k > 1 && (opt.sort_by_operand != 3 || s.boolean_path))
         std::stable_sort(order.begin() + k, order.begin() + e, [&](uint32_t x, uint32_t y) {
           const uint32_t ax = inner(ra[x - lo]) ? ra[ra[x - lo] - lo] : ra[x - lo];
           const uint32_t ay = inner(ra[y - lo]) ? ra[ra[y - lo] - lo] : ra[y - lo];
@@ -667,6 +811,12 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
   const uint32_t n = w.hi - w.lo;
   m.n_wlevels = 0;
   m.order.clear();
+  static const bool profile = getenv("ZKI_SCHED_PROFILE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t0 = now();
+  double stage[8] = {0};
+  int si = 0;
+  auto lap = [&] { auto t1 = now(); stage[si++] = std::chrono::duration<double>(t1 - t0).count(); t0 = t1; };
   if (n) {
     m.kind.assign(w.kind, w.kind + n);
     m.state.assign(n, ST_ENTRY);
@@ -674,9 +824,13 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     m.rb.assign(w.b, w.b + n);
     m.rewrite_ladders(w);
     m.propagate_copies();
+    lap();
     m.levelise();
+    lap();
     m.fuse_and_pair();
+    lap();
     m.order_by_level();
+    lap();
   } else {
     m.kind.clear();
     m.state.clear();
@@ -685,10 +839,17 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
   }
   m.assign_slots();  // also with no ops of its own: values the last window left open may have been closed since
   if (n) {
+    lap();
     m.order_levels();
+    lap();
     m.emit_entries();
     m.emit_launches();
+    lap();
     m.s.n_levels = m.base + m.n_wlevels;
+    if (profile)
+      fprintf(stderr, "[schedule] window %u: %u ops, %u levels | copies %.1f levelise %.1f fuse %.1f sort %.1f slots %.1f order %.1f emit %.1f ms\n",
+              m.n_windows, n, m.n_wlevels, stage[0] * 1e3, stage[1] * 1e3, stage[2] * 1e3, stage[3] * 1e3, stage[4] * 1e3,
+              stage[5] * 1e3, stage[6] * 1e3);
   }
   ++m.n_windows;
   m.s.n_slots = std::max<uint32_t>(m.n_slots, 1);

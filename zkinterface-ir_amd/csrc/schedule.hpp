@@ -45,13 +45,14 @@ struct Launch {
 struct ScheduleOptions {
   bool retain_all = false;          // every value keeps its own slot (wire dumps for parity tests)
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
-  int sort_by_operand = 2;          // order of a level's ops: 0 tape order, 1 by first-operand slot, 2 shared-operand walk
+  int sort_by_operand = 3;          // order of a level's ops: 0 tape order, 1 by first-operand slot, 2 that + shared-operand walk, 3 the walk alone
   bool fuse = true;                 // absorb single-reader Add/Mul producers into their consumer (never with retain_all)
   bool fermat = true;               // a Switch exponent ladder x^(p-1), p prime, becomes one `x != 0` entry (never with retain_all)
   bool pair = true;                 // one entry for the two same-level readers of a producer nobody else reads (never with retain_all)
   bool propagate_copies = true;     // readers use a copy's source; unobserved copies are not materialised (never with retain_all)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
   uint32_t threads = 0;             // worker threads for the per-level ordering (0 = min(8, hardware threads))
+  bool bank_aware = true;           // GF(2): order the ops and number the slots so that one LDS instruction hits 32 banks
 };
 
 struct Schedule {

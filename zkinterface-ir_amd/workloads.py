@@ -333,5 +333,84 @@ class R1csSynthetic:
         return w
 
 
+class StructuredArith:
+    """A structured relation of about a million backend calls (the shape of the reference's own example,
+    rust/src/producers/examples.rs:72-212, scaled up): a `For` loop of N iterations over a named function that calls
+    another function and multiplexes two anonymous branches with a `Switch`, followed by a second `For` loop (anonymous
+    body) that compares every result with an expected instance value.  Nothing here is flat: the host has to inline
+    the calls, unroll the loops, copy wires in and out of every scope (evaluator.rs:698-746) and build the 352-product
+    exponent ladder of each of the 2N case weights (evaluator.rs:801-839) -- about 745 backend calls per iteration
+    over BN254.
+
+      step(o; a, b, c):  t = mul(a, b);  switch c { 0: o = t + a;  1: o = t * b }
+
+    Wire ids: a_i = i, b_i = N + i, c_i = 2N + i (witness), o_i = 3N + i, e_i = 4N + i (instance)."""
+
+    def __init__(self, N=1408, seed=0x57C7, p=BN254_R):
+        self.N, self.seed, self.p = N, seed, p
+        self.mod_le = int_to_le(p)
+        self.width = 8 * ((p.bit_length() + 63) // 64)
+        self.n_instance = N
+        self.n_witness = 3 * N
+        self.n_out = N
+
+    def relation_messages(self):
+        from .sieve_writer import write_relation
+        N = self.N
+        neg_one = int_to_le(self.p - 1)
+        mul = 'wl::mul'
+        step = 'wl::step'
+        functions = [
+            (mul, 1, 2, 0, 0, [('mul', 0, 1, 2)]),
+            (step, 1, 3, 0, 0, [
+                ('call', mul, [4], [1, 2]),                                   # t = a * b
+                ('switch', 3, [0], [bytes([0]), bytes([1])], [
+                    ('anon', [4, 1], 0, 0, [('add', 0, 1, 2)]),              # case 0: t + a
+                    ('anon', [4, 2], 0, 0, [('mul', 0, 1, 2)]),              # case 1: t * b
+                ]),
+                ('free', 4, None),
+            ]),
+        ]
+        gates = [('witness', k) for k in range(3 * N)]
+        gates.append(('for', 'i', 0, N - 1, [(3 * N, 4 * N - 1)],
+                      ('call', step, [('add', ('name', 'i'), ('const', 3 * N))],
+                       [('name', 'i'), ('add', ('name', 'i'), ('const', N)), ('add', ('name', 'i'), ('const', 2 * N))])))
+        gates.append(('free', 0, 3 * N - 1))
+        gates += [('instance', 4 * N + k) for k in range(N)]
+        gates.append(('for', 'j', 0, N - 1, [],
+                      ('anon', [], [('add', ('name', 'j'), ('const', 3 * N)), ('add', ('name', 'j'), ('const', 4 * N))], 0, 0,
+                       [('mulc', 2, 1, neg_one), ('add', 3, 0, 2), ('assert_zero', 3)])))
+        gates.append(('free', 3 * N, 5 * N - 1))
+        return [write_relation(self.mod_le, '@add,@mul,@mulc,', '@for,@switch,@function,', functions, gates)]
+
+    def inputs(self, batch, lane_offset=0, corrupt_every=97):
+        """(instances [batch][N][width], witnesses [batch][3N][width], lanes made false); the expected values are the
+        closed form of `step` in Python integers, off by one on every `corrupt_every`-th lane (global index)."""
+        N, p = self.N, self.p
+        ab = random_field_elements(self.seed + 0x3000 + lane_offset * 2 * N * 4, (batch, 2 * N), p)[..., :self.width]
+        idx = (np.arange(batch * N, dtype=np.uint64) + np.uint64(lane_offset * N)).reshape(batch, N)
+        with np.errstate(over='ignore'):
+            c = (splitmix64(np.uint64(self.seed + 99) + idx) & np.uint64(1)).astype(np.uint8)
+        wit = np.zeros((batch, 3 * N, self.width), dtype=np.uint8)
+        wit[:, :2 * N] = ab
+        wit[:, 2 * N:, 0] = c
+        inst = np.zeros((batch, N, self.width), dtype=np.uint8)
+        bad = 0
+        for lane in range(batch):
+            row = ab[lane].reshape(2 * N, self.width).tobytes()
+            vals = [int.from_bytes(row[k * self.width:(k + 1) * self.width], 'little') for k in range(2 * N)]
+            out = bytearray()
+            for i in range(N):
+                a, b = vals[i], vals[N + i]
+                t = a * b % p
+                o = t * b % p if c[lane, i] else (t + a) % p
+                if i == 0 and corrupt_every and (lane + lane_offset) % corrupt_every == 0:
+                    o = (o + 1) % p
+                out += o.to_bytes(self.width, 'little')
+            bad += int(bool(corrupt_every) and (lane + lane_offset) % corrupt_every == 0)
+            inst[lane] = np.frombuffer(bytes(out), dtype=np.uint8).reshape(N, self.width)
+        return inst, wit, bad
+
+
 def expected_satisfied(batch, lane_offset=0, corrupt_every=97):
     return batch - sum(1 for i in range(batch) if (i + lane_offset) % corrupt_every == 0)
