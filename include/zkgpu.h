@@ -144,6 +144,15 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "xcd_map" = 0|1 (launches over a multiple of 8 lane blocks give each XCD its own lane blocks; default 1),
  * "level_ops_per_wave" = 1..8 (program entries of a wide level walked by one wave, interleaved over the 4 waves
  * of a workgroup; default 1: with the Add/Mul kernel at 60 VGPRs = 8 waves per SIMD one entry per wave measured fastest),
+ * "devices" = "0,1,...,7" (one process driving several GPUs, SURVEY.md 8b/8e: the lanes of a batch are split into
+ * contiguous shares of whole lane blocks, one engine per listed HIP device, each fed from a host thread of its own --
+ * a replay is hundreds of kernel launches; the program is replicated, no data-path collective.  zkgpu_counts combines
+ * the per-device {satisfied, failed} counters with one RCCL all-reduce (ncclCommInitAll; loaded with dlopen on first
+ * use) when the listed devices are distinct, and by a host sum when a device is listed more than once -- the
+ * rehearsal of the lane split on a one-GPU box.  Per-lane results, violations and wire dumps are gathered in lane
+ * order.  Not available with several devices: zkgpu_set_inputs_device, zkgpu_counts_device, zkgpu_stream,
+ * zkgpu_replay_timed and the R1CS entry points.  Set before the first zkgpu_set_inputs* call.  Default: one engine on
+ * the thread's current device),
  * "stream" = 0 | 1 | N (streaming ingest, rust/src/consumers/evaluator.rs:286-301: the reference consumes a relation
  * as a stream of <= 100k-gate messages; with N > 0 the tape is cut into windows of about N recorded calls ("1" = 131072),
  * and a worker thread schedules each window -- and sends its program entries to the GPU -- as soon as it is complete,
@@ -199,6 +208,8 @@ size_t zkgpu_launch_timings(const zkgpu_session* s, float* ms, uint32_t* ops, si
 int zkgpu_counts(zkgpu_session* s, uint64_t out[2]);          /* {satisfied, failed} */
 void* zkgpu_counts_device(zkgpu_session* s);                  /* device uint64[2], for an RCCL all-reduce */
 void* zkgpu_stream(zkgpu_session* s);                         /* hipStream_t the replay runs on */
+int zkgpu_device_count(void);                                 /* GPUs the HIP runtime sees (-1: none / no runtime) */
+int zkgpu_n_engines(const zkgpu_session* s);                  /* engines the batch is split over (option "devices") */
 int zkgpu_lane_results(zkgpu_session* s, uint32_t* first_fail, uint32_t* flags); /* [batch] each */
 /* Evaluator::get_violations() of lane `lane`, '\n'-separated; returns the length needed */
 size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t cap);

@@ -1,0 +1,103 @@
+"""One process driving several GPUs (option "devices"; SURVEY.md 8b threading row, 8e): the lanes of a batch split
+over several engines, each on a host thread of its own, counts combined.  A one-GPU box lists its device several times
+("0,0,0"): same lane split, same threads, counts summed on the host (RCCL needs distinct devices and is used when the
+list has them -- that branch cannot run here).  Everything a caller can ask for must equal the single-engine answer."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import zkinterface_ir_amd as zk
+from helpers import REF_EXAMPLES, ROOT, batch_arrays, oracle_lane
+from zkinterface_ir_amd import workloads
+
+
+def test_devices_option_is_parsed_on_the_host():
+    ev = zk.Evaluator()
+    ev.set_option('devices', '0,1,2,3')
+    assert ev.n_engines == 4
+    ev.set_option('devices', '')
+    assert ev.n_engines == 1
+    with pytest.raises(zk.ZkGpuError, match='comma-separated list'):
+        ev.set_option('devices', '0,x')
+
+
+def _session(wl, batch, devices, inst, wit):
+    ev = zk.Evaluator()
+    if devices:
+        ev.set_option('devices', devices)
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in wl.relation_messages():
+        ev.ingest_message(m)
+    ev.finalize()
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    ev.replay()
+    ev.synchronize()
+    return ev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('batch,devices', [(700, '0,0,0'), (64, '0,0,0'), (130, '0,0'), (1000, '0,0,0,0,0')])
+def test_lane_split_over_engines_gives_the_single_engine_answers(batch, devices):
+    wl = workloads.StructuredArith(N=24)         # switch, calls, loops: violations name wires
+    inst, wit, bad = wl.inputs(batch, corrupt_every=7)
+    one = _session(wl, batch, None, inst, wit)
+    many = _session(wl, batch, devices, inst, wit)
+    assert many.n_engines == devices.count(',') + 1 and one.n_engines == 1
+    assert many.counts() == one.counts() == (batch - bad, bad)
+    f1, g1 = one.lane_results(batch)
+    f2, g2 = many.lane_results(batch)
+    assert np.array_equal(f1, f2) and np.array_equal(g1, g2)
+    for lane in (0, 1, 7, batch // 2, batch - 1):
+        assert many.get_violations(lane) == one.get_violations(lane)
+    # a second batch through the same engines, different size
+    b2 = max(1, batch // 3)
+    many.set_inputs(inst[:b2].tobytes(), wit[:b2].tobytes(), b2)
+    many.replay()
+    many.synchronize()
+    assert many.counts() == (b2 - sum(1 for i in range(b2) if i % 7 == 0), sum(1 for i in range(b2) if i % 7 == 0))
+    with pytest.raises(zk.ZkGpuError, match='not available with several devices'):
+        many.replay_timed()
+
+
+@pytest.mark.gpu
+def test_wire_values_are_gathered_in_lane_order():
+    wl = workloads.ArithLayered(W=128, D=5, n_instance0=8, n_out=4)
+    batch = 300
+    inst, wit = wl.inputs(batch)
+    msgs = wl.relation_messages(with_epilogue=False, free_last=False)
+    cols = {}
+    for devices in (None, '0,0,0'):
+        ev = zk.Evaluator()
+        if devices:
+            ev.set_option('devices', devices)
+        ev.declare_inputs(wl.n_instance0, wl.n_witness)
+        for m in msgs:
+            ev.ingest_message(m)
+        ev.finalize()
+        ev.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), batch)
+        ev.replay()
+        ev.synchronize()
+        cols[devices] = [ev.get(w, batch) for w in wl.output_wire_ids()]
+    assert cols[None] == cols['0,0,0']
+    lane = 200
+    iv = [int.from_bytes(inst[lane, k].tobytes(), 'little') for k in range(wl.n_instance0)]
+    wv = [int.from_bytes(wit[lane, k].tobytes(), 'little') for k in range(wl.n_witness)]
+    ref = oracle_lane(wl.mod_le, iv, wv, msgs, wl.width, trace=False)
+    assert [c[lane] for c in cols['0,0,0']] == [ref.get(w) for w in wl.output_wire_ids()]
+
+
+@pytest.mark.gpu
+def test_c_example_splits_a_batch_over_the_listed_devices(tmp_path):
+    exe = str(tmp_path / 'evaluate_batch_devices')
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'),
+                           os.path.join(ROOT, 'examples', 'evaluate_batch_devices.c'),
+                           '-L', os.path.dirname(zk.LIB_PATH), '-lzkgpu',
+                           '-Wl,-rpath,' + os.path.dirname(zk.LIB_PATH), '-o', exe])
+    r = subprocess.run([exe, '--devices', '0,0', '--batch', '200'] + REF_EXAMPLES, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert '200 statements over 2 engine(s) [devices 0,0]: 199 TRUE, 1 FALSE' in r.stdout
+    assert 'lane 0: TRUE' in r.stdout and 'lane 1: FALSE: Wire_' in r.stdout
+    r = subprocess.run([exe, '--batch', '64'] + REF_EXAMPLES, capture_output=True, text=True)   # every visible GPU
+    assert r.returncode == 0 and '63 TRUE, 1 FALSE' in r.stdout

@@ -104,6 +104,8 @@ def lib():
         'zkgpu_counts': (ci, [vp, u64p]),
         'zkgpu_counts_device': (vp, [vp]),
         'zkgpu_stream': (vp, [vp]),
+        'zkgpu_n_engines': (ci, [vp]),
+        'zkgpu_device_count': (ci, []),
         'zkgpu_lane_results': (ci, [vp, vp, vp]),
         'zkgpu_lane_violations': (sz, [vp, u32, ctypes.c_char_p, sz]),
         'zkgpu_dump_trace_values': (ci, [vp, u64, u64, vp]),
@@ -419,6 +421,10 @@ class Evaluator:
 
     def counts_device_ptr(self):
         return self.L.zkgpu_counts_device(self.h)
+
+    @property
+    def n_engines(self):
+        return int(self.L.zkgpu_n_engines(self.h))
 
     def stream_ptr(self):
         return self.L.zkgpu_stream(self.h)

@@ -55,6 +55,13 @@ struct zkgpu_session {
   TapeBackend backend;
   Evaluator<TapeBackend> ev;
   std::unique_ptr<Engine> engine;
+  // option "devices": the lanes of a batch are split over several engines, one per listed device (engine = the first,
+  // peers = the others), each driven from a host thread of its own; lane_first[k] = first lane of engine k's share
+  std::vector<int> devices;
+  std::vector<std::unique_ptr<Engine>> peers;
+  std::vector<uint32_t> lane_first;
+  std::unique_ptr<CountReducer> reducer;   // RCCL, when the devices are distinct
+  uint32_t batch = 0;
   Schedule sched;
   bool finalized = false;
   bool engine_loaded = false;   // the engine holds the finished program (a streamed ingest opens the engine earlier)
@@ -262,18 +269,117 @@ void stream_wait(zkgpu_session* s) {
   st.cv.wait(lk, [&] { return st.jobs.empty() && st.idle; });
 }
 
+std::vector<Engine*> all_engines(zkgpu_session* s) {
+  std::vector<Engine*> v;
+  if (s->engine) v.push_back(s->engine.get());
+  for (auto& p : s->peers) v.push_back(p.get());
+  return v;
+}
+
+// engines that hold lanes of the current batch
+std::vector<size_t> active_engines(const zkgpu_session* s) {
+  std::vector<size_t> v;
+  for (size_t k = 0; k + 1 < s->lane_first.size(); ++k)
+    if (s->lane_first[k + 1] > s->lane_first[k]) v.push_back(k);
+  return v;
+}
+
+// f(k) for every listed engine, each on a host thread of its own when there are several (a replay is hundreds of
+// kernel launches: one thread feeding eight GPUs would be the bottleneck); the first exception is re-thrown
+template <class F>
+void per_engine(const std::vector<size_t>& which, F&& f) {
+  if (which.size() <= 1) {
+    for (size_t k : which) f(k);
+    return;
+  }
+  std::vector<std::string> failed(which.size());
+  std::vector<std::thread> pool;
+  for (size_t t = 0; t < which.size(); ++t)
+    pool.emplace_back([&, t] {
+      try {
+        f(which[t]);
+      } catch (const std::exception& e) {
+        failed[t] = e.what();
+        if (failed[t].empty()) failed[t] = "error";
+      }
+    });
+  for (auto& th : pool) th.join();
+  for (const std::string& m : failed)
+    if (!m.empty()) throw std::runtime_error(m);
+}
+
 // The engine (and with it the HIP runtime / a GPU) is only touched by the
 // replay entry points; recording and scheduling are host work.
 void need_engine(zkgpu_session* s) {
   if (!s->finalized) throw std::runtime_error("zkgpu_finalize() has not been called");
   if (!s->engine || !s->engine_loaded) {
-    std::unique_ptr<Engine> e = s->engine ? std::move(s->engine) : std::unique_ptr<Engine>(new Engine());  // a streamed ingest opened it already
-    configure_engine(s, e.get());
-    e->set_writeback(s->n_pinned != 0);
-    e->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
-    if (s->r1cs_extra_vars) e->reserve_extra_slots(s->r1cs_extra_vars);
+    const int dev0 = s->devices.empty() ? -1 : s->devices[0];
+    // a streamed ingest opened the first engine already (on the current device)
+    std::unique_ptr<Engine> e = (s->engine && s->engine->device() == dev0) ? std::move(s->engine) : std::unique_ptr<Engine>(new Engine(dev0));
+    s->engine.reset();
+    s->peers.clear();
+    s->reducer.reset();
+    auto setup = [&](Engine* x) {
+      configure_engine(s, x);
+      x->set_writeback(s->n_pinned != 0);
+      x->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
+      if (s->r1cs_extra_vars) x->reserve_extra_slots(s->r1cs_extra_vars);
+    };
+    setup(e.get());
     s->engine = std::move(e);
+    for (size_t k = 1; k < s->devices.size(); ++k) {
+      s->peers.emplace_back(new Engine(s->devices[k]));
+      setup(s->peers.back().get());
+    }
+    s->lane_first.assign(s->peers.size() + 2, 0);
     s->engine_loaded = true;
+  }
+}
+
+void single_device_only(const zkgpu_session* s, const char* what) {
+  if (!s->peers.empty()) throw std::runtime_error(std::string(what) + " is not available with several devices (option \"devices\")");
+}
+
+// lanes of a batch over the engines: contiguous shares of whole lane blocks
+void split_lanes(zkgpu_session* s, uint32_t batch) {
+  const size_t n = s->peers.size() + 1;
+  const uint32_t unit = s->backend.field().is_two ? 4096u : 64u;
+  const uint32_t blocks = (batch + unit - 1) / unit;
+  s->lane_first.assign(n + 1, 0);
+  for (size_t k = 0; k <= n; ++k) s->lane_first[k] = std::min<uint64_t>(batch, (uint64_t)unit * ((uint64_t)blocks * k / n));
+  s->batch = batch;
+}
+
+// {satisfied, failed} of the whole batch: RCCL all-reduce over the engines' device counters when they sit on distinct
+// devices, the sum of the per-engine counters otherwise (several engines on one device: the rehearsal of the lane split)
+void total_counts(zkgpu_session* s, uint64_t out[2]) {
+  const std::vector<size_t> act = active_engines(s);
+  std::vector<Engine*> eng = all_engines(s);
+  if (s->peers.empty() || act.size() <= 1) {
+    out[0] = out[1] = 0;
+    for (size_t k : act.empty() ? std::vector<size_t>{0} : act) {
+      uint64_t c[2] = {0, 0};
+      eng[k]->download(nullptr, nullptr, c);
+      out[0] += c[0];
+      out[1] += c[1];
+    }
+    return;
+  }
+  bool distinct = act.size() == eng.size();
+  for (size_t i = 0; i < eng.size() && distinct; ++i)
+    for (size_t j = 0; j < i; ++j)
+      if (eng[i]->device() == eng[j]->device()) distinct = false;
+  if (distinct) {
+    if (!s->reducer) s->reducer.reset(new CountReducer(eng));
+    s->reducer->all_reduce(out);
+    return;
+  }
+  out[0] = out[1] = 0;
+  for (size_t k : act) {
+    uint64_t c[2] = {0, 0};
+    eng[k]->download(nullptr, nullptr, c);
+    out[0] += c[0];
+    out[1] += c[1];
   }
 }
 
@@ -329,8 +435,35 @@ void fetch_results(zkgpu_session* s) {
   need_engine(s);
   if (s->results_fresh) return;
   uint64_t counts[2];
-  s->engine->download(&s->first_fail, &s->flags, counts);
+  if (s->peers.empty()) {
+    s->engine->download(&s->first_fail, &s->flags, counts);
+  } else {
+    s->first_fail.clear();
+    s->flags.clear();
+    std::vector<Engine*> eng = all_engines(s);
+    for (size_t k : active_engines(s)) {   // shares are contiguous and in lane order
+      std::vector<uint32_t> ff, fl;
+      eng[k]->download(&ff, &fl, counts);
+      s->first_fail.insert(s->first_fail.end(), ff.begin(), ff.end());
+      s->flags.insert(s->flags.end(), fl.begin(), fl.end());
+    }
+  }
   s->results_fresh = true;
+}
+
+// out[lane][k][elem] of the listed slots for every lane of the batch, gathered from the engines that hold the lanes
+void dump_slots_all(zkgpu_session* s, const std::vector<uint32_t>& slots, std::vector<uint8_t>* out) {
+  if (s->peers.empty()) {
+    s->engine->dump_slots(slots, out);
+    return;
+  }
+  out->clear();
+  std::vector<Engine*> eng = all_engines(s);
+  for (size_t k : active_engines(s)) {
+    std::vector<uint8_t> part;
+    eng[k]->dump_slots(slots, &part);
+    out->insert(out->end(), part.begin(), part.end());
+  }
 }
 
 // pad / check one little-endian Value into a fixed-width slot; values that do
@@ -445,6 +578,7 @@ void r1cs_check_assignable(zkgpu_session* s, uint32_t first_row, uint32_t n_rows
 
 void r1cs_to_device(zkgpu_session* s) {
   need_engine(s);
+  single_device_only(s, "the R1CS row kernel");
   if (!s->r1cs_ready) throw std::runtime_error("no R1CS: call zkgpu_r1cs_from_tape or zkgpu_r1cs_load_csr");
   if (!s->r1cs_on_device) {
     s->engine->r1cs_upload(s->r1cs_rows_dev, s->r1cs_terms_dev, s->r1cs_coef_words);
@@ -699,8 +833,15 @@ int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launch
 int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* witnesses, uint32_t batch) {
   return guarded(s, [&] {
     need_engine(s);
-    s->engine->set_batch(batch);
-    s->engine->upload_inputs(instances, witnesses);
+    split_lanes(s, batch);
+    const uint32_t w = s->engine->elem_bytes();
+    const size_t irow = (size_t)lane_inputs(s, true) * w, wrow = (size_t)lane_inputs(s, false) * w;
+    std::vector<Engine*> eng = all_engines(s);
+    per_engine(active_engines(s), [&](size_t k) {
+      eng[k]->set_batch(s->lane_first[k + 1] - s->lane_first[k]);
+      eng[k]->upload_inputs(instances ? instances + irow * s->lane_first[k] : nullptr,
+                            witnesses ? witnesses + wrow * s->lane_first[k] : nullptr);
+    });
     s->results_fresh = false;
   });
 }
@@ -708,6 +849,8 @@ int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* 
 int zkgpu_set_inputs_device(zkgpu_session* s, const void* d_instances, const void* d_witnesses, uint32_t batch) {
   return guarded(s, [&] {
     need_engine(s);
+    single_device_only(s, "zkgpu_set_inputs_device");
+    split_lanes(s, batch);
     s->engine->set_batch(batch);
     s->engine->use_device_inputs(d_instances, d_witnesses);
     s->results_fresh = false;
@@ -726,6 +869,7 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
       throw std::runtime_error("the tape consumes more instance/witness values than the ingested messages hold");
     for (size_t k = 0; k < li.size(); ++k) put_value(li[k], &inst[k * w], w);
     for (size_t k = 0; k < lw.size(); ++k) put_value(lw[k], &wit[k * w], w);
+    split_lanes(s, 1);
     s->engine->set_batch(1);
     s->engine->upload_inputs(inst.data(), wit.data());
     s->results_fresh = false;
@@ -735,7 +879,7 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
 int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes) {
   return guarded(s, [&] {
     s->lane_group = lanes;
-    if (s->engine) s->engine->set_lane_group(lanes);
+    for (Engine* e : all_engines(s)) e->set_lane_group(lanes);
   });
 }
 
@@ -752,10 +896,25 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->backend.set_max_ops(strtoull(v.c_str(), nullptr, 10));
     } else if (k == "streams") {
       s->n_streams = (uint32_t)std::max(1, std::min(4, atoi(v.c_str())));
-      if (s->engine) s->engine->set_streams(s->n_streams);
+      for (Engine* e : all_engines(s)) e->set_streams(s->n_streams);
     } else if (k == "level_ops_per_wave") {
       s->level_ops_per_wave = (uint32_t)std::max(1, atoi(v.c_str()));
-      if (s->engine) s->engine->set_level_ops_per_wave(s->level_ops_per_wave);
+      for (Engine* e : all_engines(s)) e->set_level_ops_per_wave(s->level_ops_per_wave);
+    } else if (k == "devices") {
+      // "0,1,2,3" (HIP device indices; a device may be listed twice: two engines share it) or "" = the current device
+      if (s->engine_loaded) throw std::runtime_error("devices must be set before the first zkgpu_set_inputs* call");
+      std::vector<int> devs;
+      size_t at = 0;
+      while (at < v.size()) {
+        size_t end = v.find(',', at);
+        if (end == std::string::npos) end = v.size();
+        const std::string tok = v.substr(at, end - at);
+        if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) throw std::runtime_error("devices: a comma-separated list of device indices");
+        devs.push_back(atoi(tok.c_str()));
+        at = end + 1;
+      }
+      if (devs.size() > 64) throw std::runtime_error("devices: at most 64 engines");
+      s->devices = devs;
     } else if (k == "stream") {
       // tape entries per window; "1" = the default window of 131072 entries; before the first Relation message
       if (s->backend.tape().size() || s->finalized) throw std::runtime_error("stream must be set before the first Relation message");
@@ -768,14 +927,14 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->sched_threads = (uint32_t)std::max(0, atoi(v.c_str()));
     } else if (k == "hot_waves") {
       s->hot_waves = (uint32_t)std::max(0, atoi(v.c_str()));
-      if (s->engine) s->engine->set_hot_waves(s->hot_waves);
+      for (Engine* e : all_engines(s)) e->set_hot_waves(s->hot_waves);
     } else if (k == "graph") {
       if (v == "0" || v == "1") s->graph_mode = atoi(v.c_str());
       else throw std::runtime_error("graph must be 0 or 1");
-      if (s->engine) s->engine->set_graph_mode(s->graph_mode);
+      for (Engine* e : all_engines(s)) e->set_graph_mode(s->graph_mode);
     } else if (k == "xcd_map") {
       s->xcd_map = v != "0";
-      if (s->engine) s->engine->set_xcd_map(s->xcd_map);
+      for (Engine* e : all_engines(s)) e->set_xcd_map(s->xcd_map);
     } else if (k == "fermat") {
       s->fermat = v != "0";
     } else if (k == "pair") {
@@ -853,12 +1012,18 @@ int zkgpu_replay(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
     s->results_fresh = false;
-    s->engine->replay(false);
+    if (s->peers.empty()) {
+      s->engine->replay(false);
+    } else {
+      std::vector<Engine*> eng = all_engines(s);
+      per_engine(active_engines(s), [&](size_t k) { eng[k]->replay(false); });
+    }
   });
 }
 int zkgpu_replay_timed(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
+    single_device_only(s, "zkgpu_replay_timed");
     s->results_fresh = false;
     s->engine->replay(true);
     s->engine->synchronize();
@@ -867,10 +1032,18 @@ int zkgpu_replay_timed(zkgpu_session* s) {
 int zkgpu_synchronize(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
-    s->engine->synchronize();
+    std::vector<Engine*> eng = all_engines(s);
+    if (s->peers.empty()) s->engine->synchronize();
+    else
+      for (size_t k : active_engines(s)) eng[k]->synchronize();
   });
 }
-float zkgpu_last_replay_ms(const zkgpu_session* s) { return (s && s->engine) ? s->engine->last_replay_ms() : 0.f; }
+float zkgpu_last_replay_ms(const zkgpu_session* s) {   // several devices: the slowest share
+  if (!s || !s->engine) return 0.f;
+  float ms = s->engine->last_replay_ms();
+  for (const auto& p : s->peers) ms = std::max(ms, p->last_replay_ms());
+  return ms;
+}
 
 size_t zkgpu_launch_timings(const zkgpu_session* s, float* ms, uint32_t* ops, size_t cap) {
   if (!s || !s->engine) return 0;
@@ -885,11 +1058,14 @@ size_t zkgpu_launch_timings(const zkgpu_session* s, float* ms, uint32_t* ops, si
 int zkgpu_counts(zkgpu_session* s, uint64_t out[2]) {
   return guarded(s, [&] {
     need_engine(s);
-    s->engine->download(nullptr, nullptr, out);
+    if (s->peers.empty()) s->engine->download(nullptr, nullptr, out);
+    else total_counts(s, out);
   });
 }
-void* zkgpu_counts_device(zkgpu_session* s) { return (s && s->engine) ? s->engine->counts_device() : nullptr; }
-void* zkgpu_stream(zkgpu_session* s) { return (s && s->engine) ? s->engine->stream() : nullptr; }
+void* zkgpu_counts_device(zkgpu_session* s) { return (s && s->engine && s->peers.empty()) ? s->engine->counts_device() : nullptr; }
+void* zkgpu_stream(zkgpu_session* s) { return (s && s->engine && s->peers.empty()) ? s->engine->stream() : nullptr; }
+int zkgpu_device_count(void) { return visible_devices(); }
+int zkgpu_n_engines(const zkgpu_session* s) { return s ? (int)(s->engine_loaded ? 1 + s->peers.size() : std::max<size_t>(1, s->devices.size())) : 0; }
 
 int zkgpu_lane_results(zkgpu_session* s, uint32_t* first_fail, uint32_t* flags) {
   return guarded(s, [&] {
@@ -935,7 +1111,7 @@ int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, ui
     std::vector<uint32_t> slots(count);
     for (uint64_t k = 0; k < count; ++k) slots[k] = s->sched.slot_of[s->value_op_index[first + k]];
     std::vector<uint8_t> tmp;
-    s->engine->dump_slots(slots, &tmp);
+    dump_slots_all(s, slots, &tmp);
     if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
   });
 }
@@ -948,7 +1124,7 @@ int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out) {
     need_engine(s);
     std::vector<uint32_t> slots(1, s->sched.slot_of[w->h]);
     std::vector<uint8_t> tmp;
-    s->engine->dump_slots(slots, &tmp);
+    dump_slots_all(s, slots, &tmp);
     if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
   });
 }
@@ -1097,6 +1273,11 @@ int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out) { return zk
 
 float zkgpu_r1cs_last_ms(const zkgpu_session* s) { return (s && s->engine) ? s->engine->last_r1cs_ms() : 0.f; }
 
-uint64_t zkgpu_table_bytes(const zkgpu_session* s) { return (s && s->engine) ? s->engine->table_bytes() : 0; }
+uint64_t zkgpu_table_bytes(const zkgpu_session* s) {
+  if (!s || !s->engine) return 0;
+  uint64_t n = s->engine->table_bytes();
+  for (const auto& p : s->peers) n += p->table_bytes();
+  return n;
+}
 
 }  // extern "C"

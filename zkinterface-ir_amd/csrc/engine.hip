@@ -1,4 +1,6 @@
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym when several devices are driven
+#include <dlfcn.h>
 #include <string.h>
 
 #include <algorithm>
@@ -73,10 +75,16 @@ void launch_dump(uint32_t nwords, dim3 grid, hipStream_t st, const uint4* table,
 
 }  // namespace
 
-Engine::Engine() {
+void Engine::use_device() const {
+  if (device_ >= 0) HIP_OK(hipSetDevice(device_));
+}
+
+Engine::Engine(int device) : device_(device) {
   int n = 0;
   HIP_OK(hipGetDeviceCount(&n));
   if (n <= 0) throw std::runtime_error("HIP: no GPU visible (no CPU fallback exists for the replay path)");
+  if (device >= n) throw std::runtime_error("Engine: device " + std::to_string(device) + " of " + std::to_string(n) + " visible");
+  use_device();
   hipStream_t st;
   HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   stream_ = st;
@@ -101,6 +109,7 @@ Engine::Engine() {
 }
 
 Engine::~Engine() {
+  if (device_ >= 0) (void)hipSetDevice(device_);
   if (graph_exec_) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec_);
   free_batch();
   free_windows();
@@ -231,6 +240,7 @@ void Engine::free_windows() {
 }
 
 void Engine::upload_window(const void* entries, uint64_t n_entries, size_t entry_bytes) {
+  use_device();
   if (!d_windows_.empty() && entry_bytes != window_entry_bytes_) throw std::runtime_error("Engine: program windows of two entry formats");
   window_entry_bytes_ = entry_bytes;
   void* d = nullptr;
@@ -241,6 +251,7 @@ void Engine::upload_window(const void* entries, uint64_t n_entries, size_t entry
 }
 
 void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness) {
+  use_device();
   free_batch();
   dfree(d_consts_);
   dfree(d_lds_ops_);
@@ -388,6 +399,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
 }
 
 void Engine::set_batch(uint32_t batch) {
+  use_device();
   if (!loaded_) throw std::runtime_error("Engine: load_program() first");
   if (batch == 0) throw std::runtime_error("Engine: empty batch");
   if (batch == batch_) return;
@@ -416,6 +428,7 @@ void Engine::set_batch(uint32_t batch) {
 }
 
 void Engine::upload_inputs(const uint8_t* inst, const uint8_t* wit) {
+  use_device();
   if (!batch_) throw std::runtime_error("Engine: set_batch() first");
   const size_t ib = (size_t)batch_ * n_inst_ * elem_bytes_, wb = (size_t)batch_ * n_wit_ * elem_bytes_;
   if (ib && !inst) throw std::runtime_error("Engine: instance values missing");
@@ -645,6 +658,7 @@ void Engine::launch_range(uint32_t lb0, uint32_t lbs, bool time_each) {
 }
 
 void Engine::replay(bool time_each_launch) {
+  use_device();
   if (!batch_) throw std::runtime_error("Engine: set_batch() first");
   if ((n_inst_ && !d_inst_) || (n_wit_ && !d_wit_)) throw std::runtime_error("Engine: inputs not set");
   hipStream_t st = (hipStream_t)stream_;
@@ -778,6 +792,7 @@ void Engine::reserve_extra_slots(uint32_t n) {
 
 void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<R1csTermDev>& terms,
                          const std::vector<uint32_t>& coef_words) {
+  use_device();
   if (boolean_) throw std::runtime_error("Engine: the R1CS row kernel needs an arithmetic field");
   // host check of every index the row kernel dereferences (same rule as validate_program)
   const uint64_t n_coefs = nwords_ ? coef_words.size() / nwords_ : 0;
@@ -820,6 +835,7 @@ void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<
 }
 
 void Engine::r1cs_begin_check() {
+  use_device();
   if (!batch_ || !d_r1cs_rows_) throw std::runtime_error("Engine: R1CS rows or batch not set");
   hipStream_t st = (hipStream_t)stream_;
   HIP_OK(hipEventRecord((hipEvent_t)ev_r1cs_begin_, st));
@@ -828,6 +844,7 @@ void Engine::r1cs_begin_check() {
 }
 
 void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
+  use_device();
   if (!batch_ || !d_r1cs_rows_) throw std::runtime_error("Engine: R1CS rows or batch not set");
   if ((uint64_t)first_row + n_rows > r1cs_rows_) throw std::runtime_error("Engine: R1CS row range out of bounds");
   if (!n_rows) return;
@@ -853,6 +870,7 @@ void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
 }
 
 void Engine::r1cs_finish_check() {
+  use_device();
   hipStream_t st = (hipStream_t)stream_;
   zkgpu::launch_verdict(dim3((batch_ + 255) / 256), st, (const zkgpu::u32*)d_r1cs_fail_, (const zkgpu::u32*)d_flags_, batch_,
                         (unsigned long long*)d_r1cs_counts_);
@@ -861,6 +879,7 @@ void Engine::r1cs_finish_check() {
 }
 
 void Engine::r1cs_results(std::vector<uint32_t>* first_fail_row, uint64_t counts[2]) {
+  use_device();
   HIP_OK(hipStreamSynchronize((hipStream_t)stream_));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, (hipEvent_t)ev_r1cs_begin_, (hipEvent_t)ev_r1cs_end_) == hipSuccess) last_r1cs_ms_ = ms;
@@ -872,13 +891,14 @@ void Engine::r1cs_results(std::vector<uint32_t>* first_fail_row, uint64_t counts
 }
 
 void Engine::synchronize() {
+  use_device();
   HIP_OK(hipStreamSynchronize((hipStream_t)stream_));
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, (hipEvent_t)ev_begin_, (hipEvent_t)ev_end_) == hipSuccess) last_ms_ = ms;
 }
 
 void Engine::download(std::vector<uint32_t>* first_fail, std::vector<uint32_t>* flags, uint64_t counts[2]) {
-  synchronize();
+  synchronize();   // (makes the engine's device current)
   if (first_fail) {
     first_fail->resize(batch_);
     HIP_OK(hipMemcpy(first_fail->data(), d_first_fail_, (size_t)batch_ * 4, hipMemcpyDeviceToHost));
@@ -891,6 +911,7 @@ void Engine::download(std::vector<uint32_t>* first_fail, std::vector<uint32_t>* 
 }
 
 void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out) {
+  use_device();
   synchronize();
   const uint32_t k = (uint32_t)slots.size();
   out->assign((size_t)batch_ * k * elem_bytes_, 0);
@@ -915,6 +936,82 @@ void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>
   HIP_OK(hipMemcpy(out->data(), d_out, out->size(), hipMemcpyDeviceToHost));
   (void)hipFree(d_slots);
   (void)hipFree(d_out);
+}
+
+int visible_devices() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return n;
+}
+
+// ---- RCCL count reduction for one process driving several GPUs -------------------------------------
+namespace {
+typedef int (*nccl_comm_init_all_t)(ncclComm_t*, int, const int*);
+typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+typedef int (*nccl_group_t)(void);
+typedef int (*nccl_comm_destroy_t)(ncclComm_t);
+typedef const char* (*nccl_error_string_t)(int);
+}  // namespace
+
+CountReducer::CountReducer(const std::vector<Engine*>& engines) : engines_(engines) {
+  std::vector<int> devs;
+  for (Engine* e : engines_) {
+    if (e->device() < 0) throw std::runtime_error("CountReducer: engine without a device of its own");
+    for (int d : devs)
+      if (d == e->device()) throw std::runtime_error("CountReducer: RCCL needs distinct devices");
+    devs.push_back(e->device());
+  }
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    lib_ = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (lib_) break;
+  }
+  if (!lib_) throw std::runtime_error(std::string("RCCL: cannot load librccl.so: ") + dlerror());
+  const char* names[6] = {"ncclCommInitAll", "ncclAllReduce", "ncclGroupStart", "ncclGroupEnd", "ncclCommDestroy", "ncclGetErrorString"};
+  for (int k = 0; k < 6; ++k) {
+    fn_[k] = dlsym(lib_, names[k]);
+    if (!fn_[k]) throw std::runtime_error(std::string("RCCL: symbol missing: ") + names[k]);
+  }
+  std::vector<ncclComm_t> comms(devs.size());
+  const int rc = ((nccl_comm_init_all_t)fn_[0])(comms.data(), (int)devs.size(), devs.data());
+  if (rc != 0) throw std::runtime_error(std::string("RCCL: ncclCommInitAll: ") + ((nccl_error_string_t)fn_[5])(rc));
+  for (ncclComm_t c : comms) comms_.push_back((void*)c);
+  for (Engine* e : engines_) {
+    HIP_OK(hipSetDevice(e->device()));
+    void* d = nullptr;
+    HIP_OK(hipMalloc(&d, 16));
+    reduced_.push_back(d);
+  }
+}
+
+CountReducer::~CountReducer() {
+  for (size_t k = 0; k < reduced_.size(); ++k) {
+    (void)hipSetDevice(engines_[k]->device());
+    (void)hipFree(reduced_[k]);
+  }
+  if (fn_[4])
+    for (void* c : comms_) (void)((nccl_comm_destroy_t)fn_[4])((ncclComm_t)c);
+  // the library stays loaded: RCCL keeps threads of its own
+}
+
+void CountReducer::all_reduce(uint64_t totals[2]) {
+  auto check_nccl = [&](int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string("RCCL: ") + what + ": " + ((nccl_error_string_t)fn_[5])(rc));
+  };
+  check_nccl(((nccl_group_t)fn_[2])(), "ncclGroupStart");
+  for (size_t k = 0; k < engines_.size(); ++k) {
+    HIP_OK(hipSetDevice(engines_[k]->device()));
+    // on the engine's stream: ordered behind the verdict kernel of its replay
+    check_nccl(((nccl_all_reduce_t)fn_[1])(engines_[k]->counts_device(), reduced_[k], 2, ncclUint64, ncclSum, (ncclComm_t)comms_[k],
+                                            (hipStream_t)engines_[k]->stream()),
+               "ncclAllReduce");
+  }
+  check_nccl(((nccl_group_t)fn_[3])(), "ncclGroupEnd");
+  for (Engine* e : engines_) e->synchronize();
+  HIP_OK(hipSetDevice(engines_[0]->device()));
+  HIP_OK(hipMemcpy(totals, reduced_[0], 16, hipMemcpyDeviceToHost));
 }
 
 }  // namespace zki

@@ -20,8 +20,12 @@ struct LaunchTiming {
 
 class Engine {
  public:
-  Engine();
+  // device < 0: whatever device is current on the calling thread (the usual single-GPU process); otherwise the
+  // engine lives on that device and every entry point makes it current on the calling thread first, so that one
+  // process can drive several GPUs, each from a host thread of its own (capi.cpp, option "devices")
+  explicit Engine(int device = -1);
   ~Engine();
+  int device() const { return device_; }
   Engine(const Engine&) = delete;
   Engine& operator=(const Engine&) = delete;
 
@@ -84,6 +88,8 @@ class Engine {
   uint32_t batch() const { return batch_; }
 
  private:
+  int device_ = -1;
+  void use_device() const;   // make device_ current on this thread
   void free_batch();
   void launch_range(uint32_t lb0, uint32_t lbs, bool time_each);
   void launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream);
@@ -165,6 +171,28 @@ class Engine {
   void set_writeback(bool on) { force_writeback_ = on; graph_dirty_ = true; }
  private:
   unsigned char field_params_[192];  // zkgpu::FieldParams, opaque here
+};
+
+// One process driving several GPUs: the {satisfied, failed} counters of engines on DISTINCT devices are combined by an
+// RCCL all-reduce over xGMI (ncclCommInitAll: one communicator per device, all owned by this process), enqueued on
+// every engine's own stream behind its replay; afterwards every device holds the totals.  RCCL is loaded on first
+// use (dlopen: the library takes no link-time dependency on it).  Throws when RCCL cannot be loaded or a call fails.
+int visible_devices();   // hipGetDeviceCount, or -1 when the HIP runtime finds no GPU
+
+class CountReducer {
+ public:
+  explicit CountReducer(const std::vector<Engine*>& engines);
+  ~CountReducer();
+  CountReducer(const CountReducer&) = delete;
+  CountReducer& operator=(const CountReducer&) = delete;
+  void all_reduce(uint64_t totals[2]);   // enqueue, wait, read the totals back from the first device
+
+ private:
+  std::vector<Engine*> engines_;
+  std::vector<void*> comms_;      // ncclComm_t per engine
+  std::vector<void*> reduced_;    // device u64[2] per engine
+  void* lib_ = nullptr;
+  void* fn_[6] = {nullptr};
 };
 
 }  // namespace zki

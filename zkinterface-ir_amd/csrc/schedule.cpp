@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <thread>
 
 namespace zki {
@@ -579,6 +580,118 @@ void StreamScheduler::Impl::assign_slots() {
       }
     for (size_t q = 0; q < cnt; ++q) order[k0 + q] = out[q];
   };
+  // The same for a run of two-operand ops (and / xor), where a group needs 32 ops with 32 different operand-a banks AND
+  // 32 different operand-b banks: a perfect matching in the bipartite graph a-bank -- b-bank whose edges are the ops
+  // still unplaced (an op with operand banks (x, y) is the edge x--y and, the gates being commutative, also y--x with
+  // its operands swapped).  Greedy choices run dry towards the end of a run; augmenting paths (Kuhn) do not, as long
+  // as a matching exists.
+  auto bank_order_two = [&](uint64_t k0, uint64_t k1) {
+    const size_t cnt = k1 - k0;
+    constexpr uint32_t kFlip = 0x80000000u;
+    std::vector<uint32_t> run(order.begin() + k0, order.begin() + k1);
+    std::vector<std::vector<uint32_t>> cell(kBanks * kBanks);   // (a bank, b bank) -> positions in `run` (| kFlip: operands swapped)
+    for (size_t r = 0; r < cnt; ++r) {
+      const uint32_t i = run[r], x = s.slot_of[ra[i - lo]] % kBanks, y = s.slot_of[rb[i - lo]] % kBanks;
+      cell[x * kBanks + y].push_back((uint32_t)r);
+      if (x != y) cell[y * kBanks + x].push_back((uint32_t)r | kFlip);
+    }
+    std::vector<uint8_t> used(cnt, 0);
+    // unplaced ops per edge (symmetric: x--y and y--x are the same ops)
+    std::vector<uint32_t> left(kBanks * kBanks, 0);
+    for (uint32_t a = 0; a < kBanks; ++a)
+      for (uint32_t b = 0; b < kBanks; ++b) left[a * kBanks + b] = (uint32_t)cell[a * kBanks + b].size();
+    std::vector<uint32_t> out(cnt, kInf);
+    const size_t n_groups = (cnt + 2 * kBanks - 1) / (2 * kBanks) * 2;
+    auto pos_of = [&](size_t g, uint32_t lane) { return (g / 2) * 64 + (g % 2) + 2 * (size_t)lane; };
+    int match_of_b[kBanks], match_of_a[kBanks];
+    uint32_t visited = 0, taken_b = 0;
+    // capacity of edge a--b for one more use in this group: the reverse edge b--a, if matched, draws on the same ops
+    auto capacity = [&](uint32_t a, uint32_t b) {
+      const uint32_t n = left[a * kBanks + b];
+      return (a != b && match_of_a[b] == (int)a) ? (n > 1 ? n - 1 : 0) : n;
+    };
+    struct Kuhn {
+      static bool augment(uint32_t a, int* match_of_b, int* match_of_a, uint32_t& visited, uint32_t& taken_b,
+                          const std::function<uint32_t(uint32_t, uint32_t)>& capacity) {
+        // a free b bank if there is one: the edge with most ops left, so that the edges are used up evenly and the graph
+        // stays dense to the end of the run
+        uint32_t best = 32, best_n = 0;
+        for (uint32_t b = 0; b < 32; ++b) {
+          if ((taken_b >> b) & 1) continue;
+          const uint32_t n = capacity(a, b);
+          if (n > best_n) { best_n = n; best = b; }
+        }
+        if (best < 32) {
+          match_of_b[best] = (int)a;
+          match_of_a[a] = (int)best;
+          taken_b |= 1u << best;
+          return true;
+        }
+        // otherwise push somebody else off a taken one (augmenting path)
+        for (uint32_t b = 0; b < 32; ++b) {
+          if ((visited >> b) & 1 || !((taken_b >> b) & 1) || !capacity(a, b)) continue;
+          visited |= 1u << b;
+          const int other = match_of_b[b];
+          match_of_a[other] = -1;
+          if (augment((uint32_t)other, match_of_b, match_of_a, visited, taken_b, capacity)) {
+            match_of_b[b] = (int)a;
+            match_of_a[a] = (int)b;
+            return true;
+          }
+          match_of_a[other] = (int)b;
+        }
+        return false;
+      }
+    };
+    const std::function<uint32_t(uint32_t, uint32_t)> capacity_fn = capacity;
+    auto alive = [&](uint32_t a, uint32_t b) {   // lazy deletion of the placed ops at the back of the edge's list
+      std::vector<uint32_t>& c = cell[a * kBanks + b];
+      while (!c.empty() && used[c.back() & ~kFlip]) c.pop_back();
+      return !c.empty();
+    };
+    for (size_t g = 0; g < n_groups; ++g) {
+      uint32_t lanes = 0;
+      for (uint32_t lane = 0; lane < kBanks; ++lane) lanes += pos_of(g, lane) < cnt;
+      if (!lanes) continue;
+      for (uint32_t b = 0; b < kBanks; ++b) match_of_b[b] = match_of_a[b] = -1;
+      taken_b = 0;
+      uint32_t matched = 0;
+      for (uint32_t t = 0; t < kBanks && matched < lanes; ++t) {
+        const uint32_t a = (t + (uint32_t)g) % kBanks;
+        visited = 0;
+        if (Kuhn::augment(a, match_of_b, match_of_a, visited, taken_b, capacity_fn)) ++matched;
+      }
+      uint32_t lane = 0;
+      for (uint32_t a = 0; a < kBanks; ++a) {
+        if (match_of_a[a] < 0) continue;
+        const uint32_t b = (uint32_t)match_of_a[a];
+        if (!alive(a, b)) continue;   // (cannot happen while `left` is exact; a hole is harmless)
+        const uint32_t e = cell[a * kBanks + b].back();
+        const uint32_t r = e & ~kFlip;
+        used[r] = 1;
+        --left[a * kBanks + b];
+        if (a != b) --left[b * kBanks + a];
+        const uint32_t i = run[r];
+        if (e & kFlip) std::swap(ra[i - lo], rb[i - lo]);
+        while (lane < kBanks && (pos_of(g, lane) >= cnt || out[pos_of(g, lane)] != kInf)) ++lane;
+        out[pos_of(g, lane)] = i;
+      }
+    }
+    if (getenv("ZKI_BANK_DEBUG")) {
+      size_t holes = 0;
+      for (size_t q = 0; q < cnt; ++q) holes += out[q] == kInf;
+      fprintf(stderr, "[bank] run of %zu: %zu holes after matching\n", cnt, holes);
+    }
+    // what no matching could take (the last few ops of the run): into the holes as they come
+    size_t r = 0;
+    for (size_t q = 0; q < cnt; ++q) {
+      if (out[q] != kInf) continue;
+      while (used[r]) ++r;
+      used[r] = 1;
+      out[q] = run[r];
+    }
+    for (size_t q = 0; q < cnt; ++q) order[k0 + q] = out[q];
+  };
   auto place = [&](uint32_t i, uint32_t bank = kInf) {
     s.slot_of[i] = take_slot(bank);
     if (opt.retain_all) return;
@@ -604,7 +717,10 @@ void StreamScheduler::Impl::assign_slots() {
         uint64_t e = k;
         while (e < level_start[l + 1] && kind[order[e] - lo] == kind[order[k] - lo]) ++e;
         wide_run = e - k >= 2 * kBanks;
-        if (wide_run && n_inputs(kind[order[k] - lo]) >= 1 && kind[order[k] - lo] != TK_ASSERT) bank_order(k, e);
+        if (wide_run && kind[order[k] - lo] != TK_ASSERT) {
+          if (n_inputs(kind[order[k] - lo]) == 2) bank_order_two(k, e);
+          else if (n_inputs(kind[order[k] - lo]) == 1) bank_order(k, e);
+        }
       }
       const uint32_t i = order[k];
       if (kind[i - lo] == TK_ASSERT || kind[i - lo] == TK_NOP) continue;
