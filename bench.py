@@ -153,6 +153,8 @@ def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_b
         ev.set_option('xcd_map', os.environ['ZKI_XCD_MAP'])
     if os.environ.get('ZKI_SORT_BY_OPERAND'):
         ev.set_option('sort_by_operand', os.environ['ZKI_SORT_BY_OPERAND'])
+    if os.environ.get('ZKI_BANK_AWARE'):
+        ev.set_option('bank_aware', os.environ['ZKI_BANK_AWARE'])
     if os.environ.get('ZKI_FERMAT'):
         ev.set_option('fermat', os.environ['ZKI_FERMAT'])
     ev.declare_inputs(wl.n_instance, wl.n_witness)

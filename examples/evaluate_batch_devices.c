@@ -1,7 +1,7 @@
 /* One process, several GPUs: a batch of statements over the same relation, split over the devices of the node.
  *
  * The statement of the workspace (its Instance / Witness messages) is replicated into a batch of B lanes -- lane 1 gets
- * its first witness value damaged, so one statement of the batch is false unless that value is unconstrained -- and the
+ * its first instance value damaged, so one statement of the batch is false unless that value is unconstrained -- and the
  * batch is evaluated across every visible GPU (or the devices given with --devices): the lanes are split into
  * contiguous shares, one engine and one host thread per device, and zkgpu_counts combines the per-device
  * {satisfied, failed} counters with one RCCL all-reduce (by a host sum when a device is listed twice: "--devices 0,0"
@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     memcpy(inst + (size_t)lane * ni * w, inst, (size_t)ni * w);
     memcpy(wit + (size_t)lane * nw * w, wit, (size_t)nw * w);
   }
-  if (batch > 1 && nw) wit[(size_t)1 * nw * w] ^= 1; /* lane 1: first witness value off by one bit */
+  if (batch > 1 && ni) inst[(size_t)1 * ni * w] ^= 1; /* lane 1: first instance value off by one bit */
   uint64_t counts[2] = {0, 0};
   if (zkgpu_set_inputs(s, inst, wit, batch) != 0 || zkgpu_replay(s) != 0 || zkgpu_synchronize(s) != 0 ||
       zkgpu_counts(s, counts) != 0) {

@@ -92,7 +92,7 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                 r = consts[a]
             elif kind in (OP['instance'], OP['witness']):
                 v = instances[a] if kind == OP['instance'] else witnesses[a]
-                if v >= p:
+                if v >= p and b:     # b: a strict input (an unreduced value would reach copy / assert_zero / not / a bit op)
                     noncanon = True
                 r = (v & 1) if boolean else (v * R % p)
             elif kind == OP['assert']:

@@ -452,5 +452,4 @@ def test_trait_level_entry_points_record_a_tape():
     # and / xor / not over an odd field are the integer bit operations of PlaintextBackend (evaluator.rs:924-938)
     w_and = ev2.backend_and(ev2.backend_constant(bytes([1])), ev2.backend_constant(bytes([1])))
     assert zk.KIND_NAMES[int(ev2.tape()[0][w_and])] == 'and'
-    with pytest.raises(zk.ZkGpuError, match='non-canonical constant'):
-        ev2.backend_constant(bytes([101]))
+    ev2.backend_constant(bytes([101]))     # >= p: recorded; whether its residue will do is decided at finalize (test_unreduced.py)

@@ -1,41 +1,78 @@
 #!/bin/bash
-# Collect the evidence `profiles/` holds for one round, on the GPU box:
-#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r01'
-# bench lines for c2 / c4 / c5, rocprofv3 kernel stats of the same commands, and the two --pmc passes
-# (FETCH_SIZE, WRITE_SIZE; separate runs, kernel trace only) that tools/pmc_traffic.py turns into bytes per launch.
+# Collect the evidence `profiles/` holds for one round, on the GPU box, in three calls (each under gpurun's limit):
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02 bench'   bench lines + rocprofv3 kernel stats
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02 pmc_c2'  --pmc passes of the C2 kernel (+ the 4096-lane variant)
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02 pmc_c45' --pmc passes of the GF(2) and R1CS kernels
+# Counters are collected in runs of their own with --kernel-trace only (FETCH_SIZE and WRITE_SIZE never share a pass);
+# tools/pmc_traffic.py applies the gfx950 corrections of MI355X_MICROARCH.md, tools/binding_evidence.py writes
+# profiles/binding_<workload>.json from the summaries.  Copy gpurun_out/<tag>/* into profiles/ afterwards.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+WHAT=${2:-bench}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for wl in c2 c4 c5; do
-  extra=""
-  [ $wl != c2 ] && extra="--workload $wl"
-  echo "[collect] bench $wl"
-  timeout -k 10 500 python3 $ROOT/bench.py --steps 20 --warmup 3 $extra > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
-  rm -rf /tmp/prof_$wl
-  echo "[collect] rocprofv3 stats $wl"
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline $extra > $OUT/prof_$wl.log 2>&1
-  cp $(find /tmp/prof_$wl -name '*kernel_stats.csv' | head -1) $OUT/${wl}_kernel_stats.csv
-done
-echo "[collect] pmc passes (c2, one stream)"
-rm -rf /tmp/pmc_f /tmp/pmc_w
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 > $OUT/pmc_f.log 2>&1
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 > $OUT/pmc_w.log 2>&1
-F=$(find /tmp/pmc_f -name '*counter_collection.csv' | head -1)
-W=$(find /tmp/pmc_w -name '*counter_collection.csv' | head -1)
-python3 $ROOT/tools/pmc_traffic.py $F $W $OUT/pmc_traffic.json 1000000 'replay_fused_kernel<8' c2 > /dev/null
-for wl in c4 c5; do
-  echo "[collect] pmc passes ($wl)"
-  rm -rf /tmp/pmc_f_$wl /tmp/pmc_w_$wl
-  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_f_$wl -- python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_f_$wl.log 2>&1
-  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_w_$wl -- python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_w_$wl.log 2>&1
-  K='bool_lds_kernel'; [ $wl = c5 ] && K='r1cs_row_kernel<8, false>'
-  python3 $ROOT/tools/pmc_traffic.py $(find /tmp/pmc_f_$wl -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_w_$wl -name '*counter_collection.csv' | head -1) $OUT/pmc_traffic_$wl.json 1000 "$K" $wl > /dev/null
-done
-head -4 $F > $OUT/pmc_fetch_sample.csv
-head -4 $W > $OUT/pmc_write_sample.csv
-echo "[collect] done"
-tail -c 600 $OUT/bench_c2.json
+B="python3 $ROOT/bench.py"
+pmc() {  # pmc <name> <counters...> -- <bench args...>
+  local name=$1; shift
+  local counters=()
+  while [ "$1" != "--" ]; do counters+=("$1"); shift; done
+  shift
+  rm -rf /tmp/pmc_$name
+  echo "[collect] pmc $name: ${counters[*]}"
+  timeout -k 10 420 rocprofv3 --pmc "${counters[@]}" --kernel-trace --output-format csv -d /tmp/pmc_$name -- $B "$@" > $OUT/pmc_$name.log 2>&1
+  cp $(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1) /tmp/pmc_$name.csv
+}
+if [ $WHAT = bench ]; then
+  for wl in c2 c4 c5 structured; do
+    extra=""; [ $wl != c2 ] && extra="--workload $wl"
+    echo "[collect] bench $wl"
+    timeout -k 10 500 $B --steps 20 --warmup 3 $extra > $OUT/${TAG}_bench_$wl.json 2> $OUT/bench_$wl.err
+    [ $wl = structured ] && continue
+    rm -rf /tmp/prof_$wl
+    echo "[collect] rocprofv3 stats $wl"
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-hbm-variant $extra > $OUT/prof_$wl.log 2>&1
+    cp $(find /tmp/prof_$wl -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_${wl}_kernel_stats.csv
+  done
+  tail -c 400 $OUT/${TAG}_bench_c2.json
+elif [ $WHAT = pmc_c2 ]; then
+  C2="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-variant --streams 1"
+  K='replay_fused_kernel<8, 0>'
+  pmc c2_f FETCH_SIZE -- $C2
+  pmc c2_w WRITE_SIZE -- $C2
+  python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c2_f.csv /tmp/pmc_c2_w.csv $OUT/pmc_traffic_latest.json 1000000 "$K" c2 > /dev/null
+  head -4 /tmp/pmc_c2_f.csv > $OUT/${TAG}_pmc_fetch_sample.csv
+  head -4 /tmp/pmc_c2_w.csv > $OUT/${TAG}_pmc_write_sample.csv
+  pmc c2_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -- $C2
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c2_sq.csv "$K" 1000000 > $OUT/${TAG}_pmc_c2_sq_counters.json
+  pmc c2_tcc TCC_HIT_sum TCC_MISS_sum -- $C2
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c2_tcc.csv "$K" 1000000 > $OUT/${TAG}_pmc_c2_tcc_counters.json
+  # the same program with 4096 witnesses in flight (1.05 GB wire table: cannot sit in the Infinity Cache)
+  H="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-variant --streams 1 --batch-per-gpu 4096 --lane-group 4096"
+  pmc c2h_f FETCH_SIZE -- $H
+  pmc c2h_w WRITE_SIZE -- $H
+  python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c2h_f.csv /tmp/pmc_c2h_w.csv $OUT/pmc_traffic_c2_hbm_variant.json 4000000 "$K" c2_hbm_variant > /dev/null
+elif [ $WHAT = pmc_c45 ]; then
+  C4="--workload c4 --steps 2 --warmup 1 --no-cpu-baseline"
+  pmc c4_f FETCH_SIZE -- $C4
+  pmc c4_w WRITE_SIZE -- $C4
+  python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c4_f.csv /tmp/pmc_c4_w.csv $OUT/pmc_traffic_c4.json 1000 bool_lds_kernel c4 > /dev/null
+  LDS="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU"
+  pmc c4_lds $LDS -- $C4
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_lds.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_lds_counters.json
+  export ZKI_BANK_AWARE=0   # the slot numbering of round 1, for the before / after of the bank-aware schedule
+  pmc c4_lds_unbanked $LDS -- $C4
+  unset ZKI_BANK_AWARE
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_lds_unbanked.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_lds_counters_bank_unaware.json
+  C5="--workload c5 --steps 2 --warmup 1 --no-cpu-baseline"
+  K5='r1cs_row_kernel<8, false>'
+  pmc c5_f FETCH_SIZE -- $C5
+  pmc c5_w WRITE_SIZE -- $C5
+  python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c5_f.csv /tmp/pmc_c5_w.csv $OUT/pmc_traffic_c5.json 1000 "$K5" c5 > /dev/null
+  pmc c5_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- $C5
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c5_sq.csv "$K5" 1000 > $OUT/${TAG}_pmc_c5_sq_counters.json
+fi
+echo "[collect] $WHAT done"
+ls $OUT

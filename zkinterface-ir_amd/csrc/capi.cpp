@@ -466,16 +466,24 @@ void dump_slots_all(zkgpu_session* s, const std::vector<uint32_t>& slots, std::v
   }
 }
 
-// pad / check one little-endian Value into a fixed-width slot; values that do
-// not fit are necessarily >= p: written as all-ones so the device flags them.
-void put_value(const Value& v, uint8_t* dst, uint32_t width) {
+// pad one little-endian Value into a fixed-width slot.  A value that does not fit is >= p: its residue goes in
+// (what every arithmetic gate would make of it) and `oversize` tells the caller, who flags the lane if the position is
+// one where the residue will not do (Schedule::strict_instance / strict_witness).
+void put_value(const Value& v, uint8_t* dst, uint32_t width, const FieldHost& f, bool* oversize) {
   size_t n = v.size();
   while (n > 0 && v[n - 1] == 0) --n;
+  memset(dst, 0, width);
   if (n > width) {
-    memset(dst, 0xff, width);
+    *oversize = true;
+    if (f.is_two) {
+      dst[0] = v[0] & 1;
+    } else {
+      uint32_t r[kFieldWords];
+      f.reduce(v, r);
+      memcpy(dst, r, std::min<size_t>(width, sizeof r));
+    }
     return;
   }
-  memset(dst, 0, width);
   memcpy(dst, v.data(), n);
 }
 
@@ -867,8 +875,18 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
     const auto& lw = s->backend.lane0_witnesses();
     if (s->backend.tape().n_instance > li.size() || s->backend.tape().n_witness > lw.size())
       throw std::runtime_error("the tape consumes more instance/witness values than the ingested messages hold");
-    for (size_t k = 0; k < li.size(); ++k) put_value(li[k], &inst[k * w], w);
-    for (size_t k = 0; k < lw.size(); ++k) put_value(lw[k], &wit[k * w], w);
+    const FieldHost& f = s->backend.field();
+    // a value too wide for the buffer is >= p: at a position where only the residue matters the residue goes in; at a
+    // strict one (Schedule::strict_*) all-ones does, which the device flags like any other non-canonical strict input
+    auto fill = [&](const std::vector<Value>& vals, std::vector<uint8_t>& buf, const std::vector<uint8_t>& strict) {
+      for (size_t k = 0; k < vals.size(); ++k) {
+        bool big = false;
+        put_value(vals[k], &buf[k * w], w, f, &big);
+        if (big && k < strict.size() && strict[k]) memset(&buf[k * w], 0xff, w);
+      }
+    };
+    fill(li, inst, s->sched.strict_instance);
+    fill(lw, wit, s->sched.strict_witness);
     split_lanes(s, 1);
     s->engine->set_batch(1);
     s->engine->upload_inputs(inst.data(), wit.data());
@@ -1087,8 +1105,9 @@ size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t 
         if (!s->ev.has_error() || m != s->ev.error()) v.push_back(m);  // "Did not receive any gate to verify."
     const uint32_t ff = s->first_fail[lane];
     if (s->flags[lane] & ZKGPU_LANE_NONCANONICAL) {
-      v.push_back("GPU backend: an instance or witness value is not canonical (>= field characteristic); "
-                  "the reference keeps such values unreduced and this path does not support them");
+      v.push_back("GPU backend: an instance or witness value is not canonical (>= field characteristic) and reaches copy / "
+                  "assert_zero / not / and / xor / Evaluator::get without passing through an arithmetic gate; the reference "
+                  "evaluates those on the unreduced integer (evaluator.rs:896-946) and this path does not");
     } else if (ff != ZKGPU_NO_FAIL) {
       v.push_back("Wire_" + std::to_string(s->backend.tape().assert_wire[ff]) +
                   " (may be weighted) should be 0, while it is not");

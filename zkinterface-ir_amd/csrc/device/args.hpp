@@ -187,7 +187,7 @@ ZKGPU_DECLARE_WIDTH(12)
 void launch_verdict(dim3 grid, hipStream_t st, const u32* first_fail, const u32* lane_flags, u32 batch,
                     unsigned long long* counts);
 void launch_pack_inputs(dim3 grid, hipStream_t st, const uint8_t* raw, u32 n_vals, u32 batch, u32 total_words,
-                        u64* packed, u32* lane_flags);
+                        u64* packed, u32* lane_flags, const uint8_t* strict);
 void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a);
 hipError_t bool_lds_set_max_shared(int bytes);
 void launch_bool_lds(u32 n_cols, size_t lds_bytes, hipStream_t st, const BoolLdsArgs& a);

@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void verdict_kernel(const u32* __restrict__ fi
 // One wave = 64 witnesses x 256 positions.  Each lane reads 16 of its bytes per load (rows are
 // 16-byte aligned when n_vals % 16 == 0), every byte position is turned into a 64-bit word by a
 // wave ballot, and lane b keeps / stores the word of position k + b: one store per 16 positions.
+// strict[k] != 0: a value > 1 at position k flags the lane (it would reach assert_zero / not unreduced, see
+// schedule.cpp mark_strict_sources); elsewhere the low bit is the residue and that is all and / xor ever look at.
 __global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restrict__ raw, u32 n_vals, u32 batch,
                                                           u32 total_words, u64* __restrict__ packed,
-                                                          u32* __restrict__ lane_flags) {
+                                                          u32* __restrict__ lane_flags, const uint8_t* __restrict__ strict) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   const u32 word = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restr
       uint4 v = make_uint4(0, 0, 0, 0);
       if (valid) v = *reinterpret_cast<const uint4*>(row + k);
       const u32 w[4] = {v.x, v.y, v.z, v.w};
-      bad |= ((v.x | v.y | v.z | v.w) & 0xFEFEFEFEu) != 0;
+      const uint4 sm = *reinterpret_cast<const uint4*>(strict + k);   // 0x00 / 0xFF per position (padded to 16)
+      bad |= (((v.x & sm.x) | (v.y & sm.y) | (v.z & sm.z) | (v.w & sm.w)) & 0xFEFEFEFEu) != 0;
       u64 mine = 0;
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restr
   }
   for (; k < k1; ++k) {
     const uint8_t v = valid ? row[k] : 0;
-    bad |= v > 1;
+    bad |= v > 1 && strict[k];
     const u64 m = __ballot(v & 1);
     if (lane == 0) packed[(size_t)k * total_words + word] = m;
   }

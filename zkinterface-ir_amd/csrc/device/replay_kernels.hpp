@@ -162,12 +162,12 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
         const bool is_inst = op.kind == OP_INSTANCE;
         Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit,
                                   op.a, lane_valid);
-        if (fp_geq_p<N>(raw, fp)) {
-          // The reference keeps unreduced inputs (evaluator.rs:862-864,940-946);
-          // this path only claims parity for canonical ones: flag the lane.
+        if (op.b && fp_geq_p<N>(raw, fp)) {
+          // The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  op.b: this one can reach copy /
+          // assert_zero / not / a bit operation as it is, where the residue would not do: flag the lane.
           atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
         }
-        r = fp_to_mont<N>(raw, fp);
+        r = fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
         break;
       }
       case OP_ASSERT: {
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
           const bool is_inst = kind == OP_INSTANCE;
           Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0,
                                     lane_valid);
-          if (fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+          if (op.b0 && fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);   // strict inputs only
           r = fp_to_mont<N>(raw, fp);
           break;
         }

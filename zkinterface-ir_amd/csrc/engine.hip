@@ -117,6 +117,8 @@ Engine::~Engine() {
   dfree(d_counts_);
   dfree(d_lds_ops_);
   dfree(d_launches_);
+  dfree(d_strict_inst_);
+  dfree(d_strict_wit_);
   dfree(d_r1cs_rows_);
   dfree(d_r1cs_terms_);
   dfree(d_r1cs_coefs_);
@@ -302,6 +304,18 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   HIP_OK(hipMemset(d_consts_, 0, cbytes));
   if (!s.const_words.empty())
     HIP_OK(hipMemcpy(d_consts_, s.const_words.data(), s.const_words.size() * 4, hipMemcpyHostToDevice));
+  if (boolean_) {
+    // per input position: 0xFF = a value > 1 flags the lane (padded to whole 16-byte rows of the packing kernel)
+    auto upload_mask = [&](void*& d, const std::vector<uint8_t>& strict, uint32_t n) {
+      dfree(d);
+      std::vector<uint8_t> m(((size_t)n + 31) / 16 * 16, 0);
+      for (size_t k = 0; k < strict.size() && k < n; ++k) m[k] = strict[k] ? 0xFF : 0;
+      HIP_OK(hipMalloc(&d, m.size()));
+      HIP_OK(hipMemcpy(d, m.data(), m.size(), hipMemcpyHostToDevice));
+    };
+    upload_mask(d_strict_inst_, s.strict_instance, n_instance);
+    upload_mask(d_strict_wit_, s.strict_witness, n_witness);
+  }
   // GF(2): if every live wire of a 32-witness slice fits in one CU's LDS, run LDS-resident
   constexpr uint32_t kLdsBytes = 160 * 1024;
   lds_path_ = false;
@@ -742,10 +756,10 @@ void Engine::enqueue_replay(bool time_each_launch) {
     const uint32_t words = lane_blocks_ * 64;
     if (n_inst_)
       zkgpu::launch_pack_inputs(dim3((words + 3) / 4, (n_inst_ + 255) / 256), st, (const uint8_t*)d_inst_, n_inst_, batch_,
-                                words, (zkgpu::u64*)d_packed_inst_, (zkgpu::u32*)d_flags_);
+                                words, (zkgpu::u64*)d_packed_inst_, (zkgpu::u32*)d_flags_, (const uint8_t*)d_strict_inst_);
     if (n_wit_)
       zkgpu::launch_pack_inputs(dim3((words + 3) / 4, (n_wit_ + 255) / 256), st, (const uint8_t*)d_wit_, n_wit_, batch_,
-                                words, (zkgpu::u64*)d_packed_wit_, (zkgpu::u32*)d_flags_);
+                                words, (zkgpu::u64*)d_packed_wit_, (zkgpu::u32*)d_flags_, (const uint8_t*)d_strict_wit_);
   }
   if (lds_path_) {
     zkgpu::BoolLdsArgs a;

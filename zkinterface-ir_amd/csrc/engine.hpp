@@ -143,6 +143,8 @@ class Engine {
   bool set_read_[2] = {false, false};
   const void* d_inst_ = nullptr;
   const void* d_wit_ = nullptr;
+  void* d_strict_inst_ = nullptr;  // GF(2): per input position, 0xFF where a value > 1 must flag the lane
+  void* d_strict_wit_ = nullptr;
   void* d_packed_inst_ = nullptr;  // GF(2) path
   void* d_packed_wit_ = nullptr;
   void* h_stage_[2] = {nullptr, nullptr};  // pinned staging for host -> HBM input uploads

@@ -9,8 +9,8 @@ void launch_verdict(dim3 grid, hipStream_t st, const u32* first_fail, const u32*
 }
 
 void launch_pack_inputs(dim3 grid, hipStream_t st, const uint8_t* raw, u32 n_vals, u32 batch, u32 total_words,
-                        u64* packed, u32* lane_flags) {
-  pack_inputs_kernel<<<grid, 256, 0, st>>>(raw, n_vals, batch, total_words, packed, lane_flags);
+                        u64* packed, u32* lane_flags, const uint8_t* strict) {
+  pack_inputs_kernel<<<grid, 256, 0, st>>>(raw, n_vals, batch, total_words, packed, lane_flags, strict);
 }
 
 void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a) {

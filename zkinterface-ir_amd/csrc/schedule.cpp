@@ -146,7 +146,9 @@ struct StreamScheduler::Impl {
   uint8_t st(uint32_t h) const { return state[h - lo]; }
   bool inner(uint32_t h) const { return h >= lo && (state[h - lo] == ST_FUSED || state[h - lo] == ST_PAIR_SHARED); }
 
+  std::vector<uint8_t> strict;           // sources: the value must not be reduced silently (see mark_strict_sources)
   void grow(uint32_t n);
+  void mark_strict_sources(const TapeWindow& w);
   void rewrite_ladders(const TapeWindow& w);
   void propagate_copies();
   void levelise();
@@ -168,6 +170,47 @@ void StreamScheduler::Impl::grow(uint32_t n) {
   flags.resize(n, 0);
   s.slot_of.resize(n, kNoWire);
   s.level_of.resize(n, 0);
+}
+
+// PlaintextBackend keeps constants, instance and witness values UNREDUCED (evaluator.rs:862-864,896-898,940-946):
+// `copy` clones them as they are, `assert_zero` / `not` test the unreduced integer for zero, `and` / `xor` work on its
+// bits, `Evaluator::get` returns it -- while add / mul / add_constant / mul_constant reduce their result (`% m`), and
+// over GF(2) the low bit of `a & b` and `a ^ b` only depends on the low bits of a and b.  So a value >= p behaves like
+// its residue unless it reaches one of the former through copies alone.  This pass marks the sources of the window for
+// which that can happen ("strict"): the device reduces every other input on the fly (to_mont of a value < R is the
+// Montgomery form of its residue) and flags a lane only where a strict input is >= p.  A source that later windows may
+// still read (not closed) is strict by caution.
+void StreamScheduler::Impl::mark_strict_sources(const TapeWindow& w) {
+  const uint32_t n = hi - lo;
+  strict.assign(n, 0);
+  std::vector<uint8_t> sens(n, 0);
+  auto mark = [&](uint32_t h) {
+    if (h >= lo) sens[h - lo] = 1;
+  };
+  for (uint32_t i = hi; i-- > lo;) {
+    const uint8_t k = w.kind[i - lo];
+    const bool bit_op = (k == TK_AND || k == TK_XOR) && !field.is_two;
+    if (k == TK_ASSERT || k == TK_NOT || bit_op) {
+      mark(w.a[i - lo]);
+      if (bit_op) mark(w.b[i - lo]);
+    } else if (k == TK_COPY && (sens[i - lo] || !closed(i))) {
+      mark(w.a[i - lo]);
+    }
+  }
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint8_t k = w.kind[i - lo];
+    if (k != TK_CONST && k != TK_INSTANCE && k != TK_WITNESS) continue;
+    strict[i - lo] = sens[i - lo] || !closed(i);
+    if (k == TK_CONST && w.b[i - lo] != 0 && strict[i - lo])
+      throw Error("GPU backend: a constant >= the field characteristic reaches copy / assert_zero / not / and / xor / "
+                  "Evaluator::get without passing through an arithmetic gate; the reference evaluates those on the unreduced "
+                  "integer (evaluator.rs:896-938) and this path does not");
+    if (k != TK_CONST && strict[i - lo]) {
+      std::vector<uint8_t>& pos = k == TK_INSTANCE ? s.strict_instance : s.strict_witness;
+      if (pos.size() <= w.a[i - lo]) pos.resize((size_t)w.a[i - lo] + 1, 0);
+      pos[w.a[i - lo]] = 1;
+    }
+  }
 }
 
 // Switch weights are 1 - (case - cond)^(p-1) (evaluator.rs:823-839); the reference computes the power with a
@@ -814,7 +857,8 @@ void StreamScheduler::Impl::emit_entries() {
           d.b0 = y;
           break;
         case TK_COPY: case TK_NOT: case TK_NZ: d.a0 = s.slot_of[x]; break;
-        case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a0 = x; break;
+        case TK_CONST: d.a0 = x; break;
+        case TK_INSTANCE: case TK_WITNESS: d.a0 = x; d.b0 = strict[i - lo]; break;   // b0: flag the lane if the value is >= p
         case TK_ASSERT:
           d.a0 = s.slot_of[x];
           d.b0 = y;
@@ -843,7 +887,8 @@ void StreamScheduler::Impl::emit_entries() {
         d.b = y;
         break;
       case TK_COPY: case TK_NOT: case TK_NZ: d.a = s.slot_of[x]; break;
-      case TK_CONST: case TK_INSTANCE: case TK_WITNESS: d.a = x; break;
+      case TK_CONST: d.a = x; break;
+      case TK_INSTANCE: case TK_WITNESS: d.a = x; d.b = strict[i - lo]; break;
       case TK_ASSERT:
         d.a = s.slot_of[x];
         d.b = y;
@@ -938,6 +983,7 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     m.state.assign(n, ST_ENTRY);
     m.ra.assign(w.a, w.a + n);
     m.rb.assign(w.b, w.b + n);
+    m.mark_strict_sources(w);
     m.rewrite_ladders(w);
     m.propagate_copies();
     lap();

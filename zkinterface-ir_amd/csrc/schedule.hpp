@@ -66,6 +66,9 @@ struct Schedule {
   std::vector<Launch> launches;
   std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)
   std::vector<uint32_t> level_of;   // per tape op
+  // input positions whose value must be canonical (an unreduced value would reach copy / assert_zero / not / a bit
+  // operation / Evaluator::get): the GF(2) input packing flags a lane only for these (arithmetic entries carry the flag)
+  std::vector<uint8_t> strict_instance, strict_witness;
   std::vector<uint64_t> window_first_op;   // per window: index of its first program entry (+ a final end marker)
   uint32_t n_slots = 0;
   uint32_t n_levels = 0;

@@ -167,11 +167,10 @@ uint32_t TapeBackend::intern(const Value& bytes) {
 uint32_t TapeBackend::h_constant(FieldElement val) {
   need_field();
   if (val.kind != TapeElement::LITERAL) throw Error("GPU backend: constant() needs literal bytes");
-  // constant() stores the integer unreduced in the reference (evaluator.rs:896-898);
-  // parity is only claimed for canonical values.
-  if (!field_.is_canonical(val.bytes))
-    throw Error("GPU backend: non-canonical constant (value >= field characteristic) is not supported");
-  return push(TK_CONST, intern(val.bytes), 0);
+  // constant() stores the integer unreduced in the reference (evaluator.rs:896-898).  Here it is reduced, which is the
+  // same thing wherever the value first meets an arithmetic gate; b = 1 marks a value >= p so that the scheduler can
+  // refuse the cases where it is not (schedule.cpp mark_strict_sources).
+  return push(TK_CONST, intern(val.bytes), field_.is_canonical(val.bytes) ? 0u : 1u);
 }
 
 uint32_t TapeBackend::h_add_constant(uint32_t x, FieldElement c) {
