@@ -66,6 +66,9 @@ elif [ $WHAT = pmc_c45 ]; then
   pmc c4_lds_unbanked $LDS -- $C4
   unset ZKI_BANK_AWARE
   python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_lds_unbanked.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_lds_counters_bank_unaware.json
+  # the same relation shape with gate j reading wires j and j+1 of the previous layer: conflict-free by construction,
+  # same program size -- what is left is the program stream and the barriers
+  ZKI_C4_WIRING=identity $B --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_c4_identity_wiring.json 2> $OUT/bench_c4_identity.err || true
   C5="--workload c5 --steps 2 --warmup 1 --no-cpu-baseline"
   K5='r1cs_row_kernel<8, false>'
   pmc c5_f FETCH_SIZE -- $C5
