@@ -425,6 +425,11 @@ def main():
     gates = wl.n_gates if hasattr(wl, 'n_gates') else int((kinds != 9).sum())
     algo_bytes_per_lane = float(sum(bytes_table.get(int(k), 0) * int(c) for k, c in zip(*np.unique(kinds, return_counts=True))))
     info = ev.schedule_info()
+    if args.workload == 'structured':
+        # the bytes of the program that runs (one entry = one gate's reads and write; 13 = the `x != 0` entry a ladder
+        # became): the backend calls the rewrite removed -- scope copies, ladder products -- move no bytes at all
+        pk = ev.schedule_dump()[0][:, 1] & 0xFF
+        algo_bytes_per_lane = float(sum({**BYTES_PER_OP, 13: 64}.get(int(k), 0) * int(c) for k, c in zip(*np.unique(pk, return_counts=True))))
     lds = args.workload == 'c4' and ev.uses_lds_path()
     wide_launches = 1 if lds else info['launches'] - info['sequential_launches']
 

@@ -123,14 +123,15 @@ struct LdsOp {  // 8-byte program entry; wide fields are split over the halves t
 
 // The program is cut into kind-uniform chunks of at most kLdsRows rows of 2048 ops (the host sorts a
 // level by kind and pads every kind to a multiple of 2048 with ops writing a scratch slot), so the
-// inner loop carries no per-op decode: chunk = {first op, rows, kind | barrier_after << 8 | sequential << 9, -}.
-// A thread fetches two consecutive ops per row with one 16-byte load (8-byte loads stream at ~0.6x
-// the 16-byte rate, MI355X_MICROARCH.md).
+// inner loop carries no per-op decode: chunk = {first, rows, kind | barrier_after << 8 | sequential << 9, run}; `first`
+// is an op index into `ops` for a generic chunk and the index of the first 12-byte thread record in `ops6` for a
+// kind-uniform one (a thread fetches its two consecutive ops of a row with one 12-byte load).
 constexpr int kLdsRows = 4;
 constexpr int kLdsRowOps = 2048;
 
 struct BoolLdsArgs {
-  const LdsOp* ops;
+  const LdsOp* ops;         // generic chunks (inputs, constants, asserts, sequential segments): 8-byte entries
+  const u32* ops6;          // kind-uniform chunks: 12 bytes per thread and row (two ops of three u16 each)
   const u32* chunks;
   u32 n_chunks;
   u32 n_slots;              // including the scratch slot

@@ -160,19 +160,22 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
 
 // All ops of a chunk belong to one level, hence are mutually independent: every operand read is
 // issued before the first result is written, so LDS latency is paid once per chunk, not per op.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native vector: usable as an asm operand
+// The ops of the kind-uniform chunks are stored without their kind (it is in the chunk header): three u16 per op,
+// two ops = 12 bytes per thread and row -- {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16} -- because the program
+// stream, which every workgroup reads in full, is what bounds this kernel once the LDS accesses are conflict-free.
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));  // native vector: usable as an asm operand
 
 template <u32 KIND, bool FULL>
-__device__ __forceinline__ void lds_rows(const u32x4 (&raw)[kLdsRows], u32 rows, u32* __restrict__ T) {
+__device__ __forceinline__ void lds_rows(const u32x3 (&raw)[kLdsRows], u32 rows, u32* __restrict__ T) {
   u32 x[2 * kLdsRows], y[2 * kLdsRows];
 #pragma unroll
   for (int j = 0; j < kLdsRows; ++j) {
     if (FULL || (u32)j < rows) {
       x[2 * j] = T[raw[j].x >> 16];
-      x[2 * j + 1] = T[raw[j].z >> 16];
+      x[2 * j + 1] = T[raw[j].z & 0xFFFF];
       if (KIND == OP_XOR || KIND == OP_AND) {
         y[2 * j] = T[raw[j].y & 0xFFFF];
-        y[2 * j + 1] = T[raw[j].w & 0xFFFF];
+        y[2 * j + 1] = T[raw[j].z >> 16];
       }
     }
   }
@@ -185,7 +188,7 @@ __device__ __forceinline__ void lds_rows(const u32x4 (&raw)[kLdsRows], u32 rows,
       else if (KIND == OP_NOT) { r0 = ~x[2 * j]; r1 = ~x[2 * j + 1]; }
       else { r0 = x[2 * j]; r1 = x[2 * j + 1]; }
       T[raw[j].x & 0xFFFF] = r0;
-      T[raw[j].z & 0xFFFF] = r1;
+      T[raw[j].y >> 16] = r1;
     }
   }
 }
@@ -207,17 +210,17 @@ __device__ __forceinline__ void lds_barrier() {
 // Program-stream loads hidden from hipcc's s_waitcnt bookkeeping (cdna_hip_programming.md 5.7): the
 // compiler would drain vmcnt(0) at every join of the kind/rows branches; here the waits are counted by
 // hand.  The destination registers are only consumed behind lds_wait_vm<N>, which names them "+v".
-__device__ __forceinline__ void lds_gload16(u32x4& dst, const u32x4* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+__device__ __forceinline__ void lds_gload12(u32x3& dst, const u32* p) {
+  asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void lds_wait_vm(u32x4 (&b)[kLdsRows]) {
+__device__ __forceinline__ void lds_wait_vm(u32x3 (&b)[kLdsRows]) {
   static_assert(kLdsRows == 4, "operand list below names 4 rows");
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void lds_simple_chunk(const u32x4 (&buf)[kLdsRows], u32 rows, u32 flags,
+__device__ __forceinline__ void lds_simple_chunk(const u32x3 (&buf)[kLdsRows], u32 rows, u32 flags,
                                                  u32* __restrict__ T) {
   const u32 kind = flags & 0xFF;
   if (rows == kLdsRows) {
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) 
   const u32 lane0 = col * 32;
   const u32 valid_mask = lane0 >= args.batch ? 0u
                          : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
-  const u32x4* __restrict__ prog = reinterpret_cast<const u32x4*>(args.ops) + tid;
+  const u32* __restrict__ prog = args.ops6 + 3 * tid;   // this thread's 12-byte record of a row
   u32 c = 0;
   while (c < args.n_chunks) {
     c = __builtin_amdgcn_readfirstlane(c);
@@ -265,11 +268,11 @@ __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) 
     // (index clamped to the run), the body holds no other vector-memory op, and the barrier does not
     // drain vmcnt, so the compiler emits counted vmcnt waits.
     const u32 e = c + run;
-    u32x4 b0[kLdsRows], b1[kLdsRows], b2[kLdsRows];
-    auto fetch = [&](u32x4 (&buf)[kLdsRows], u32 cc) {
-      const u32x4* src = prog + (lds_sload(args.chunks, 4 * min(cc, e - 1)) >> 1);
+    u32x3 b0[kLdsRows], b1[kLdsRows], b2[kLdsRows];
+    auto fetch = [&](u32x3 (&buf)[kLdsRows], u32 cc) {
+      const u32* src = prog + 3 * (size_t)lds_sload(args.chunks, 4 * min(cc, e - 1));   // chunk field 0: first thread record
 #pragma unroll
-      for (int j = 0; j < kLdsRows; ++j) lds_gload16(buf[j], src + j * 1024);
+      for (int j = 0; j < kLdsRows; ++j) lds_gload12(buf[j], src + j * (3 * 1024));
     };
     // in flight at every wait: the chunk about to run + the two behind it = 12 loads -> vmcnt(8)
     fetch(b0, c);

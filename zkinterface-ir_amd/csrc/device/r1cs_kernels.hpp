@@ -8,6 +8,10 @@
 #pragma once
 #include "replay_kernels.hpp"
 
+#ifndef ZKGPU_R1CS_WAVES
+#define ZKGPU_R1CS_WAVES 1   // minimum waves per SIMD asked of the register allocator (1 = no constraint)
+#endif
+
 namespace zkgpu {
 
 // wave-uniform row / term descriptors on the scalar path
@@ -91,7 +95,7 @@ __device__ __forceinline__ Fp<N> r1cs_lincomb(const R1csArgs& args, const uint4*
 // ASSIGN = false: compare and record the first failing row per lane.
 // ASSIGN = true : C must be a single term with coefficient 1; its slot receives <a,w>*<b,w>.
 template <int N, bool ASSIGN>
-__global__ __launch_bounds__(256) void r1cs_row_kernel(const R1csArgs args, const FieldParams fp) {
+__global__ __launch_bounds__(256, ZKGPU_R1CS_WAVES) void r1cs_row_kernel(const R1csArgs args, const FieldParams fp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   const u32 lb = blockIdx.y;

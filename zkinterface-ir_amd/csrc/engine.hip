@@ -116,6 +116,7 @@ Engine::~Engine() {
   dfree(d_consts_);
   dfree(d_counts_);
   dfree(d_lds_ops_);
+  dfree(d_lds_ops6_);
   dfree(d_launches_);
   dfree(d_strict_inst_);
   dfree(d_strict_wit_);
@@ -342,6 +343,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
         return o;
       };
       std::vector<zkgpu::LdsOp> lo;
+      std::vector<unsigned short> lo6;   // the kind-uniform chunks: u16 {dst, a, b} per op
       std::vector<uint32_t> ln;
       lo.reserve(s.ops.size() + 4096 * s.launches.size());
       const unsigned short scratch = (unsigned short)s.n_slots;  // extra slot: target of the padding ops
@@ -358,19 +360,36 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
           const uint32_t kind = s.ops[L.first + k].kind;
           uint32_t e = k;
           while (e < L.count && s.ops[L.first + e].kind == kind) ++e;
-          if (lo.size() & 1) lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});  // 16-B aligned rows
-          const uint32_t first = (uint32_t)lo.size();
-          for (uint32_t q = k; q < e; ++q) lo.push_back(encode(s.ops[L.first + q]));
           const bool simple = kind == zkgpu::OP_XOR || kind == zkgpu::OP_AND || kind == zkgpu::OP_NOT || kind == zkgpu::OP_COPY;
           // padding: simple kinds re-do a harmless op into the scratch slot; others are NOPs
-          zkgpu::LdsOp pad{scratch, 0, 0, (unsigned short)(simple ? kind : (uint32_t)zkgpu::OP_NOP)};
-          while ((lo.size() - first) % zkgpu::kLdsRowOps) lo.push_back(pad);
-          const uint32_t rows = ((uint32_t)lo.size() - first) / zkgpu::kLdsRowOps;
+          const zkgpu::LdsOp pad{scratch, 0, 0, (unsigned short)(simple ? kind : (uint32_t)zkgpu::OP_NOP)};
+          uint32_t first, rows;
+          if (simple) {
+            // three u16 per op (the kind is the chunk's): {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16} per two ops
+            first = (uint32_t)(lo6.size() / 6);   // in 12-byte thread records
+            size_t n = 0;
+            auto put6 = [&](const zkgpu::LdsOp& o) {
+              lo6.push_back(o.dst);
+              lo6.push_back(o.a);
+              lo6.push_back(o.b);
+              ++n;
+            };
+            for (uint32_t q = k; q < e; ++q) put6(encode(s.ops[L.first + q]));
+            while (n % zkgpu::kLdsRowOps) put6(pad);
+            rows = (uint32_t)(n / zkgpu::kLdsRowOps);
+          } else {
+            if (lo.size() & 1) lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});  // 16-B aligned rows
+            first = (uint32_t)lo.size();
+            for (uint32_t q = k; q < e; ++q) lo.push_back(encode(s.ops[L.first + q]));
+            while ((lo.size() - first) % zkgpu::kLdsRowOps) lo.push_back(pad);
+            rows = ((uint32_t)lo.size() - first) / zkgpu::kLdsRowOps;
+          }
           const bool last_kind = e >= L.count;
           for (uint32_t r = 0; r < rows; r += zkgpu::kLdsRows) {
             const uint32_t n = std::min<uint32_t>(zkgpu::kLdsRows, rows - r);
             const uint32_t barrier = (last_kind && r + n >= rows) ? 1u : 0u;
-            ln.insert(ln.end(), {first + r * zkgpu::kLdsRowOps, n, kind | (barrier << 8), 0u});
+            // a row is kLdsRowOps ops = 1024 thread records of a kind-uniform chunk
+            ln.insert(ln.end(), {first + r * (simple ? 1024u : (uint32_t)zkgpu::kLdsRowOps), n, kind | (barrier << 8), 0u});
           }
           k = e;
         }
@@ -392,12 +411,17 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
           c = e;
         }
         // rows past a short chunk are fetched (and ignored): keep them inside the allocation
-        for (int k = 0; k < zkgpu::kLdsRows * zkgpu::kLdsRowOps; ++k)
+        for (int k = 0; k < zkgpu::kLdsRows * zkgpu::kLdsRowOps; ++k) {
           lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});
+          lo6.insert(lo6.end(), {scratch, 0, 0});
+        }
         n_lds_chunks_ = (uint32_t)nc;
       }
       HIP_OK(hipMalloc(&d_lds_ops_, std::max<size_t>(lo.size() * sizeof(zkgpu::LdsOp), 64)));
       if (!lo.empty()) HIP_OK(hipMemcpy(d_lds_ops_, lo.data(), lo.size() * sizeof(zkgpu::LdsOp), hipMemcpyHostToDevice));
+      dfree(d_lds_ops6_);
+      HIP_OK(hipMalloc(&d_lds_ops6_, std::max<size_t>(lo6.size() * 2, 64)));
+      if (!lo6.empty()) HIP_OK(hipMemcpy(d_lds_ops6_, lo6.data(), lo6.size() * 2, hipMemcpyHostToDevice));
       HIP_OK(hipMalloc(&d_launches_, std::max<size_t>(ln.size() * 4, 64)));
       if (!ln.empty()) HIP_OK(hipMemcpy(d_launches_, ln.data(), ln.size() * 4, hipMemcpyHostToDevice));
       HIP_OK(zkgpu::bool_lds_set_max_shared((int)kLdsBytes));
@@ -765,6 +789,7 @@ void Engine::enqueue_replay(bool time_each_launch) {
     zkgpu::BoolLdsArgs a;
     memset(&a, 0, sizeof a);
     a.ops = (const zkgpu::LdsOp*)d_lds_ops_;
+    a.ops6 = (const zkgpu::u32*)d_lds_ops6_;
     a.chunks = (const zkgpu::u32*)d_launches_;
     a.n_chunks = n_lds_chunks_;
     a.n_slots = sched_.n_slots + 1;  // + scratch slot of the padding ops

@@ -161,7 +161,8 @@ class Engine {
   uint32_t r1cs_rows_ = 0, r1cs_one_coef_ = 0;
   uint32_t extra_slots_ = 0, table_slots_ = 0;
   float last_r1cs_ms_ = 0.f;
-  void* d_lds_ops_ = nullptr;       // 8-byte program for the LDS-resident GF(2) kernel
+  void* d_lds_ops_ = nullptr;       // 8-byte program entries of the LDS-resident GF(2) kernel (generic chunks)
+  void* d_lds_ops6_ = nullptr;      // its kind-uniform chunks: 6 bytes per op
   void* d_launches_ = nullptr;
   uint32_t n_lds_chunks_ = 0;
   int bool_path_ = 0;
