@@ -366,6 +366,7 @@ def main():
     ap.add_argument('--lane-group', type=int, default=0, help='replay lane groups of this size one after the other')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hbm-variant', action='store_true', help='c2: skip the 4096-witnesses-in-flight variant')
+    ap.add_argument('--no-first-verdict', action='store_true', help='c2: skip the relation-in -> first-verdict-out sessions')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -489,7 +490,7 @@ def main():
     exp_sat = workloads.expected_satisfied(batch * world)
     assert total[0] == exp_sat and total[0] + total[1] == batch * world, (total, exp_sat)
     first_verdict = None
-    if world == 1 and args.workload == 'c2':
+    if world == 1 and args.workload == 'c2' and not args.no_first_verdict:
         first_verdict = {}
         for name, stream, pinned in (('at_finalize', 0, False), ('streamed', 1, False), ('streamed_pinned_inputs', 1, True)):
             runs = [first_verdict_seconds(zk, wl, msgs, inst, wit, batch, stream, pinned) for _ in range(3)]

@@ -256,6 +256,11 @@ int zkgpu_r1cs_results(zkgpu_session* s, uint32_t* first_fail_row, uint64_t coun
 int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out);
 /* the same for n_vars variables at once: out[lane][k][elem_bytes] */
 int zkgpu_r1cs_get_vars(zkgpu_session* s, const uint64_t* vars, uint32_t n_vars, uint8_t* out);
+/* The quotient ("correction") wires of ToR1CSConverter with use_correction (to_r1cs.rs:163-211,213-260,262-359): for
+ * the listed recorded calls (tape indices of add / multiply / add_constant / mul_constant / not calls; the correction
+ * variable of call i is var_of_op[i] + 1 of zkgpu_r1cs_export) the integer q = (a op b) / p of every lane, computed on
+ * the GPU from the retain_all wire table of the last replay: out[lane][k][elem_bytes], little-endian. */
+int zkgpu_r1cs_correction_values(zkgpu_session* s, const uint64_t* tape_ops, uint32_t n_ops, uint8_t* out);
 float zkgpu_r1cs_last_ms(const zkgpu_session* s);             /* HIP-event time of the last check */
 
 #ifdef __cplusplus

@@ -530,6 +530,50 @@ def test_r1cs_of_a_relation_is_satisfied_by_the_replayed_wires(name):
         assert int(ff[0]) == zk.NO_FAIL
 
 
+@pytest.mark.parametrize('p', [101, circuits.BN254_R, 2 ** 61 - 1])
+def test_r1cs_quotient_wires_on_the_gpu(p):
+    """ToR1CSConverter with use_correction gives every add / mul / add_constant / mul_constant call a second variable,
+    the integer quotient q = (a op b) / p (to_r1cs.rs:163-211,213-260,262-359), so that `a op b = out + q * p` holds over
+    the integers.  The GPU computes it for a whole batch from the retain_all wire table; here against Python integers on
+    the oracle's wire values of every lane, for all such calls of the example relation (ladders included)."""
+    lanes = 5
+    _, _, rel = circuits.arith_example(p)
+    rows_i, rows_w = _batched_example(p, lanes)
+    ev = zk.Evaluator()
+    ev.declare_inputs(3, 4)
+    ev.ingest_message(rel)
+    ev.finalize(retain_all=True)
+    ev.r1cs_from_tape(use_correction=True)
+    inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+    ev.set_inputs(inst, wit, lanes)
+    ev.replay()
+    ev.synchronize()
+    kinds, a, b = ev.tape()
+    consts = [int.from_bytes(c, 'little') for c in ev.constants()]
+    calls = [i for i, k in enumerate(kinds) if int(k) in (1, 2, 3, 4)]
+    assert len(calls) > 300
+    got = ev.r1cs_correction_values(calls, lanes)
+    value_index = {i: t for t, i in enumerate(j for j, k in enumerate(kinds) if int(k) != 9)}
+    mod_le = p.to_bytes((p.bit_length() + 7) // 8, 'little')
+    for lane in range(lanes):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32)
+        vals = ref.trace_values()
+        checked = 0
+        for n, i in enumerate(calls):
+            if value_index[i] >= len(vals):
+                break                      # the oracle stopped at this lane's first failing assert
+            x = vals[value_index[int(a[i])]]
+            k = int(kinds[i])
+            y = vals[value_index[int(b[i])]] if k in (1, 2) else consts[int(b[i])]
+            full = x + y if k in (1, 3) else x * y
+            assert full % p == vals[value_index[i]]
+            assert got[lane][n] == full // p, (lane, i, k)
+            checked += 1
+        assert checked > 100
+    with pytest.raises(zk.ZkGpuError, match='is not add / mul'):
+        ev.r1cs_correction_values([i for i, k in enumerate(kinds) if int(k) == 5][:1], lanes)
+
+
 def test_r1cs_batched_matches_evaluation_counts():
     lanes = 70
     _, _, rel = circuits.arith_example(circuits.BN254_R)

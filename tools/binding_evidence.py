@@ -75,8 +75,16 @@ def main():
               'lds_bank_conflict_cycles': lds.get('SQ_LDS_BANK_CONFLICT'),
               'program_stream_GB_per_s_per_CU': prog_bytes / (ms * 1e-3) / 1e9,
               'program_bytes_per_workgroup': prog_bytes, 'workgroups': wgs,
-              'reading': 'every workgroup (one per CU, 128 of 256 CUs at batch 4096) streams the whole program from L2; '
-                         'MI355X_MICROARCH.md measures 66-73 GB/s per CU for rows shared by every workgroup',
+              'waves_parked_frac': lds.get('SQ_WAIT_ANY', 0) / max(lds.get('SQ_WAVE_CYCLES', 1), 1),
+              'lds_issue_stall_frac': lds.get('SQ_WAIT_INST_LDS', 0) / max(lds.get('SQ_WAVE_CYCLES', 1), 1),
+              'valu_insts_per_gate_and_wave': lds.get('SQ_INSTS_VALU', 0) / max(lds.get('SQ_INSTS_LDS', 1) / 3.0, 1),
+              'reading': 'one workgroup = one CU walks all 10.5 M ops (128 of 256 CUs at batch 4096).  With the bank-aware schedule '
+                         'the conflict cycles fall from 0.67 to 0.13 of the LDS cycles and the kernel from 1.99 to 1.49 ms; '
+                         'a conflict-free wiring of the same size runs in the same 1.51 ms, and so does a program stream a quarter '
+                         'smaller (6-byte entries): neither conflicts nor the stream bound it any more.  The waves are parked on '
+                         's_waitcnt / s_barrier about half of their cycles: what is left is the dependent chain program word -> '
+                         'address -> LDS read -> op -> LDS write inside each of the 644 barrier-separated levels (16 ops per thread '
+                         'and level)',
               'sources': ['profiles/%s_pmc_c4_lds_counters.json' % tag]}
         if lds0:
             ev['before_bank_aware_schedule'] = {'lds_bank_conflict_cycles_over_lds_active_cycles': ratio(lds0),
@@ -87,7 +95,7 @@ def main():
             ev['kernel_ms_under_pmc'] = lds.get('avg_ns', 0) / 1e6
         if ident:
             ev['conflict_free_wiring_same_program_size_ms'] = ident['ms_per_step']
-        json.dump({'workload': 'c4', 'kernel': 'bool_lds_kernel', 'binding': 'program stream (L2 -> CU), then LDS', 'evidence': ev},
+        json.dump({'workload': 'c4', 'kernel': 'bool_lds_kernel', 'binding': 'lds latency (waits and level barriers), not LDS bandwidth', 'evidence': ev},
                   open(os.path.join(d, 'binding_c4.json'), 'w'), indent=1)
     # ---- C5
     bench = load(d, '%s_bench_c5.json' % tag)

@@ -38,19 +38,21 @@ if [ $WHAT = bench ]; then
   done
   tail -c 400 $OUT/${TAG}_bench_c2.json
 elif [ $WHAT = pmc_c2 ]; then
-  C2="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-variant --streams 1"
+  # one stream: a level is ONE launch over all 1024 witnesses (grid > 2M threads); the probe session of bench.py replays
+  # its lane halves on two streams (1.3M threads per launch) and is left out by the grid filter
+  C2="--steps 3 --warmup 1 --no-cpu-baseline --no-hbm-variant --no-first-verdict --streams 1"
   K='replay_fused_kernel<8, 0>'
   pmc c2_f FETCH_SIZE -- $C2
   pmc c2_w WRITE_SIZE -- $C2
-  python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c2_f.csv /tmp/pmc_c2_w.csv $OUT/pmc_traffic_latest.json 1000000 "$K" c2 > /dev/null
+  python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c2_f.csv /tmp/pmc_c2_w.csv $OUT/pmc_traffic_latest.json 2000000 "$K" c2 > /dev/null
   head -4 /tmp/pmc_c2_f.csv > $OUT/${TAG}_pmc_fetch_sample.csv
   head -4 /tmp/pmc_c2_w.csv > $OUT/${TAG}_pmc_write_sample.csv
   pmc c2_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -- $C2
-  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c2_sq.csv "$K" 1000000 > $OUT/${TAG}_pmc_c2_sq_counters.json
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c2_sq.csv "$K" 2000000 > $OUT/${TAG}_pmc_c2_sq_counters.json
   pmc c2_tcc TCC_HIT_sum TCC_MISS_sum -- $C2
-  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c2_tcc.csv "$K" 1000000 > $OUT/${TAG}_pmc_c2_tcc_counters.json
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c2_tcc.csv "$K" 2000000 > $OUT/${TAG}_pmc_c2_tcc_counters.json
   # the same program with 4096 witnesses in flight (1.05 GB wire table: cannot sit in the Infinity Cache)
-  H="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-variant --streams 1 --batch-per-gpu 4096 --lane-group 4096"
+  H="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-variant --no-first-verdict --streams 1 --batch-per-gpu 4096 --lane-group 4096"
   pmc c2h_f FETCH_SIZE -- $H
   pmc c2h_w WRITE_SIZE -- $H
   python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c2h_f.csv /tmp/pmc_c2h_w.csv $OUT/pmc_traffic_c2_hbm_variant.json 4000000 "$K" c2_hbm_variant > /dev/null

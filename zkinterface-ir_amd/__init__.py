@@ -121,6 +121,7 @@ def lib():
         'zkgpu_r1cs_results': (ci, [vp, vp, u64p]),
         'zkgpu_r1cs_get_var': (ci, [vp, u64, vp]),
         'zkgpu_r1cs_get_vars': (ci, [vp, vp, u32, vp]),
+        'zkgpu_r1cs_correction_values': (ci, [vp, vp, u32, vp]),
         'zkgpu_r1cs_last_ms': (ctypes.c_float, [vp]),
     }
     for name, (res, args) in sig.items():
@@ -527,6 +528,17 @@ class Evaluator:
         buf = ctypes.create_string_buffer(max(batch * w, 1))
         self._ck(self.L.zkgpu_r1cs_get_var(self.h, var, buf))
         return [int.from_bytes(buf.raw[l * w:(l + 1) * w], 'little') for l in range(batch)]
+
+    def r1cs_correction_values(self, tape_ops, batch):
+        """q[lane][k] = the integer quotient (a op b) // p of the k-th listed call (to_r1cs.rs use_correction)"""
+        import numpy as np
+        w = self.elem_bytes
+        ids = np.ascontiguousarray(tape_ops, dtype=np.uint64)
+        buf = ctypes.create_string_buffer(max(batch * len(ids) * w, 1))
+        self._ck(self.L.zkgpu_r1cs_correction_values(self.h, ids.ctypes.data, len(ids), buf))
+        raw = buf.raw
+        return [[int.from_bytes(raw[(l * len(ids) + k) * w:(l * len(ids) + k + 1) * w], 'little') for k in range(len(ids))]
+                for l in range(batch)]
 
     def r1cs_get_vars(self, variables, batch):
         """values[lane][k] of the k-th listed variable (one device dump for all of them)"""

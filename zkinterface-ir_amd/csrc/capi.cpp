@@ -1290,6 +1290,49 @@ int zkgpu_r1cs_get_vars(zkgpu_session* s, const uint64_t* vars, uint32_t n_vars,
 
 int zkgpu_r1cs_get_var(zkgpu_session* s, uint64_t var, uint8_t* out) { return zkgpu_r1cs_get_vars(s, &var, 1, out); }
 
+int zkgpu_r1cs_correction_values(zkgpu_session* s, const uint64_t* tape_ops, uint32_t n_ops, uint8_t* out) {
+  return guarded(s, [&] {
+    need_engine(s);
+    single_device_only(s, "zkgpu_r1cs_correction_values");
+    if (!s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) is required: the quotients are computed from the wire values");
+    const Tape& t = s->backend.tape();
+    const FieldHost& f = s->backend.field();
+    if (f.is_two) throw std::runtime_error("quotient wires need an odd field characteristic");
+    const uint32_t one_const = (uint32_t)t.consts.size();   // the literal 1 of `not` = add_constant(a, 1) (to_r1cs.rs:369-371)
+    std::vector<uint32_t> calls, const_words((size_t)(t.consts.size() + 1) * f.nwords, 0);
+    for (size_t c = 0; c < t.consts.size(); ++c) {
+      size_t n = t.consts[c].size();
+      while (n > 0 && t.consts[c][n - 1] == 0) --n;
+      if (n > 4 * (size_t)f.nwords) continue;   // checked below, only if a listed call uses it
+      for (size_t b = 0; b < n; ++b) const_words[c * f.nwords + b / 4] |= (uint32_t)t.consts[c][b] << (8 * (b % 4));
+    }
+    const_words[(size_t)one_const * f.nwords] = 1;
+    for (uint32_t k = 0; k < n_ops; ++k) {
+      const uint64_t i = tape_ops[k];
+      if (i >= t.size()) throw std::runtime_error("zkgpu_r1cs_correction_values: not a recorded call");
+      const uint8_t kind = t.kind[i];
+      uint32_t flags = 0, b = 0;
+      switch (kind) {
+        case TK_ADD: b = s->sched.slot_of[t.b[i]]; break;
+        case TK_MUL: b = s->sched.slot_of[t.b[i]]; flags = 1; break;
+        case TK_ADDC: b = t.b[i]; flags = 2; break;
+        case TK_MULC: b = t.b[i]; flags = 3; break;
+        case TK_NOT: b = one_const; flags = 2; break;
+        default: throw std::runtime_error("zkgpu_r1cs_correction_values: call " + std::to_string(i) + " is not add / mul / add_constant / mul_constant / not");
+      }
+      if ((flags & 2) && b < t.consts.size()) {
+        size_t n = t.consts[b].size();
+        while (n > 0 && t.consts[b][n - 1] == 0) --n;
+        if (n > 4 * (size_t)f.nwords) throw std::runtime_error("zkgpu_r1cs_correction_values: a constant wider than the field's limbs");
+      }
+      calls.insert(calls.end(), {s->sched.slot_of[t.a[i]], b, s->sched.slot_of[i], flags});
+    }
+    std::vector<uint8_t> tmp;
+    s->engine->r1cs_corrections(calls, const_words, &tmp);
+    if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+  });
+}
+
 float zkgpu_r1cs_last_ms(const zkgpu_session* s) { return (s && s->engine) ? s->engine->last_r1cs_ms() : 0.f; }
 
 uint64_t zkgpu_table_bytes(const zkgpu_session* s) {

@@ -169,6 +169,23 @@ struct R1csArgs {
   u32 one_coef;          // index of the Montgomery form of 1 in `coefs` (the host appends it to the pool)
 };
 
+// quotient wires of the R1CS conversion (r1cs_correction_kernel)
+struct R1csCorrCall {
+  u32 a, b, out;   // slots of the operands and of the result; b = constant index with kCorrConstB
+  u32 flags;
+};
+constexpr u32 kCorrMul = 1u, kCorrConstB = 2u;
+struct R1csCorrArgs {
+  const R1csCorrCall* calls;
+  u32 n_calls;
+  const uint4* table;
+  u32 n_slots;
+  u32 batch;
+  const u32* consts;   // canonical little-endian words of the raw constants, N each
+  u32 pinv[kMaxWords]; // p^{-1} mod 2^(32N)
+  u32* out;            // [lane][call][N words]
+};
+
 // ---- launchers (defined in kernels_arith.hip, one set per field width, and kernels_bool.hip) ----
 #define ZKGPU_DECLARE_WIDTH(W)                                                                                      \
   void launch_replay_fused_w##W(int cls, dim3 grid, size_t lds_pad, hipStream_t st, const ReplayArgs2& a,         \
@@ -176,7 +193,8 @@ struct R1csArgs {
   void launch_replay_w##W(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp);     \
   void launch_r1cs_w##W(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp);         \
   void launch_dump_w##W(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,  \
-                        u32 batch, u32* out, const FieldParams& fp);
+                        u32 batch, u32* out, const FieldParams& fp);                                               \
+  void launch_r1cs_corr_w##W(dim3 grid, hipStream_t st, const R1csCorrArgs& a, const FieldParams& fp);
 ZKGPU_DECLARE_WIDTH(2)
 ZKGPU_DECLARE_WIDTH(4)
 ZKGPU_DECLARE_WIDTH(6)

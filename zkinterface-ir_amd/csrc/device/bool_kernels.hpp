@@ -165,17 +165,35 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
 // stream, which every workgroup reads in full, is what bounds this kernel once the LDS accesses are conflict-free.
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));  // native vector: usable as an asm operand
 
+// LDS byte address of the slot in the low / high half of a program word: (half << 2) in ONE instruction -- SDWA
+// selects the 16-bit half as the shifted operand (hipcc emits v_and / v_bfe + v_lshl_add: two per field, twelve per
+// pair of ops, most of this kernel's VALU work).  The wire table starts at LDS address 0 (the kernel has no static LDS).
+__device__ __forceinline__ u32 lds_addr_lo(u32 word) {
+  u32 r;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(2u), "v"(word));
+  return r;
+}
+__device__ __forceinline__ u32 lds_addr_hi(u32 word) {
+  u32 r;
+  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(2u), "v"(word));
+  return r;
+}
+typedef u32 __attribute__((address_space(3))) lds_u32;
+__device__ __forceinline__ u32 lds_get(u32 byte_addr) { return *(lds_u32*)(uintptr_t)byte_addr; }
+__device__ __forceinline__ void lds_put(u32 byte_addr, u32 v) { *(lds_u32*)(uintptr_t)byte_addr = v; }
+
 template <u32 KIND, bool FULL>
 __device__ __forceinline__ void lds_rows(const u32x3 (&raw)[kLdsRows], u32 rows, u32* __restrict__ T) {
+  (void)T;
   u32 x[2 * kLdsRows], y[2 * kLdsRows];
 #pragma unroll
   for (int j = 0; j < kLdsRows; ++j) {
     if (FULL || (u32)j < rows) {
-      x[2 * j] = T[raw[j].x >> 16];
-      x[2 * j + 1] = T[raw[j].z & 0xFFFF];
+      x[2 * j] = lds_get(lds_addr_hi(raw[j].x));
+      x[2 * j + 1] = lds_get(lds_addr_lo(raw[j].z));
       if (KIND == OP_XOR || KIND == OP_AND) {
-        y[2 * j] = T[raw[j].y & 0xFFFF];
-        y[2 * j + 1] = T[raw[j].z >> 16];
+        y[2 * j] = lds_get(lds_addr_lo(raw[j].y));
+        y[2 * j + 1] = lds_get(lds_addr_hi(raw[j].z));
       }
     }
   }
@@ -187,8 +205,8 @@ __device__ __forceinline__ void lds_rows(const u32x3 (&raw)[kLdsRows], u32 rows,
       else if (KIND == OP_AND) { r0 = x[2 * j] & y[2 * j]; r1 = x[2 * j + 1] & y[2 * j + 1]; }
       else if (KIND == OP_NOT) { r0 = ~x[2 * j]; r1 = ~x[2 * j + 1]; }
       else { r0 = x[2 * j]; r1 = x[2 * j + 1]; }
-      T[raw[j].x & 0xFFFF] = r0;
-      T[raw[j].y >> 16] = r1;
+      lds_put(lds_addr_lo(raw[j].x), r0);
+      lds_put(lds_addr_hi(raw[j].y), r1);
     }
   }
 }

@@ -132,4 +132,81 @@ __global__ __launch_bounds__(256, ZKGPU_R1CS_WAVES) void r1cs_row_kernel(const R
   }
 }
 
+// ---- quotient ("correction") wires of ToR1CSConverter with use_correction (to_r1cs.rs:163-211, :213-260, :262-359):
+// every add / mul / add_constant / mul_constant call gets a second variable q = (a op b) / p, the integer quotient
+// that makes `a op b = out + q * p` hold over the integers (for an R1CS over a larger field).  q is not a field
+// operation, but it needs no division: a op b - out = q * p exactly and q < 2^(32N), so
+//     q = ((a op b) - out) * p^{-1}  mod 2^(32N)
+// -- the low halves of two products.  One wave = one call x 64 witnesses; operands come out of the retain_all wire
+// table (Montgomery form -> canonical), the quotient goes out as canonical little-endian words.
+template <int N>
+__device__ __forceinline__ void mul_low(const u32 (&a)[N], const u32 (&b)[N], u32 (&r)[N]) {   // a * b mod 2^(32N)
+  u64 acc = 0;
+  u32 carry_hi = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) {
+      const u64 prod = (u64)a[i] * b[k - i];
+      acc += prod;
+      carry_hi += acc < prod;
+    }
+    r[k] = (u32)acc;
+    acc = (acc >> 32) | ((u64)carry_hi << 32);
+    carry_hi = 0;
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void r1cs_correction_kernel(const R1csCorrArgs args, const FieldParams fp) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 lb = blockIdx.y;
+  const u32 k = blockIdx.x * (blockDim.x >> 6) + wave;
+  const u32 lane_g = lb * 64 + lane;
+  if (k >= args.n_calls) return;
+  const R1csCorrCall c = args.calls[k];
+  const uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
+  const Fp<N> av = fp_from_mont<N>(wire_load<N>(T + (size_t)c.a * Layout<N>::kRecord), fp);
+  const Fp<N> ov = fp_from_mont<N>(wire_load<N>(T + (size_t)c.out * Layout<N>::kRecord), fp);
+  u32 a[N], b[N], out[N], low[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { a[i] = av.w[i]; out[i] = ov.w[i]; }
+  if (c.flags & kCorrConstB) {   // the raw constant, as the call got it
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] = args.consts[(size_t)c.b * N + i];
+  } else {
+    const Fp<N> bv = fp_from_mont<N>(wire_load<N>(T + (size_t)c.b * Layout<N>::kRecord), fp);
+#pragma unroll
+    for (int i = 0; i < N; ++i) b[i] = bv.w[i];
+  }
+  if (c.flags & kCorrMul) {
+    mul_low<N>(a, b, low);
+  } else {
+    u64 carry = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      carry += (u64)a[i] + b[i];
+      low[i] = (u32)carry;
+      carry >>= 32;
+    }
+  }
+  u64 borrow = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {   // (a op b) - out  mod 2^(32N)
+    const u64 d = (u64)low[i] - out[i] - borrow;
+    low[i] = (u32)d;
+    borrow = (d >> 63) & 1;
+  }
+  u32 pinv[N], q[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) pinv[i] = args.pinv[i];
+  mul_low<N>(low, pinv, q);
+  if (lane_g < args.batch) {
+    u32* o = args.out + ((size_t)lane_g * args.n_calls + k) * N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) o[i] = q[i];
+  }
+}
+
 }  // namespace zkgpu

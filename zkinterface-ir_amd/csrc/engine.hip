@@ -908,6 +908,83 @@ void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
   HIP_OK(hipGetLastError());
 }
 
+void Engine::r1cs_corrections(const std::vector<uint32_t>& calls4, const std::vector<uint32_t>& const_words, std::vector<uint8_t>* out) {
+  use_device();
+  if (boolean_) throw std::runtime_error("Engine: quotient wires need an arithmetic field");
+  if (!batch_ || !d_table_) throw std::runtime_error("Engine: set_batch() and a replay first");
+  synchronize();
+  const uint32_t n = (uint32_t)(calls4.size() / 4);
+  out->assign((size_t)batch_ * n * elem_bytes_, 0);
+  if (!n) return;
+  const uint64_t n_consts = nwords_ ? const_words.size() / nwords_ : 0;
+  for (uint32_t k = 0; k < n; ++k) {   // host check of every index the kernel dereferences
+    const uint32_t* c = &calls4[4 * k];
+    if (c[0] >= table_slots_ || c[2] >= table_slots_ || ((c[3] & zkgpu::kCorrConstB) ? c[1] >= n_consts : c[1] >= table_slots_))
+      throw std::runtime_error("Engine: quotient call " + std::to_string(k) + " names a slot or constant out of range");
+  }
+  zkgpu::FieldParams fp;
+  memcpy(&fp, field_params_, sizeof fp);
+  zkgpu::R1csCorrArgs a;
+  memset(&a, 0, sizeof a);
+  // p^{-1} mod 2^(32 * nwords) by Hensel lifting from -n0inv = p^{-1} mod 2^32: x <- x * (2 - p * x)
+  {
+    const uint32_t N = nwords_;
+    std::vector<uint32_t> x(N, 0), t(N), u(N);
+    x[0] = 0u - fp.n0inv;
+    auto mul_low = [&](const uint32_t* p, const uint32_t* q, uint32_t* r) {
+      std::vector<uint64_t> acc(N + 1, 0);
+      for (uint32_t i = 0; i < N; ++i) {
+        uint64_t carry = 0;
+        for (uint32_t j = 0; i + j < N; ++j) {
+          const uint64_t v = (uint64_t)p[i] * q[j] + (acc[i + j] & 0xFFFFFFFFu) + carry;
+          acc[i + j] = v & 0xFFFFFFFFu;
+          carry = v >> 32;
+        }
+      }
+      for (uint32_t i = 0; i < N; ++i) r[i] = (uint32_t)acc[i];
+    };
+    for (uint32_t bits = 32; bits < 32 * N; bits *= 2) {
+      mul_low(fp.p, x.data(), t.data());            // p * x
+      uint64_t borrow = 0;                          // 2 - p * x
+      for (uint32_t i = 0; i < N; ++i) {
+        const uint64_t d = (uint64_t)(i == 0 ? 2u : 0u) - t[i] - borrow;
+        u[i] = (uint32_t)d;
+        borrow = (d >> 63) & 1;
+      }
+      mul_low(x.data(), u.data(), t.data());
+      x = t;
+    }
+    for (uint32_t i = 0; i < N; ++i) a.pinv[i] = x[i];
+  }
+  hipStream_t st = (hipStream_t)stream_;
+  void *d_calls = nullptr, *d_consts = nullptr, *d_out = nullptr;
+  HIP_OK(hipMalloc(&d_calls, calls4.size() * 4));
+  HIP_OK(hipMalloc(&d_consts, std::max<size_t>(const_words.size() * 4, 64)));
+  HIP_OK(hipMalloc(&d_out, out->size()));
+  HIP_OK(hipMemcpy(d_calls, calls4.data(), calls4.size() * 4, hipMemcpyHostToDevice));
+  if (!const_words.empty()) HIP_OK(hipMemcpy(d_consts, const_words.data(), const_words.size() * 4, hipMemcpyHostToDevice));
+  a.calls = (const zkgpu::R1csCorrCall*)d_calls;
+  a.n_calls = n;
+  a.table = (const uint4*)d_table_;
+  a.n_slots = table_slots_;
+  a.batch = batch_;
+  a.consts = (const zkgpu::u32*)d_consts;
+  a.out = (zkgpu::u32*)d_out;
+  const dim3 grid((n + 3) / 4, lane_blocks_);
+  switch (nwords_) {
+#define X(W) case W: zkgpu::launch_r1cs_corr_w##W(grid, st, a, fp); break;
+    ZK_WIDTHS(X)
+#undef X
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(hipMemcpy(out->data(), d_out, out->size(), hipMemcpyDeviceToHost));
+  (void)hipFree(d_calls);
+  (void)hipFree(d_consts);
+  (void)hipFree(d_out);
+}
+
 void Engine::r1cs_finish_check() {
   use_device();
   hipStream_t st = (hipStream_t)stream_;

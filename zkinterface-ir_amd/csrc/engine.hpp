@@ -83,6 +83,10 @@ class Engine {
   void r1cs_finish_check();                                       // counts; records the event time
   void r1cs_results(std::vector<uint32_t>* first_fail_row, uint64_t counts[2]);
   float last_r1cs_ms() const { return last_r1cs_ms_; }
+  // quotient ("correction") wires of the R1CS conversion for the listed calls: calls4 = {slot a, slot b | constant
+  // index, slot out, flags (1 mul, 2 b is a constant)} per call, const_words = the raw constants (nwords each);
+  // out[lane][call][elem_bytes] little-endian.  Needs the retain_all wire table of a replay.
+  void r1cs_corrections(const std::vector<uint32_t>& calls4, const std::vector<uint32_t>& const_words, std::vector<uint8_t>* out);
 
   uint64_t table_bytes() const { return table_bytes_; }
   uint32_t batch() const { return batch_; }

@@ -39,4 +39,8 @@ void ZKGPU_FN(launch_dump_w)(dim3 grid, hipStream_t st, const uint4* table, u32 
   dump_slots_kernel<ZKGPU_W><<<grid, 64, 0, st>>>(table, n_slots, slots, n_dump, batch, out, fp);
 }
 
+void ZKGPU_FN(launch_r1cs_corr_w)(dim3 grid, hipStream_t st, const R1csCorrArgs& a, const FieldParams& fp) {
+  r1cs_correction_kernel<ZKGPU_W><<<grid, 256, 0, st>>>(a, fp);
+}
+
 }  // namespace zkgpu
