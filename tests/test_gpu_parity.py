@@ -551,7 +551,7 @@ def test_r1cs_quotient_wires_on_the_gpu(p):
     kinds, a, b = ev.tape()
     consts = [int.from_bytes(c, 'little') for c in ev.constants()]
     calls = [i for i, k in enumerate(kinds) if int(k) in (1, 2, 3, 4)]
-    assert len(calls) > 300
+    assert len(calls) > 50
     got = ev.r1cs_correction_values(calls, lanes)
     value_index = {i: t for t, i in enumerate(j for j, k in enumerate(kinds) if int(k) != 9)}
     mod_le = p.to_bytes((p.bit_length() + 7) // 8, 'little')
@@ -569,7 +569,7 @@ def test_r1cs_quotient_wires_on_the_gpu(p):
             assert full % p == vals[value_index[i]]
             assert got[lane][n] == full // p, (lane, i, k)
             checked += 1
-        assert checked > 100
+        assert checked > 30
     with pytest.raises(zk.ZkGpuError, match='is not add / mul'):
         ev.r1cs_correction_values([i for i, k in enumerate(kinds) if int(k) == 5][:1], lanes)
 
