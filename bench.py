@@ -153,6 +153,8 @@ def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_b
         ev.set_option('xcd_map', os.environ['ZKI_XCD_MAP'])
     if os.environ.get('ZKI_SORT_BY_OPERAND'):
         ev.set_option('sort_by_operand', os.environ['ZKI_SORT_BY_OPERAND'])
+    if os.environ.get('ZKI_STRAND_WIDTH'):
+        ev.set_option('strand_width', os.environ['ZKI_STRAND_WIDTH'])
     if os.environ.get('ZKI_BANK_AWARE'):
         ev.set_option('bank_aware', os.environ['ZKI_BANK_AWARE'])
     if os.environ.get('ZKI_FERMAT'):
@@ -366,6 +368,7 @@ def main():
     ap.add_argument('--lane-group', type=int, default=0, help='replay lane groups of this size one after the other')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hbm-variant', action='store_true', help='c2: skip the 4096-witnesses-in-flight variant')
+    ap.add_argument('--chained', action='store_true', help='structured: every iteration depends on the one before')
     ap.add_argument('--no-first-verdict', action='store_true', help='c2: skip the relation-in -> first-verdict-out sessions')
     args = ap.parse_args()
 
@@ -409,7 +412,7 @@ def main():
         batch = args.batch_per_gpu or 1024
         bytes_table, bool_path = BYTES_PER_OP, None
     elif args.workload == 'structured':
-        wl = workloads.StructuredArith(N=args.width or 1408)
+        wl = workloads.StructuredArith(N=args.width or 1408, chained=args.chained)
         batch = args.batch_per_gpu or 1024
         bytes_table, bool_path = BYTES_PER_OP, None
     else:
@@ -544,8 +547,9 @@ def main():
             metric = ('backend-ops/sec (whole node), 256-bit field, For/Call/Switch relation of ~1M backend calls, batched '
                       'witnesses (one unit = one value-returning ZKBackend call of the reference evaluator)')
             dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
-            wl_name = ('structured: For over a named function with a nested call and a 2-case Switch, %d iterations, '
-                       'BN254 (shape of producers/examples.rs:72-212), witness batch=%d per GPU, %d GPU(s)' % (wl.N, batch, world))
+            wl_name = ('structured%s: For over a named function with a nested call and a 2-case Switch, %d iterations, '
+                       'BN254 (shape of producers/examples.rs:72-212), witness batch=%d per GPU, %d GPU(s)'
+                       % (' (chained: each iteration reads the previous result)' if wl.chained else '', wl.N, batch, world))
             kernel = 'replay_fused_kernel<8, 0> + <8, 1>' if fused else 'replay_kernel<8, false, false>'
         else:
             metric = 'gate-ops/sec (whole node), GF(2), 10M-gate And/Xor/Not relation, bit-packed batched witnesses'

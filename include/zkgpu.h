@@ -137,6 +137,9 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * "sort_by_operand" = 0|1|2|3 (order of the ops inside a level: tape order, by first operand, that followed by a
  * depth-first walk over shared operands so that the readers of a wire run back to back, or the walk alone; default 3:
  * the pre-sort buys nothing measurable on C2 and costs a third of the scheduling time),
+ * "strand_width" = N (levels with fewer than N entries do not get a launch of their own: consecutive ones form a strand
+ * that one workgroup per lane block walks with a barrier between levels -- the dependency chains of a structured
+ * relation; default 17, 3 = only the levels round 1 walked with a single wave),
  * "bank_aware" = 0|1 (GF(2): order the ops of a level and number the wire-table slots so that the 32 lanes one LDS
  * instruction serves read and write 32 different banks -- and / xor operands are swapped where that helps; default 1),
  * "graph" = 0|1 (replay the captured hipGraph of the whole launch sequence instead of issuing it launch by launch;

@@ -83,6 +83,7 @@ struct zkgpu_session {
   uint32_t stream_window = 0;        // option "stream": tape entries per window, 0 = schedule everything at finalize
   uint32_t sched_threads = 0;
   bool bank_aware = true;
+  uint32_t strand_width = 0;   // 0 = the scheduler's default
   std::unique_ptr<StreamState> stream;
   double stream_busy_s = 0;
   uint32_t stream_windows = 0;
@@ -156,6 +157,7 @@ ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
   opt.propagate_copies = s->propagate_copies;
   opt.threads = s->sched_threads;
   opt.bank_aware = s->bank_aware;
+  if (s->strand_width) opt.strand_width = s->strand_width;
   return opt;
 }
 
@@ -939,6 +941,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       const long n = atol(v.c_str());
       s->stream_window = n <= 0 ? 0 : n == 1 ? 131072u : (uint32_t)std::max<long>(n, 16);
       s->backend.set_window(s->stream_window, s->stream_window ? stream_cut : nullptr, s);
+    } else if (k == "strand_width") {
+      s->strand_width = (uint32_t)std::max(0, atoi(v.c_str()));
     } else if (k == "bank_aware") {
       s->bank_aware = v != "0";
     } else if (k == "schedule_threads") {

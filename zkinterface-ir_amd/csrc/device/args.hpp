@@ -134,7 +134,7 @@ struct BoolLdsArgs {
   const u32* ops6;          // kind-uniform chunks: 12 bytes per thread and row (two ops of three u16 each)
   const u32* chunks;
   u32 n_chunks;
-  u32 n_slots;              // including the scratch slot
+  u32 n_slots;              // including the 32 scratch slots of the padding ops
   u32 batch;
   u32 n_cols;               // 32-witness slices in the batch
   u32 total_words64;        // 64 * lane blocks (layout of the packed inputs)
@@ -190,6 +190,8 @@ struct R1csCorrArgs {
 #define ZKGPU_DECLARE_WIDTH(W)                                                                                      \
   void launch_replay_fused_w##W(int cls, dim3 grid, size_t lds_pad, hipStream_t st, const ReplayArgs2& a,         \
                                 const FieldParams& fp);                                                             \
+  void launch_replay_strand_w##W(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const u32* level_ptr,   \
+                                 u32 n_levels, const FieldParams& fp);                                             \
   void launch_replay_w##W(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp);     \
   void launch_r1cs_w##W(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp);         \
   void launch_dump_w##W(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,  \

@@ -317,8 +317,9 @@ __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) 
     // table[lane_block][slot][word64] as u32 halves: col -> (lane block, word64, half)
     const u32 lb = col / 128, w64 = (col % 128) / 2, half = col % 2;
     u32* out = reinterpret_cast<u32*>(args.table);
-    for (u32 s = tid; s < args.n_slots - 1; s += 1024)
-      out[(((size_t)lb * (args.n_slots - 1) + s) * 64 + w64) * 2 + half] = T[s];
+    const u32 n_real = args.n_slots - 32;   // without the scratch slots of the padding ops
+    for (u32 s = tid; s < n_real; s += 1024)
+      out[(((size_t)lb * n_real + s) * 64 + w64) * 2 + half] = T[s];
   }
 }
 

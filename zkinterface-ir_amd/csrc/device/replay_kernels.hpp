@@ -251,6 +251,52 @@ __device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restric
   wire_store<N>(T + (size_t)dst_slot * REC, r);
 }
 
+// one entry of any kind (the body of the kFusedMisc / kFusedAll instantiations)
+template <int N, int CLS>
+__device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict__ T, const ReplayArgs2& args, u32 lane_g,
+                                            bool lane_valid, const FieldParams& fp) {
+  constexpr int REC = Layout<N>::kRecord;
+  const u32 kind = op.kind & 0xFF;
+  Fp<N> r;
+  bool has_out = true;
+  switch (kind) {
+    case OP_ADD:
+    case OP_MUL: fused_addmul<N>(op, T, fp); has_out = false; break;
+    case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+    case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+    case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
+    case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
+    case OP_AND:
+      if constexpr (CLS == kFusedAll) r = fp_bit_and<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
+      else has_out = false;
+      break;
+    case OP_XOR:
+      if constexpr (CLS == kFusedAll) r = fp_bit_xor<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
+      else has_out = false;
+      break;
+    case OP_NOT: r = fp_is_zero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
+    case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
+    case OP_INSTANCE:
+    case OP_WITNESS: {
+      const bool is_inst = kind == OP_INSTANCE;
+      Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0, lane_valid);
+      if (op.b0 && fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);   // strict inputs only
+      r = fp_to_mont<N>(raw, fp);
+      break;
+    }
+    case OP_ASSERT: {
+      has_out = false;
+      const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC));
+      if (__ballot(nz && lane_valid) != 0ull) {
+        if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b0);
+      }
+      break;
+    }
+    default: has_out = false; break;
+  }
+  if (has_out) wire_store<N>(T + (size_t)op.dst * REC, r);
+}
+
 template <int N, int CLS>
 __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 args, const FieldParams fp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -258,63 +304,45 @@ __global__ __launch_bounds__(256) void replay_fused_kernel(const ReplayArgs2 arg
   u32 chunk, lb_rel;
   block_coords(args.xcd_chunks, chunk, lb_rel);
   const u32 lb = args.lb_base + lb_rel;
-  // Ops of a workgroup: consecutive per wave (op_stride 1: sequential segments must keep their order), or
-  // interleaved over its 4 waves (op_stride 4, levels): the neighbours of the shared-operand order then run
-  // at the same time in neighbouring waves, not one after the other in one wave.
+  // Ops of a workgroup: consecutive per wave (op_stride 1), or interleaved over its 4 waves (op_stride 4): the
+  // neighbours of the shared-operand order then run at the same time in neighbouring waves.
   const u32 stride = args.op_stride;
   const u32 begin = stride == 1 ? (chunk * 4 + wave) * args.ops_per_wave : chunk * 4 * args.ops_per_wave + wave;
   if (begin >= args.n_ops) return;
   const u32 end = min(args.n_ops, begin + args.ops_per_wave * stride);
   uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
-  constexpr int REC = Layout<N>::kRecord;
   if constexpr (CLS == kFusedHot) {
     for (u32 i = begin; i < end; i += stride) fused_addmul<N>(load_entry_scalar(args.ops, i), T, fp);
   } else {
     const u32 lane_g = lb * 64 + lane;
     const bool lane_valid = lane_g < args.batch;
-    for (u32 i = begin; i < end; i += stride) {
-      const TapeOp2 op = load_entry_scalar(args.ops, i);
-      const u32 kind = op.kind & 0xFF;
-      Fp<N> r;
-      bool has_out = true;
-      switch (kind) {
-        case OP_ADD:
-        case OP_MUL: fused_addmul<N>(op, T, fp); has_out = false; break;
-        case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
-        case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
-        case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
-        case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
-        case OP_AND:
-          if constexpr (CLS == kFusedAll) r = fp_bit_and<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
-          else has_out = false;
-          break;
-        case OP_XOR:
-          if constexpr (CLS == kFusedAll) r = fp_bit_xor<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
-          else has_out = false;
-          break;
-        case OP_NOT: r = fp_is_zero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
-        case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
-        case OP_INSTANCE:
-        case OP_WITNESS: {
-          const bool is_inst = kind == OP_INSTANCE;
-          Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0,
-                                    lane_valid);
-          if (op.b0 && fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);   // strict inputs only
-          r = fp_to_mont<N>(raw, fp);
-          break;
-        }
-        case OP_ASSERT: {
-          has_out = false;
-          const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC));
-          if (__ballot(nz && lane_valid) != 0ull) {
-            if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b0);
-          }
-          break;
-        }
-        default: has_out = false; break;
-      }
-      if (has_out) wire_store<N>(T + (size_t)op.dst * REC, r);
-    }
+    for (u32 i = begin; i < end; i += stride) fused_entry<N, CLS>(load_entry_scalar(args.ops, i), T, args, lane_g, lane_valid, fp);
+  }
+}
+
+// Strands: a run of consecutive NARROW levels (fewer entries than pay for a launch of their own -- the dependency
+// chains of a structured relation: one iteration of a loop feeding the next) is walked by ONE workgroup per lane block,
+// level by level, its four waves sharing the entries of a level, with a workgroup barrier between levels.  The barrier
+// also orders the memory accesses: the waves of a workgroup share their CU's L1, so workgroup scope is all it takes for
+// wave B to see what wave A stored to the wire table before the barrier.  One launch instead of one per level: the
+// reference's example relation chained 1,408 times is 7,046 levels.
+template <int N, int CLS>
+__global__ __launch_bounds__(256) void replay_strand_kernel(const ReplayArgs2 args, const u32* __restrict__ level_ptr, u32 n_levels,
+                                                            const FieldParams fp) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 lb = args.lb_base + blockIdx.x;
+  const u32 lane_g = lb * 64 + lane;
+  const bool lane_valid = lane_g < args.batch;
+  uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* lp = (cu32*)(unsigned long long)level_ptr;
+  u32 b = lp[0];
+  for (u32 l = 0; l < n_levels; ++l) {
+    const u32 e = lp[l + 1];
+    for (u32 i = b + wave; i < e; i += 4) fused_entry<N, CLS>(load_entry_scalar(args.ops, i), T, args, lane_g, lane_valid, fp);
+    b = e;
+    __syncthreads();   // every wave of the workgroup reaches it once per level (the level bounds are wave-uniform)
   }
 }
 

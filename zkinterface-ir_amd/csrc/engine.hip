@@ -47,6 +47,15 @@ void launch_fused(uint32_t nwords, int cls, dim3 grid, size_t lds_pad, hipStream
     default: throw std::runtime_error("Engine: unsupported limb count");
   }
 }
+void launch_strand(uint32_t nwords, int cls, dim3 grid, hipStream_t st, const zkgpu::ReplayArgs2& a, const uint32_t* level_ptr,
+                   uint32_t n_levels, const zkgpu::FieldParams& fp) {
+  switch (nwords) {
+#define X(W) case W: zkgpu::launch_replay_strand_w##W(cls, grid, st, a, level_ptr, n_levels, fp); break;
+    ZK_WIDTHS(X)
+#undef X
+    default: throw std::runtime_error("Engine: unsupported limb count");
+  }
+}
 void launch_plain(uint32_t nwords, bool bitops, dim3 grid, hipStream_t st, const zkgpu::ReplayArgs& a, const zkgpu::FieldParams& fp) {
   switch (nwords) {
 #define X(W) case W: zkgpu::launch_replay_w##W(bitops, grid, st, a, fp); break;
@@ -114,6 +123,7 @@ Engine::~Engine() {
   free_batch();
   free_windows();
   dfree(d_consts_);
+  dfree(d_level_ptr_);
   dfree(d_counts_);
   dfree(d_lds_ops_);
   dfree(d_lds_ops6_);
@@ -231,8 +241,17 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
   for (const std::string& c : complaint)
     if (!c.empty()) throw std::runtime_error(c);
   size_t n_ops = s.fused ? s.ops2.size() : s.ops.size();
-  for (const Launch& L : s.launches)
+  for (const Launch& L : s.launches) {
     if ((uint64_t)L.first + L.count > n_ops) throw std::runtime_error("Engine: a launch reaches past the program");
+    if (L.sequential && s.fused) {   // a strand: its level bounds must be a non-decreasing walk over exactly its entries
+      const uint32_t nl = L.level_end - L.level_begin;
+      if ((uint64_t)L.level_ptr + nl + 1 > s.strand_level_ptr.size()) throw std::runtime_error("Engine: a strand's level bounds are missing");
+      const uint32_t* lp = &s.strand_level_ptr[L.level_ptr];
+      for (uint32_t q = 0; q < nl; ++q)
+        if (lp[q] > lp[q + 1]) throw std::runtime_error("Engine: a strand's level bounds decrease");
+      if (lp[0] != 0 || lp[nl] != L.count) throw std::runtime_error("Engine: a strand's level bounds do not cover its entries");
+    }
+  }
 }
 
 void Engine::free_windows() {
@@ -300,6 +319,10 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
     for (size_t w = d_windows_.size(); w < n_win; ++w)
       upload_window(host + s.window_first_op[w] * eb, s.window_first_op[w + 1] - s.window_first_op[w], eb);
   }
+  dfree(d_level_ptr_);
+  HIP_OK(hipMalloc(&d_level_ptr_, std::max<size_t>(s.strand_level_ptr.size() * 4, 64)));
+  if (!s.strand_level_ptr.empty())
+    HIP_OK(hipMemcpy(d_level_ptr_, s.strand_level_ptr.data(), s.strand_level_ptr.size() * 4, hipMemcpyHostToDevice));
   const size_t cbytes = std::max<size_t>(s.const_words.size() * 4, 64);
   HIP_OK(hipMalloc(&d_consts_, cbytes));
   HIP_OK(hipMemset(d_consts_, 0, cbytes));
@@ -321,7 +344,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   constexpr uint32_t kLdsBytes = 160 * 1024;
   lds_path_ = false;
   if (boolean_ && bool_path_ != 1) {
-    const bool fits = ((uint64_t)s.n_slots + 1) * 4 + 64 <= kLdsBytes && s.n_slots < 0xFFFF;
+    const bool fits = ((uint64_t)s.n_slots + 32) * 4 + 64 <= kLdsBytes && s.n_slots + 32 < 0xFFFF;   // + 32 scratch slots
     if (fits) {
       // program in 8-byte entries, every non-sequential launch padded with NOPs to a multiple of 1024
       // ops and cut into chunks of <= kLdsRows rows (device/bool_kernels.hpp)
@@ -375,7 +398,13 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
               ++n;
             };
             for (uint32_t q = k; q < e; ++q) put6(encode(s.ops[L.first + q]));
-            while (n % zkgpu::kLdsRowOps) put6(pad);
+            // padding ops write 32 scratch slots, one per bank and lane group (the op at position n runs on lane
+            // (n / 2) % 64): 32 lanes storing to ONE address would serialise in the LDS
+            while (n % zkgpu::kLdsRowOps) {
+              zkgpu::LdsOp q = pad;
+              q.dst = (unsigned short)(scratch + (n / 2) % 32);
+              put6(q);
+            }
             rows = (uint32_t)(n / zkgpu::kLdsRowOps);
           } else {
             if (lo.size() & 1) lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});  // 16-B aligned rows
@@ -618,9 +647,11 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.lane_flags = (zkgpu::u32*)d_flags_;
     if (L.sequential) {
+      // a strand: one workgroup per lane block walks the levels of the run, barrier between levels
       a.xcd_chunks = 0;
       a.op_stride = 1;
-      launch_fused(nwords_, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, grid, 0, st, a, fp);
+      launch_strand(nwords_, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, dim3(lbs), st, a,
+                    (const uint32_t*)d_level_ptr_ + L.level_ptr, L.level_end - L.level_begin, fp);
       return;
     }
     // a level: its Add/Mul entries (scheduled first) run in the instantiation that holds nothing else; the
@@ -792,7 +823,7 @@ void Engine::enqueue_replay(bool time_each_launch) {
     a.ops6 = (const zkgpu::u32*)d_lds_ops6_;
     a.chunks = (const zkgpu::u32*)d_launches_;
     a.n_chunks = n_lds_chunks_;
-    a.n_slots = sched_.n_slots + 1;  // + scratch slot of the padding ops
+    a.n_slots = sched_.n_slots + 32;  // + scratch slots of the padding ops (one per bank)
     a.batch = batch_;
     a.n_cols = (batch_ + 31) / 32;
     a.total_words64 = lane_blocks_ * 64;
@@ -802,7 +833,7 @@ void Engine::enqueue_replay(bool time_each_launch) {
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.table = (zkgpu::u64*)d_table_;
     a.writeback = (lds_writeback_ || force_writeback_) ? 1 : 0;
-    const size_t lds_bytes = (((size_t)sched_.n_slots + 1) * 4 + 15) / 16 * 16;
+    const size_t lds_bytes = (((size_t)sched_.n_slots + 32) * 4 + 15) / 16 * 16;
     zkgpu::launch_bool_lds(a.n_cols, lds_bytes, st, a);
   }
   uint32_t group_blocks = lane_blocks_;

@@ -131,6 +131,7 @@ class Engine {
   size_t window_entry_bytes_ = 0;
   void free_windows();
   void* d_consts_ = nullptr;
+  void* d_level_ptr_ = nullptr;     // level bounds of the strands (Schedule::strand_level_ptr)
   void* d_table_ = nullptr;
   void* d_first_fail_ = nullptr;
   void* d_flags_ = nullptr;

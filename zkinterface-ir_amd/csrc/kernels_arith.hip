@@ -22,6 +22,12 @@ void ZKGPU_FN(launch_replay_fused_w)(int cls, dim3 grid, size_t lds_pad, hipStre
   else replay_fused_kernel<ZKGPU_W, kFusedAll><<<grid, 256, 0, st>>>(a, fp);
 }
 
+void ZKGPU_FN(launch_replay_strand_w)(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const u32* level_ptr, u32 n_levels,
+                                      const FieldParams& fp) {
+  if (cls == kFusedAll) replay_strand_kernel<ZKGPU_W, kFusedAll><<<grid, 256, 0, st>>>(a, level_ptr, n_levels, fp);
+  else replay_strand_kernel<ZKGPU_W, kFusedMisc><<<grid, 256, 0, st>>>(a, level_ptr, n_levels, fp);
+}
+
 // The scheduler always emits ops_per_wave = 1 for a level (measured fastest) and one wave per lane block
 // for sequential segments; neither wants the in-wave operand prefetch variant (PIPE, kept for tools/kbench).
 void ZKGPU_FN(launch_replay_w)(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp) {

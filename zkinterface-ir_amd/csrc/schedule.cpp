@@ -912,7 +912,10 @@ void StreamScheduler::Impl::emit_launches() {
     L.window = n_windows;
     const uint64_t k0 = level_start[l];
     uint64_t k1;
-    if (width >= opt.narrow_width) {
+    // a level too narrow to pay for a launch of its own goes into a sequential launch with its narrow neighbours: a
+    // strand (workgroup per lane block, barrier between levels) in the fused format, one wave per lane block otherwise
+    const uint32_t narrow = s.fused ? std::max(opt.strand_width, opt.narrow_width) : opt.narrow_width;
+    if (width >= narrow) {
       L.count = (uint32_t)width;
       L.ops_per_wave = 1;
       L.level_end = base + l + 1;
@@ -920,8 +923,10 @@ void StreamScheduler::Impl::emit_launches() {
       ++l;
     } else {
       uint32_t e = l;
-      while (e < n_wlevels && level_start[e + 1] - level_start[e] < opt.narrow_width) ++e;
+      while (e < n_wlevels && level_start[e + 1] - level_start[e] < narrow) ++e;
       L.count = (uint32_t)(level_start[e] - level_start[l]);
+      L.level_ptr = (uint32_t)s.strand_level_ptr.size();
+      for (uint32_t q = l; q <= e; ++q) s.strand_level_ptr.push_back((uint32_t)(level_start[q] - level_start[l]));
       L.ops_per_wave = std::max<uint32_t>(L.count, 1);
       L.sequential = true;
       L.level_end = base + e;

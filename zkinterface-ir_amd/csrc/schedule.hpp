@@ -37,6 +37,8 @@ struct Launch {
   uint32_t ops_per_wave = 1;  // count => one wave walks the whole launch in order
   bool sequential = false;    // ops depend on each other: no operand prefetch
   uint32_t level_begin = 0, level_end = 0;
+  uint32_t level_ptr = 0;     // sequential launch of the fused format (a strand): index into Schedule::strand_level_ptr of
+                              // its level_end - level_begin + 1 entry offsets (relative to `first`)
   uint32_t window = 0;        // tape window the launch belongs to (its entries were uploaded with that window)
   uint32_t hot_count = 0;     // a level of the fused program: its first hot_count entries are the Add/Mul ones
   bool has_bitops = false;    // holds and / xor over an odd field (the kernels' cold instantiation)
@@ -45,6 +47,8 @@ struct Launch {
 struct ScheduleOptions {
   bool retain_all = false;          // every value keeps its own slot (wire dumps for parity tests)
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
+  uint32_t strand_width = 17;       // ... with the fused entry format: into strands (one workgroup per lane block walks the
+                                    // levels with a barrier between them, device/replay_kernels.hpp replay_strand_kernel)
   int sort_by_operand = 3;          // order of a level's ops: 0 tape order, 1 by first-operand slot, 2 that + shared-operand walk, 3 the walk alone
   bool fuse = true;                 // absorb single-reader Add/Mul producers into their consumer (never with retain_all)
   bool fermat = true;               // a Switch exponent ladder x^(p-1), p prime, becomes one `x != 0` entry (never with retain_all)
@@ -69,6 +73,7 @@ struct Schedule {
   // input positions whose value must be canonical (an unreduced value would reach copy / assert_zero / not / a bit
   // operation / Evaluator::get): the GF(2) input packing flags a lane only for these (arithmetic entries carry the flag)
   std::vector<uint8_t> strict_instance, strict_witness;
+  std::vector<uint32_t> strand_level_ptr;  // level bounds of the strands (see Launch::level_ptr)
   std::vector<uint64_t> window_first_op;   // per window: index of its first program entry (+ a final end marker)
   uint32_t n_slots = 0;
   uint32_t n_levels = 0;

@@ -346,13 +346,16 @@ class StructuredArith:
 
     Wire ids: a_i = i, b_i = N + i, c_i = 2N + i (witness), o_i = 3N + i, e_i = 4N + i (instance)."""
 
-    def __init__(self, N=1408, seed=0x57C7, p=BN254_R):
-        self.N, self.seed, self.p = N, seed, p
+    def __init__(self, N=1408, seed=0x57C7, p=BN254_R, chained=False):
+        """chained: iteration i takes iteration i-1's result as its first input (acc = step(acc, b_i, c_i)) and only the
+        last result is compared -- the same calls, but a dependency chain N iterations deep instead of N independent ones:
+        the shape that leaves a GPU nothing but the witnesses to run in parallel."""
+        self.N, self.seed, self.p, self.chained = N, seed, p, chained
         self.mod_le = int_to_le(p)
         self.width = 8 * ((p.bit_length() + 63) // 64)
-        self.n_instance = N
-        self.n_witness = 3 * N
-        self.n_out = N
+        self.n_instance = 1 if chained else N
+        self.n_witness = 2 * N + 1 if chained else 3 * N
+        self.n_out = 1 if chained else N
 
     def relation_messages(self):
         from .sieve_writer import write_relation
@@ -371,6 +374,15 @@ class StructuredArith:
                 ('free', 4, None),
             ]),
         ]
+        if self.chained:
+            # b_i = i, c_i = N + i, acc_0 = 2N (witness), acc_{i+1} = 2N + 1 + i, expected = 3N + 1 (instance)
+            gates = [('witness', k) for k in range(2 * N + 1)]
+            gates.append(('for', 'i', 0, N - 1, [(2 * N + 1, 3 * N)],
+                          ('call', step, [('add', ('name', 'i'), ('const', 2 * N + 1))],
+                           [('add', ('name', 'i'), ('const', 2 * N)), ('name', 'i'), ('add', ('name', 'i'), ('const', N))])))
+            gates += [('instance', 3 * N + 1), ('mulc', 3 * N + 2, 3 * N + 1, neg_one), ('add', 3 * N + 3, 3 * N, 3 * N + 2),
+                      ('assert_zero', 3 * N + 3), ('free', 0, 3 * N + 3)]
+            return [write_relation(self.mod_le, '@add,@mul,@mulc,', '@for,@switch,@function,', functions, gates)]
         gates = [('witness', k) for k in range(3 * N)]
         gates.append(('for', 'i', 0, N - 1, [(3 * N, 4 * N - 1)],
                       ('call', step, [('add', ('name', 'i'), ('const', 3 * N))],
@@ -387,6 +399,8 @@ class StructuredArith:
         """(instances [batch][N][width], witnesses [batch][3N][width], lanes made false); the expected values are the
         closed form of `step` in Python integers, off by one on every `corrupt_every`-th lane (global index)."""
         N, p = self.N, self.p
+        if self.chained:
+            return self._chained_inputs(batch, lane_offset, corrupt_every)
         ab = random_field_elements(self.seed + 0x3000 + lane_offset * 2 * N * 4, (batch, 2 * N), p)[..., :self.width]
         idx = (np.arange(batch * N, dtype=np.uint64) + np.uint64(lane_offset * N)).reshape(batch, N)
         with np.errstate(over='ignore'):
@@ -410,6 +424,35 @@ class StructuredArith:
             bad += int(bool(corrupt_every) and (lane + lane_offset) % corrupt_every == 0)
             inst[lane] = np.frombuffer(bytes(out), dtype=np.uint8).reshape(N, self.width)
         return inst, wit, bad
+
+
+def _chained_inputs(self, batch, lane_offset=0, corrupt_every=97):
+    N, p = self.N, self.p
+    vals = random_field_elements(self.seed + 0x5000 + lane_offset * (N + 1) * 4, (batch, N + 1), p)[..., :self.width]
+    idx = (np.arange(batch * N, dtype=np.uint64) + np.uint64(lane_offset * N)).reshape(batch, N)
+    with np.errstate(over='ignore'):
+        c = (splitmix64(np.uint64(self.seed + 99) + idx) & np.uint64(1)).astype(np.uint8)
+    wit = np.zeros((batch, 2 * N + 1, self.width), dtype=np.uint8)
+    wit[:, :N] = vals[:, :N]            # b_i
+    wit[:, N:2 * N, 0] = c              # c_i
+    wit[:, 2 * N] = vals[:, N]          # acc_0
+    inst = np.zeros((batch, 1, self.width), dtype=np.uint8)
+    bad = 0
+    for lane in range(batch):
+        row = vals[lane].reshape(N + 1, self.width).tobytes()
+        v = [int.from_bytes(row[k * self.width:(k + 1) * self.width], 'little') for k in range(N + 1)]
+        acc = v[N]
+        for i in range(N):
+            t = acc * v[i] % p
+            acc = t * v[i] % p if c[lane, i] else (t + acc) % p
+        if corrupt_every and (lane + lane_offset) % corrupt_every == 0:
+            acc = (acc + 1) % p
+            bad += 1
+        inst[lane, 0] = np.frombuffer(acc.to_bytes(self.width, 'little'), dtype=np.uint8)
+    return inst, wit, bad
+
+
+StructuredArith._chained_inputs = _chained_inputs
 
 
 def expected_satisfied(batch, lane_offset=0, corrupt_every=97):
