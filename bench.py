@@ -214,7 +214,7 @@ def cpu_baseline(wl, msgs, inst, wit, gates, ev=None):
             'satisfied_in_sample': int(sum(ok))}
 
 
-def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
+def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda', dist_on=False):
     """BASELINE configs[4]: 2^20-row R1CS over BN254 (3+3+1 terms per row), witness batch 1024 per GPU.
     step = the row check <a,w>*<b,w> = <c,w> of every row for every lane + the count reduction."""
     M = args.width or (1 << 20)
@@ -257,7 +257,7 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     ts = time.perf_counter()
     ms = []
@@ -265,11 +265,11 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
         ff, counts = step()
         ms.append(ev.r1cs_last_ms)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - ts
     total = list(counts)
-    if world > 1:
+    if dist_on:
         t = torch.tensor(total + [0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t)
         total = [int(t[0].item()), int(t[1].item())]
@@ -318,7 +318,7 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda'):
                                    'sample': '%d witnesses of the same %d-row system, 4x64 Montgomery row check on %d '
                                              'threads, %.1f s wall (witness generation excluded)' % (sample, n_rows, threads, secs)}
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -393,7 +393,10 @@ def main():
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     red_dev = 'cuda' if backend == 'nccl' else 'cpu'
-    if world > 1:
+    # ZKI_FORCE_DIST=1 with one rank: the process group, the view of the engine's device counters and the all-reduce run
+    # exactly as they do with N ranks (the GPU tier uses it to exercise the RCCL path on a one-GPU box)
+    dist_on = world > 1 or os.environ.get('ZKI_FORCE_DIST') == '1'
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
@@ -405,7 +408,7 @@ def main():
     from zkinterface_ir_amd import workloads
 
     if args.workload == 'c5':
-        return bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev)
+        return bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev, dist_on)
     if args.workload == 'c2':
         mp = os.environ.get('ZKI_C2_MUL_PERCENT')  # developer sensitivity runs only; the metric is quoted on the default mix
         wl = workloads.ArithLayered(W=args.width or 4096, D=args.depth or 256, mul_percent=int(mp) if mp else None)
@@ -437,13 +440,13 @@ def main():
     lds = args.workload == 'c4' and ev.uses_lds_path()
     wide_launches = 1 if lds else info['launches'] - info['sequential_launches']
 
-    counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if world > 1 else None
-    reduced = torch.zeros(2, dtype=torch.int64, device=red_dev) if world > 1 else None
+    counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if dist_on else None
+    reduced = torch.zeros(2, dtype=torch.int64, device=red_dev) if dist_on else None
 
     def step():
         ev.replay()
         ev.synchronize()                # verdict words and counts are final on the engine's stream
-        if world > 1:
+        if dist_on:
             reduced.copy_(counts_t)     # 16 bytes out of the engine's counter words
             dist.all_reduce(reduced)    # RCCL over xGMI: {satisfied, failed}
             # the collective runs on RCCL's stream: finish it before the next replay resets the counters
@@ -453,7 +456,7 @@ def main():
         step()
     ev.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     ev_ms = []
@@ -462,11 +465,11 @@ def main():
         ev_ms.append(ev.last_replay_ms)
     ev.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    if world > 1:
+    if dist_on:
         total = reduced.cpu().tolist()
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -608,7 +611,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates, ev)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -56,3 +56,24 @@ def test_a_failing_rank_fails_the_launcher():
                           '--batch-per-gpu', '64', '--width', '64', '--depth', '3', '--no-cpu-baseline'], env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
+
+
+@pytest.mark.gpu
+def test_rccl_path_with_one_rank():
+    """what the 8-GPU run does per step -- process group over RCCL, a torch view of the engine's device counters, the
+    all-reduce, the max-over-ranks timing -- with a world of one rank, so that the code path the driver launches on a
+    multi-GPU node has at least run against the real RCCL on this box (ZKI_FORCE_DIST=1)"""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               ZKI_FORCE_DIST='1')
+    env.pop('ZKI_DIST_BACKEND', None)
+    for extra in ([], ['--workload', 'c5', '--width', '2048'], ['--workload', 'c4', '--width', '2048', '--depth', '4']):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                              '--batch-per-gpu', '128', '--no-cpu-baseline', '--no-hbm-variant', '--no-first-verdict']
+                             + (extra or ['--width', '256', '--depth', '6']), env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+        assert r['n_gpus'] == 1 and r['config']['satisfied'] == workloads.expected_satisfied(128) == 126
