@@ -850,13 +850,27 @@ def test_inputs_handed_over_while_the_previous_batch_replays():
     ev.replay()
     ev.synchronize()
     assert ev.counts() == (batch - n_bad, n_bad)
-    # page-locked caller memory is read by the DMA engine directly (no staging copy): same answers
-    import torch
-    pin_i = torch.from_numpy(np.ascontiguousarray(inst).reshape(-1)).pin_memory()
-    pin_bad = torch.from_numpy(np.ascontiguousarray(bad_w).reshape(-1)).pin_memory()
-    pin_good = torch.from_numpy(np.ascontiguousarray(good[1]).reshape(-1)).pin_memory()
-    for pin_w, want in ((pin_bad, (0, batch)), (pin_good, (batch - n_bad, n_bad)), (pin_bad, (0, batch))):
-        ev.set_inputs(pin_i.data_ptr(), pin_w.data_ptr(), batch)
-        ev.replay()
+    # page-locked caller memory is read by the DMA engine directly (no staging copy): same answers.  The buffers come
+    # from the HIP runtime the library itself links (a torch pin_memory() here would bring up torch's own bundled
+    # runtime after the library's, which a fresh box does not always survive)
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+
+    def pinned(arr):
+        arr = np.ascontiguousarray(arr).reshape(-1)
+        p = ctypes.c_void_p()
+        assert hip.hipHostMalloc(ctypes.byref(p), ctypes.c_size_t(arr.nbytes), ctypes.c_uint(0)) == 0
+        ctypes.memmove(p, arr.ctypes.data, arr.nbytes)
+        return p
+
+    pin_i, pin_bad, pin_good = pinned(inst), pinned(bad_w), pinned(good[1])
+    try:
+        for pin_w, want in ((pin_bad, (0, batch)), (pin_good, (batch - n_bad, n_bad)), (pin_bad, (0, batch))):
+            ev.set_inputs(pin_i.value, pin_w.value, batch)
+            ev.replay()
+            ev.synchronize()
+            assert ev.counts() == want
+    finally:
         ev.synchronize()
-        assert ev.counts() == want
+        for p in (pin_i, pin_bad, pin_good):
+            hip.hipHostFree(p)

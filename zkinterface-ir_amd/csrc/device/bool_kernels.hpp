@@ -165,6 +165,10 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
 // stream, which every workgroup reads in full, is what bounds this kernel once the LDS accesses are conflict-free.
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));  // native vector: usable as an asm operand
 
+#ifndef ZKGPU_LDS_DIAG_BITS
+#define ZKGPU_LDS_DIAG_BITS 0  // 1 no level barriers, 2 no LDS writes, 4 no LDS reads, 8 no program fetch: wrong results
+#endif
+
 // LDS byte address of the slot in the low / high half of a program word: (half << 2) in ONE instruction -- SDWA
 // selects the 16-bit half as the shifted operand (hipcc emits v_and / v_bfe + v_lshl_add: two per field, twelve per
 // pair of ops, most of this kernel's VALU work).  The wire table starts at LDS address 0 (the kernel has no static LDS).
@@ -182,13 +186,18 @@ typedef u32 __attribute__((address_space(3))) lds_u32;
 __device__ __forceinline__ u32 lds_get(u32 byte_addr) { return *(lds_u32*)(uintptr_t)byte_addr; }
 __device__ __forceinline__ void lds_put(u32 byte_addr, u32 v) { *(lds_u32*)(uintptr_t)byte_addr = v; }
 
+// dbg: timing diagnostics only (results are wrong with any bit set): 1 no barriers, 2 no LDS writes, 4 no LDS reads
 template <u32 KIND, bool FULL>
-__device__ __forceinline__ void lds_rows(const u32x3 (&raw)[kLdsRows], u32 rows, u32* __restrict__ T) {
+__device__ __forceinline__ void lds_rows(const u32x3 (&raw)[kLdsRows], u32 rows, u32* __restrict__ T, u32 dbg = 0) {
   (void)T;
   u32 x[2 * kLdsRows], y[2 * kLdsRows];
 #pragma unroll
   for (int j = 0; j < kLdsRows; ++j) {
     if (FULL || (u32)j < rows) {
+      if (dbg & 4) {
+        x[2 * j] = raw[j].x; x[2 * j + 1] = raw[j].z; y[2 * j] = raw[j].y; y[2 * j + 1] = raw[j].z;
+        continue;
+      }
       x[2 * j] = lds_get(lds_addr_hi(raw[j].x));
       x[2 * j + 1] = lds_get(lds_addr_lo(raw[j].z));
       if (KIND == OP_XOR || KIND == OP_AND) {
@@ -205,6 +214,10 @@ __device__ __forceinline__ void lds_rows(const u32x3 (&raw)[kLdsRows], u32 rows,
       else if (KIND == OP_AND) { r0 = x[2 * j] & y[2 * j]; r1 = x[2 * j + 1] & y[2 * j + 1]; }
       else if (KIND == OP_NOT) { r0 = ~x[2 * j]; r1 = ~x[2 * j + 1]; }
       else { r0 = x[2 * j]; r1 = x[2 * j + 1]; }
+      if (dbg & 2) {
+        asm volatile("" ::"v"(r0), "v"(r1));
+        continue;
+      }
       lds_put(lds_addr_lo(raw[j].x), r0);
       lds_put(lds_addr_hi(raw[j].y), r1);
     }
@@ -239,20 +252,20 @@ __device__ __forceinline__ void lds_wait_vm(u32x3 (&b)[kLdsRows]) {
 }
 
 __device__ __forceinline__ void lds_simple_chunk(const u32x3 (&buf)[kLdsRows], u32 rows, u32 flags,
-                                                 u32* __restrict__ T) {
+                                                 u32* __restrict__ T, u32 dbg = 0) {
   const u32 kind = flags & 0xFF;
   if (rows == kLdsRows) {
-    if (kind == OP_XOR) lds_rows<OP_XOR, true>(buf, rows, T);
-    else if (kind == OP_AND) lds_rows<OP_AND, true>(buf, rows, T);
-    else if (kind == OP_NOT) lds_rows<OP_NOT, true>(buf, rows, T);
-    else lds_rows<OP_COPY, true>(buf, rows, T);
+    if (kind == OP_XOR) lds_rows<OP_XOR, true>(buf, rows, T, dbg);
+    else if (kind == OP_AND) lds_rows<OP_AND, true>(buf, rows, T, dbg);
+    else if (kind == OP_NOT) lds_rows<OP_NOT, true>(buf, rows, T, dbg);
+    else lds_rows<OP_COPY, true>(buf, rows, T, dbg);
   } else {
-    if (kind == OP_XOR) lds_rows<OP_XOR, false>(buf, rows, T);
-    else if (kind == OP_AND) lds_rows<OP_AND, false>(buf, rows, T);
-    else if (kind == OP_NOT) lds_rows<OP_NOT, false>(buf, rows, T);
-    else lds_rows<OP_COPY, false>(buf, rows, T);
+    if (kind == OP_XOR) lds_rows<OP_XOR, false>(buf, rows, T, dbg);
+    else if (kind == OP_AND) lds_rows<OP_AND, false>(buf, rows, T, dbg);
+    else if (kind == OP_NOT) lds_rows<OP_NOT, false>(buf, rows, T, dbg);
+    else lds_rows<OP_COPY, false>(buf, rows, T, dbg);
   }
-  if ((flags >> 8) & 1) lds_barrier();
+  if (((flags >> 8) & 1) && !(dbg & 1)) lds_barrier();
 }
 
 __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) {
@@ -263,6 +276,8 @@ __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) 
   const u32 valid_mask = lane0 >= args.batch ? 0u
                          : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
   const u32* __restrict__ prog = args.ops6 + 3 * tid;   // this thread's 12-byte record of a row
+  // timing experiments (tools/build_variant.sh + tools/c4_diag.py): a constant, so that the switches cost nothing
+  constexpr u32 dbg = ZKGPU_LDS_DIAG_BITS;
   u32 c = 0;
   while (c < args.n_chunks) {
     c = __builtin_amdgcn_readfirstlane(c);
@@ -280,31 +295,59 @@ __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) 
       ++c;
       continue;
     }
-    // A run of `run` simple chunks (xor / and / not / copy).  The program stream is the only global
-    // traffic and all waves want it at the same moment (levels are barrier-synchronised), so it is
-    // latency-limited: three chunks (3 x 64 KiB per CU) stay in flight.  Fetches are unconditional
-    // (index clamped to the run), the body holds no other vector-memory op, and the barrier does not
-    // drain vmcnt, so the compiler emits counted vmcnt waits.
-    const u32 e = c + run;
+    // A run of `run` simple chunks (xor / and / not / copy).  The program stream is the only global traffic; three
+    // chunks (3 x 48 KiB per CU) stay in flight.  Fetches are unconditional (index clamped to the run), the body holds
+    // no other vector-memory op and the barrier does not drain vmcnt, so the vmcnt waits are counted by hand.
+    const u32 e = c + run, c_start = c;
     u32x3 b0[kLdsRows], b1[kLdsRows], b2[kLdsRows];
-    auto fetch = [&](u32x3 (&buf)[kLdsRows], u32 cc) {
-      const u32* src = prog + 3 * (size_t)lds_sload(args.chunks, 4 * min(cc, e - 1));   // chunk field 0: first thread record
+    // Chunk headers {first record, rows, kind | flags, -} ride in SGPRs three chunks ahead of their use, like the
+    // program words.  Each is read right AFTER a fetch has used its predecessor and right BEFORE a chunk's LDS work:
+    // its latency is covered by the lgkmcnt wait the LDS reads need anyway (scalar loads and LDS share that counter;
+    // read at the point of use, a header cost every wave a scalar-cache round trip twice per chunk: 1.34 -> 1.27 ms).
+    // (Carrying the headers on the vector path instead -- an 8-byte load per chunk, v_readfirstlane -- with every chunk
+    // owning kLdsRows rows of the stream so that fetch addresses need no header was measured slower: 1.49 ms; the
+    // stream grows from 63 to 93 MB and its first touch per XCD is an L2 miss.)
+    struct Hdr {
+      u32 first, rows, flags;
+    };
+    auto header = [&](u32 cc) {
+      typedef const u32 __attribute__((address_space(4))) cu32;
+      cu32* q = (cu32*)(unsigned long long)(args.chunks + 4 * (size_t)__builtin_amdgcn_readfirstlane(min(cc, e - 1)));
+      Hdr h;
+      h.first = q[0];
+      h.rows = q[1];
+      h.flags = q[2];
+      return h;
+    };
+    auto fetch = [&](u32x3 (&buf)[kLdsRows], const Hdr& h) {
+      if ((dbg & 8) && c != c_start) return;
+      const u32* src = prog + 3 * (size_t)h.first;   // chunk field 0: first thread record
 #pragma unroll
       for (int j = 0; j < kLdsRows; ++j) lds_gload12(buf[j], src + j * (3 * 1024));
     };
     // in flight at every wait: the chunk about to run + the two behind it = 12 loads -> vmcnt(8)
-    fetch(b0, c);
-    fetch(b1, c + 1);
+    Hdr h0 = header(c), h1 = header(c + 1), h2 = header(c + 2);
+    fetch(b0, h0);
+    fetch(b1, h1);
     for (; c < e; c += 3) {
-      fetch(b2, c + 2);
+      fetch(b2, h2);
+      __builtin_amdgcn_sched_barrier(0);
+      const Hdr h3 = header(c + 3);
       lds_wait_vm<2 * kLdsRows>(b0);
-      lds_simple_chunk(b0, lds_sload(args.chunks, 4 * c + 1), lds_sload(args.chunks, 4 * c + 2), T);
-      fetch(b0, c + 3);
+      lds_simple_chunk(b0, h0.rows, h0.flags, T, dbg);
+      fetch(b0, h3);
+      __builtin_amdgcn_sched_barrier(0);
+      const Hdr h4 = header(c + 4);
       lds_wait_vm<2 * kLdsRows>(b1);
-      if (c + 1 < e) lds_simple_chunk(b1, lds_sload(args.chunks, 4 * c + 5), lds_sload(args.chunks, 4 * c + 6), T);
-      fetch(b1, c + 4);
+      if (c + 1 < e) lds_simple_chunk(b1, h1.rows, h1.flags, T, dbg);
+      fetch(b1, h4);
+      __builtin_amdgcn_sched_barrier(0);
+      const Hdr h5 = header(c + 5);
       lds_wait_vm<2 * kLdsRows>(b2);
-      if (c + 2 < e) lds_simple_chunk(b2, lds_sload(args.chunks, 4 * c + 9), lds_sload(args.chunks, 4 * c + 10), T);
+      if (c + 2 < e) lds_simple_chunk(b2, h2.rows, h2.flags, T, dbg);
+      h0 = h3;
+      h1 = h4;
+      h2 = h5;
     }
     c = e;
     // drain the clamped over-fetches before their registers can be reused
