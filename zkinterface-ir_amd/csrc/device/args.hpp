@@ -121,17 +121,22 @@ struct LdsOp {  // 8-byte program entry; wide fields are split over the halves t
   unsigned short dst, a, b, kind;
 };
 
-// The program is cut into kind-uniform chunks of at most kLdsRows rows of 2048 ops (the host sorts a
-// level by kind and pads every kind to a multiple of 2048 with ops writing a scratch slot), so the
-// inner loop carries no per-op decode: chunk = {first, rows, kind | barrier_after << 8 | sequential << 9, run}; `first`
-// is an op index into `ops` for a generic chunk and the index of the first 12-byte thread record in `ops6` for a
-// kind-uniform one (a thread fetches its two consecutive ops of a row with one 12-byte load).
-constexpr int kLdsRows = 4;
+// The program of the LDS-resident kernel.  chunk = {first, rows, kind | barrier_after << 8 | sequential << 9 |
+// blocks << 10, run}.  A generic chunk (inputs, constants, asserts, sequential segments) holds 8-byte entries: `first`
+// indexes `ops`.  A chunk with bit 10 set is a run of `run` BLOCKS starting at block `first`: the xor / and / not /
+// copy ops of a level as rows of kLdsRowOps ops of one kind, 12 bytes per thread and row in `ops6`
+// (device/bool_kernels.hpp).  Block header (two u32 in `blocks`):
+//   { rows (1..block_rows) | barrier_after << 4 | kind of row r << (kLdsBlockKindShift + 2 r),  first thread record }
 constexpr int kLdsRowOps = 2048;
+constexpr int kLdsMaxBlockRows = 12;   // block_rows: 4, 6, 8, 9, 10 or 12 (one kernel instantiation each)
+constexpr int kLdsBlockKindShift = 5;
+constexpr u32 kLdsXor = 0, kLdsAnd = 1, kLdsNot = 2, kLdsCopy = 3;   // row kinds in a block header
 
 struct BoolLdsArgs {
   const LdsOp* ops;         // generic chunks (inputs, constants, asserts, sequential segments): 8-byte entries
-  const u32* ops6;          // kind-uniform chunks: 12 bytes per thread and row (two ops of three u16 each)
+  const u32* ops6;          // rows: 12 bytes per thread and row (two ops of three u16 each)
+  const u32* blocks;        // block headers
+  u32 block_rows;           // rows per block of this program = rows every block fetches
   const u32* chunks;
   u32 n_chunks;
   u32 n_slots;              // including the 32 scratch slots of the padding ops
@@ -211,6 +216,7 @@ void launch_pack_inputs(dim3 grid, hipStream_t st, const uint8_t* raw, u32 n_val
                         u64* packed, u32* lane_flags, const uint8_t* strict);
 void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a);
 hipError_t bool_lds_set_max_shared(int bytes);
+bool bool_lds_has_block_rows(u32 rows);
 void launch_bool_lds(u32 n_cols, size_t lds_bytes, hipStream_t st, const BoolLdsArgs& a);
 void launch_bool_dump(dim3 grid, hipStream_t st, const u64* table, u32 n_slots, const u32* slots, u32 n_dump,
                       u32 batch, uint8_t* out);

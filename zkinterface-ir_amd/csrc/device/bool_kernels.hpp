@@ -158,132 +158,154 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
   T[op.dst] = r;
 }
 
-// All ops of a chunk belong to one level, hence are mutually independent: every operand read is
-// issued before the first result is written, so LDS latency is paid once per chunk, not per op.
-// The ops of the kind-uniform chunks are stored without their kind (it is in the chunk header): three u16 per op,
-// two ops = 12 bytes per thread and row -- {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16} -- because the program
-// stream, which every workgroup reads in full, is what bounds this kernel once the LDS accesses are conflict-free.
-typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));  // native vector: usable as an asm operand
+// The xor / and / not / copy ops of a level are stored as ROWS of 2048 ops of one kind (the host sorts a level by kind
+// and pads each kind to whole rows with ops on scratch slots), without their kind: three u16 per op, two ops = 12 bytes
+// per thread and row -- {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}; unary kinds store b = 0.  Consecutive rows of
+// a level form BLOCKS of at most BR rows (args.hpp: block header).
 
-#ifndef ZKGPU_LDS_DIAG_BITS
-#define ZKGPU_LDS_DIAG_BITS 0  // 1 no level barriers, 2 no LDS writes, 4 no LDS reads, 8 no program fetch: wrong results
-#endif
-
-// LDS byte address of the slot in the low / high half of a program word: (half << 2) in ONE instruction -- SDWA
-// selects the 16-bit half as the shifted operand (hipcc emits v_and / v_bfe + v_lshl_add: two per field, twelve per
-// pair of ops, most of this kernel's VALU work).  The wire table starts at LDS address 0 (the kernel has no static LDS).
-__device__ __forceinline__ u32 lds_addr_lo(u32 word) {
-  u32 r;
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "s"(2u), "v"(word));
-  return r;
-}
-__device__ __forceinline__ u32 lds_addr_hi(u32 word) {
-  u32 r;
-  asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "s"(2u), "v"(word));
-  return r;
-}
-typedef u32 __attribute__((address_space(3))) lds_u32;
-__device__ __forceinline__ u32 lds_get(u32 byte_addr) { return *(lds_u32*)(uintptr_t)byte_addr; }
-__device__ __forceinline__ void lds_put(u32 byte_addr, u32 v) { *(lds_u32*)(uintptr_t)byte_addr = v; }
-
-// dbg: timing diagnostics only (results are wrong with any bit set): 1 no barriers, 2 no LDS writes, 4 no LDS reads
-template <u32 KIND, bool FULL>
-__device__ __forceinline__ void lds_rows(const u32x3 (&raw)[kLdsRows], u32 rows, u32* __restrict__ T, u32 dbg = 0) {
-  (void)T;
-  u32 x[2 * kLdsRows], y[2 * kLdsRows];
-#pragma unroll
-  for (int j = 0; j < kLdsRows; ++j) {
-    if (FULL || (u32)j < rows) {
-      if (dbg & 4) {
-        x[2 * j] = raw[j].x; x[2 * j + 1] = raw[j].z; y[2 * j] = raw[j].y; y[2 * j + 1] = raw[j].z;
-        continue;
-      }
-      x[2 * j] = lds_get(lds_addr_hi(raw[j].x));
-      x[2 * j + 1] = lds_get(lds_addr_lo(raw[j].z));
-      if (KIND == OP_XOR || KIND == OP_AND) {
-        y[2 * j] = lds_get(lds_addr_lo(raw[j].y));
-        y[2 * j + 1] = lds_get(lds_addr_hi(raw[j].z));
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < kLdsRows; ++j) {
-    if (FULL || (u32)j < rows) {
-      u32 r0, r1;
-      if (KIND == OP_XOR) { r0 = x[2 * j] ^ y[2 * j]; r1 = x[2 * j + 1] ^ y[2 * j + 1]; }
-      else if (KIND == OP_AND) { r0 = x[2 * j] & y[2 * j]; r1 = x[2 * j + 1] & y[2 * j + 1]; }
-      else if (KIND == OP_NOT) { r0 = ~x[2 * j]; r1 = ~x[2 * j + 1]; }
-      else { r0 = x[2 * j]; r1 = x[2 * j + 1]; }
-      if (dbg & 2) {
-        asm volatile("" ::"v"(r0), "v"(r1));
-        continue;
-      }
-      lds_put(lds_addr_lo(raw[j].x), r0);
-      lds_put(lds_addr_hi(raw[j].y), r1);
-    }
-  }
-}
-
-// wave-uniform table read on the scalar path (s_load): a vector load here would sit in vmcnt and
-// force the program prefetch to drain
+// wave-uniform table read on the scalar path (s_load)
 __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
   typedef const u32 __attribute__((address_space(4))) cu32;
   cu32* q = (cu32*)(unsigned long long)table;
   return q[__builtin_amdgcn_readfirstlane(idx)];
 }
 
-// workgroup barrier for LDS data only: waits for this wave's LDS traffic, not for the global loads of
-// the program prefetch (a plain __syncthreads() would drain them: vmcnt(0))
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+// ---- the block pipeline --------------------------------------------------------------------------------------------
+// All rows of a level are independent, so the operand reads of row r + 2 are issued BEFORE the results of row r are
+// computed and written: the LDS queue of a wave always holds the reads of the next two rows and the writes of the last
+// two, and the waves' address arithmetic and gate instructions run while the LDS pipe works.  (With the reads of a
+// chunk of four rows issued, waited for and only then followed by its writes, all 16 waves of the workgroup sat in the
+// same phase and the LDS pipe idled 60 % of the time: 1.27 ms for C4.)  Every row is exactly 4 reads + 2 writes (a
+// unary row reads slot 0 for its absent operands) and the LDS instructions of a wave complete in order, hence "row r
+// has arrived" is `s_waitcnt lgkmcnt(#LDS instructions issued after its last read)`, a constant per unrolled step.
+// The program words arrive the same way: every block issues the same global loads in the same order -- the header of
+// block k + 3, then after the writes of row r the 12 bytes of row r of block k + 1 into the registers row r just left,
+// for all BR rows (the kernel's template parameter) whatever the blocks hold -- so "row r + 2 of this block has arrived" is always
+// vmcnt(BR - 2): one block of program words in flight.
+//
+// hipcc cannot be told that a register is waiting for a load: it is free to copy it (at a branch join, say) before the
+// data is there.  So everything that is in flight lives in registers the compiler does not own -- the kernel is
+// compiled for kLdsCompilerVgprs registers (amdgpu_num_vgpr) and the registers above are named in the asm text:
+//   v[kRegP + 4 r .. + 2]  program words of row r: {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}
+//   v[kRegV + 4 s .. + 3]  operand values a0, a1, b0, b1 of the row in value set s (row r uses set r mod 3)
+//   v[kRegH .. + 1]        block header in flight
+// No scalar load may be in flight inside a run (they share lgkmcnt with the LDS and return out of order): block headers
+// travel on the vector path.  The slot fields become LDS byte addresses by ONE SDWA shift each (the 16-bit half is the
+// shifted operand; the wire table starts at LDS address 0: the kernel has no static LDS).
+constexpr int kLdsCompilerVgprs = 64;
+constexpr int kRegP = 64, kRegV = kRegP + 4 * kLdsMaxBlockRows, kRegH = kRegV + 12;
+static_assert(kRegH + 2 <= 128, "a 1024-thread workgroup has 128 registers per lane");
 
-// Program-stream loads hidden from hipcc's s_waitcnt bookkeeping (cdna_hip_programming.md 5.7): the
-// compiler would drain vmcnt(0) at every join of the kind/rows branches; here the waits are counted by
-// hand.  The destination registers are only consumed behind lds_wait_vm<N>, which names them "+v".
-__device__ __forceinline__ void lds_gload12(u32x3& dst, const u32* p) {
-  asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+#define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
+#define ZKGPU_SDWA_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
+
+template <int R>   // issue the four operand reads of row R
+__device__ __forceinline__ void ldsp_read() {
+  constexpr int P = kRegP + 4 * R, V = kRegV + 4 * (R % 3);
+  u32 a0, a1, b0, b1;
+  asm volatile("v_lshlrev_b32_sdwa %0, %4, v[%5]" ZKGPU_SDWA_HI
+               "v_lshlrev_b32_sdwa %1, %4, v[%7]" ZKGPU_SDWA_LO
+               "v_lshlrev_b32_sdwa %2, %4, v[%6]" ZKGPU_SDWA_LO
+               "v_lshlrev_b32_sdwa %3, %4, v[%7]" ZKGPU_SDWA_HI
+               "ds_read_b32 v[%8], %0\n\t"
+               "ds_read_b32 v[%9], %1\n\t"
+               "ds_read_b32 v[%10], %2\n\t"
+               "ds_read_b32 v[%11], %3"
+               : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+               : "s"(2u), "n"(P), "n"(P + 1), "n"(P + 2), "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3)
+               : "memory");
 }
 template <int N>
-__device__ __forceinline__ void lds_wait_vm(u32x3 (&b)[kLdsRows]) {
-  static_assert(kLdsRows == 4, "operand list below names 4 rows");
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ void ldsp_wait_lds() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory");
+}
+template <int BR>
+__device__ __forceinline__ void ldsp_wait_row() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - 2) : "memory");
+}
+template <int R>   // the two gates of row R (operands arrived) and their writes
+__device__ __forceinline__ void ldsp_op_write(u32 kind) {
+  constexpr int P = kRegP + 4 * R, V = kRegV + 4 * (R % 3);
+  u32 r0, r1;
+  if (kind == kLdsXor)
+    asm volatile("v_xor_b32 %0, v[%2], v[%4]\n\tv_xor_b32 %1, v[%3], v[%5]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3));
+  else if (kind == kLdsAnd)
+    asm volatile("v_and_b32 %0, v[%2], v[%4]\n\tv_and_b32 %1, v[%3], v[%5]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3));
+  else if (kind == kLdsNot)
+    asm volatile("v_not_b32 %0, v[%2]\n\tv_not_b32 %1, v[%3]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1));
+  else
+    asm volatile("v_mov_b32 %0, v[%2]\n\tv_mov_b32 %1, v[%3]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1));
+  u32 d0, d1;
+  asm volatile("v_lshlrev_b32_sdwa %0, %4, v[%5]" ZKGPU_SDWA_LO
+               "v_lshlrev_b32_sdwa %1, %4, v[%6]" ZKGPU_SDWA_HI
+               "ds_write_b32 %0, %2\n\t"
+               "ds_write_b32 %1, %3"
+               : "=&v"(d0), "=&v"(d1)
+               : "v"(r0), "v"(r1), "s"(2u), "n"(P), "n"(P + 1)
+               : "memory");
+}
+template <int R>   // this thread's 12 bytes of a row -> the registers of row R
+__device__ __forceinline__ void ldsp_gload(const u32* p) {
+  asm volatile("global_load_dwordx3 v[%1:%2], %0, off" : : "v"(p), "n"(kRegP + 4 * R), "n"(kRegP + 4 * R + 2) : "memory");
+}
+__device__ __forceinline__ void ldsp_gload_header(const u32* p) {
+  asm volatile("global_load_dwordx2 v[%1:%2], %0, off" : : "v"(p), "n"(kRegH), "n"(kRegH + 1) : "memory");
 }
 
-__device__ __forceinline__ void lds_simple_chunk(const u32x3 (&buf)[kLdsRows], u32 rows, u32 flags,
-                                                 u32* __restrict__ T, u32 dbg = 0) {
-  const u32 kind = flags & 0xFF;
-  if (rows == kLdsRows) {
-    if (kind == OP_XOR) lds_rows<OP_XOR, true>(buf, rows, T, dbg);
-    else if (kind == OP_AND) lds_rows<OP_AND, true>(buf, rows, T, dbg);
-    else if (kind == OP_NOT) lds_rows<OP_NOT, true>(buf, rows, T, dbg);
-    else lds_rows<OP_COPY, true>(buf, rows, T, dbg);
-  } else {
-    if (kind == OP_XOR) lds_rows<OP_XOR, false>(buf, rows, T, dbg);
-    else if (kind == OP_AND) lds_rows<OP_AND, false>(buf, rows, T, dbg);
-    else if (kind == OP_NOT) lds_rows<OP_NOT, false>(buf, rows, T, dbg);
-    else lds_rows<OP_COPY, false>(buf, rows, T, dbg);
+// One block of N rows, straight-line (one instantiation per N: every wait is a constant).
+template <int BR, int N, int R>
+__device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next) {
+  if constexpr (R < BR) {
+    if constexpr (R < N) {
+      constexpr int w = 2 * (R < 2 ? R : 2);                       // writes of the last two rows, behind the reads
+      constexpr int ahead = N - 1 - R < 2 ? N - 1 - R : 2;         // rows whose reads are behind those of row R
+      if constexpr (R + 2 < N) {
+        ldsp_wait_row<BR>();
+        ldsp_read<R + 2>();
+      }
+      ldsp_wait_lds<4 * ahead + w>();
+      ldsp_op_write<R>((desc >> (kLdsBlockKindShift + 2 * R)) & 3);
+    }
+    ldsp_gload<R>(src_next + R * (3 * 1024));
+    ldsp_rows<BR, N, R + 1>(desc, src_next);
   }
-  if (((flags >> 8) & 1) && !(dbg & 1)) lds_barrier();
+}
+template <int BR, int N>
+__device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 desc, const u32* src_next) {
+  if constexpr (N <= BR) {
+    ldsp_read<0>();
+    if constexpr (N > 1) ldsp_read<1>();
+    ldsp_gload_header(hdr_next3);
+    ldsp_rows<BR, N, 0>(desc, src_next);
+  }
+}
+template <int BR, int R>
+__device__ __forceinline__ void ldsp_gload_all(const u32* src) {
+  if constexpr (R < BR) {
+    ldsp_gload<R>(src + R * (3 * 1024));
+    ldsp_gload_all<BR, R + 1>(src);
+  }
 }
 
-__global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) {
+// BR: rows every block fetches (the host picks the instantiation that fetches least for the program at hand)
+template <int BR>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVgprs))) void bool_lds_kernel(const BoolLdsArgs args) {
+  static_assert(BR >= 3 && BR <= kLdsMaxBlockRows, "block rows");
   extern __shared__ __attribute__((aligned(16))) u32 T[];
+  asm volatile("" ::: "v125");   // the highest hand-managed register: the kernel is allocated 126 (-> 128) registers
   const u32 tid = threadIdx.x;
   const u32 col = blockIdx.x;
   const u32 lane0 = col * 32;
   const u32 valid_mask = lane0 >= args.batch ? 0u
                          : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
   const u32* __restrict__ prog = args.ops6 + 3 * tid;   // this thread's 12-byte record of a row
-  // timing experiments (tools/build_variant.sh + tools/c4_diag.py): a constant, so that the switches cost nothing
-  constexpr u32 dbg = ZKGPU_LDS_DIAG_BITS;
   u32 c = 0;
   while (c < args.n_chunks) {
     c = __builtin_amdgcn_readfirstlane(c);
     const u32 first = lds_sload(args.chunks, 4 * c), rows = lds_sload(args.chunks, 4 * c + 1),
               flags = lds_sload(args.chunks, 4 * c + 2), run = lds_sload(args.chunks, 4 * c + 3);
-    if (run == 0) {
+    ++c;
+    if (!((flags >> 10) & 1)) {
       // generic chunk: inputs, constants, asserts, NOP padding, or a sequential (narrow-level) segment
       if ((flags >> 9) & 1) {
         if (tid == 0)
@@ -292,68 +314,47 @@ __global__ __launch_bounds__(1024) void bool_lds_kernel(const BoolLdsArgs args) 
         for (u32 j = 0; j < 2 * rows; ++j) lds_exec(args.ops[first + j * 1024 + tid], T, args, col, valid_mask);
       }
       if ((flags >> 8) & 1) __syncthreads();
-      ++c;
       continue;
     }
-    // A run of `run` simple chunks (xor / and / not / copy).  The program stream is the only global traffic; three
-    // chunks (3 x 48 KiB per CU) stay in flight.  Fetches are unconditional (index clamped to the run), the body holds
-    // no other vector-memory op and the barrier does not drain vmcnt, so the vmcnt waits are counted by hand.
-    const u32 e = c + run, c_start = c;
-    u32x3 b0[kLdsRows], b1[kLdsRows], b2[kLdsRows];
-    // Chunk headers {first record, rows, kind | flags, -} ride in SGPRs three chunks ahead of their use, like the
-    // program words.  Each is read right AFTER a fetch has used its predecessor and right BEFORE a chunk's LDS work:
-    // its latency is covered by the lgkmcnt wait the LDS reads need anyway (scalar loads and LDS share that counter;
-    // read at the point of use, a header cost every wave a scalar-cache round trip twice per chunk: 1.34 -> 1.27 ms).
-    // (Carrying the headers on the vector path instead -- an 8-byte load per chunk, v_readfirstlane -- with every chunk
-    // owning kLdsRows rows of the stream so that fetch addresses need no header was measured slower: 1.49 ms; the
-    // stream grows from 63 to 93 MB and its first touch per XCD is an L2 miss.)
-    struct Hdr {
-      u32 first, rows, flags;
-    };
-    auto header = [&](u32 cc) {
-      typedef const u32 __attribute__((address_space(4))) cu32;
-      cu32* q = (cu32*)(unsigned long long)(args.chunks + 4 * (size_t)__builtin_amdgcn_readfirstlane(min(cc, e - 1)));
-      Hdr h;
-      h.first = q[0];
-      h.rows = q[1];
-      h.flags = q[2];
-      return h;
-    };
-    auto fetch = [&](u32x3 (&buf)[kLdsRows], const Hdr& h) {
-      if ((dbg & 8) && c != c_start) return;
-      const u32* src = prog + 3 * (size_t)h.first;   // chunk field 0: first thread record
-#pragma unroll
-      for (int j = 0; j < kLdsRows; ++j) lds_gload12(buf[j], src + j * (3 * 1024));
-    };
-    // in flight at every wait: the chunk about to run + the two behind it = 12 loads -> vmcnt(8)
-    Hdr h0 = header(c), h1 = header(c + 1), h2 = header(c + 2);
-    fetch(b0, h0);
-    fetch(b1, h1);
-    for (; c < e; c += 3) {
-      fetch(b2, h2);
-      __builtin_amdgcn_sched_barrier(0);
-      const Hdr h3 = header(c + 3);
-      lds_wait_vm<2 * kLdsRows>(b0);
-      lds_simple_chunk(b0, h0.rows, h0.flags, T, dbg);
-      fetch(b0, h3);
-      __builtin_amdgcn_sched_barrier(0);
-      const Hdr h4 = header(c + 4);
-      lds_wait_vm<2 * kLdsRows>(b1);
-      if (c + 1 < e) lds_simple_chunk(b1, h1.rows, h1.flags, T, dbg);
-      fetch(b1, h4);
-      __builtin_amdgcn_sched_barrier(0);
-      const Hdr h5 = header(c + 5);
-      lds_wait_vm<2 * kLdsRows>(b2);
-      if (c + 2 < e) lds_simple_chunk(b2, h2.rows, h2.flags, T, dbg);
-      h0 = h3;
-      h1 = h4;
-      h2 = h5;
+    // A run of `run` blocks starting with block `first`.
+    const u32* hdr = args.blocks + 2 * (size_t)first;
+    const u32 last = run - 1;
+    u32 d_cur = lds_sload(hdr, 0), f_cur = lds_sload(hdr, 1);
+    u32 d_nxt = lds_sload(hdr, 2 * min(1u, last)), f_nxt = lds_sload(hdr, 2 * min(1u, last) + 1);
+    ldsp_gload_header(hdr + 2 * min(2u, last));
+    ldsp_gload_all<BR, 0>(prog + 3 * (size_t)f_cur);
+    // the scalar loads above have to be over: none may be in flight below (naming the values orders the loads before)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d_cur), "+s"(f_cur), "+s"(d_nxt), "+s"(f_nxt) : : "memory");
+    for (u32 k = 0; k < run; ++k) {
+      const u32 n = d_cur & 15;
+      // rows 0, 1 and the header of block k + 2 (issued a block ago) have arrived
+      ldsp_wait_row<BR>();
+      u32 d_n2, f_n2;
+      asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
+      const u32* hdr_next3 = hdr + 2 * min(k + 3, last);
+      const u32* src_next = prog + 3 * (size_t)f_nxt;   // past the last block: re-reads it (never used)
+      switch (n) {
+        case 1: ldsp_block<BR, 1>(hdr_next3, d_cur, src_next); break;
+        case 2: ldsp_block<BR, 2>(hdr_next3, d_cur, src_next); break;
+        case 3: ldsp_block<BR, 3>(hdr_next3, d_cur, src_next); break;
+        case 4: ldsp_block<BR, 4>(hdr_next3, d_cur, src_next); break;
+        case 5: ldsp_block<BR, 5>(hdr_next3, d_cur, src_next); break;
+        case 6: ldsp_block<BR, 6>(hdr_next3, d_cur, src_next); break;
+        case 7: ldsp_block<BR, 7>(hdr_next3, d_cur, src_next); break;
+        case 8: ldsp_block<BR, 8>(hdr_next3, d_cur, src_next); break;
+        case 9: ldsp_block<BR, 9>(hdr_next3, d_cur, src_next); break;
+        case 10: ldsp_block<BR, 10>(hdr_next3, d_cur, src_next); break;
+        case 11: ldsp_block<BR, 11>(hdr_next3, d_cur, src_next); break;
+        default: ldsp_block<BR, 12>(hdr_next3, d_cur, src_next); break;
+      }
+      if ((d_cur >> 4) & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
+      d_cur = d_nxt;
+      f_cur = f_nxt;
+      d_nxt = d_n2;
+      f_nxt = f_n2;
     }
-    c = e;
-    // drain the clamped over-fetches before their registers can be reused
-    lds_wait_vm<0>(b0);
-    lds_wait_vm<0>(b1);
-    lds_wait_vm<0>(b2);
+    (void)f_cur;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }
   if (args.writeback) {

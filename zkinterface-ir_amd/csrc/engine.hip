@@ -127,6 +127,7 @@ Engine::~Engine() {
   dfree(d_counts_);
   dfree(d_lds_ops_);
   dfree(d_lds_ops6_);
+  dfree(d_lds_blocks_);
   dfree(d_launches_);
   dfree(d_strict_inst_);
   dfree(d_strict_wit_);
@@ -346,8 +347,8 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   if (boolean_ && bool_path_ != 1) {
     const bool fits = ((uint64_t)s.n_slots + 32) * 4 + 64 <= kLdsBytes && s.n_slots + 32 < 0xFFFF;   // + 32 scratch slots
     if (fits) {
-      // program in 8-byte entries, every non-sequential launch padded with NOPs to a multiple of 1024
-      // ops and cut into chunks of <= kLdsRows rows (device/bool_kernels.hpp)
+      // program of the LDS kernel (device/args.hpp): generic chunks of 8-byte entries, and for the xor / and / not /
+      // copy ops of a level rows of 2048 ops of one kind, gathered into blocks of <= block_rows rows
       auto encode = [](const DevOp& d) {
         zkgpu::LdsOp o;
         o.kind = (unsigned short)d.kind;
@@ -365,11 +366,78 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
         }
         return o;
       };
+      auto row_kind = [](uint32_t kind) -> int {
+        switch (kind) {
+          case zkgpu::OP_XOR: return (int)zkgpu::kLdsXor;
+          case zkgpu::OP_AND: return (int)zkgpu::kLdsAnd;
+          case zkgpu::OP_NOT: return (int)zkgpu::kLdsNot;
+          case zkgpu::OP_COPY: return (int)zkgpu::kLdsCopy;
+          default: return -1;
+        }
+      };
       std::vector<zkgpu::LdsOp> lo;
-      std::vector<unsigned short> lo6;   // the kind-uniform chunks: u16 {dst, a, b} per op
-      std::vector<uint32_t> ln;
-      lo.reserve(s.ops.size() + 4096 * s.launches.size());
-      const unsigned short scratch = (unsigned short)s.n_slots;  // extra slot: target of the padding ops
+      std::vector<unsigned short> lo6;   // rows: u16 {dst, a, b} per op
+      std::vector<uint32_t> blocks;      // block headers {descriptor, first thread record}
+      std::vector<uint32_t> ln;          // chunks
+      lo.reserve(s.ops.size() / 8 + 4096);
+      lo6.reserve(s.ops.size() * 3 + 3 * 4096 * s.launches.size());
+      const unsigned short scratch = (unsigned short)s.n_slots;  // extra slots: targets of the padding ops
+      // Rows per block: every block fetches that many rows of the stream whatever it holds (the kernel counts its
+      // loads), and the fetch is what bounds the kernel -- pick the size that fetches least for this program (C4: a
+      // level is 9 rows; 12-row blocks would fetch a third more).  A block costs about a row of time by itself.
+      uint32_t block_rows = zkgpu::kLdsMaxBlockRows;
+      {
+        std::vector<uint32_t> level_rows;   // rows of every maximal sequence of xor / and / not / copy rows
+        for (const Launch& L : s.launches) {
+          if (L.sequential) continue;
+          uint32_t k = 0, open = 0;
+          while (k < L.count) {
+            const uint32_t kind = s.ops[L.first + k].kind;
+            uint32_t e = k;
+            while (e < L.count && s.ops[L.first + e].kind == kind) ++e;
+            if (row_kind(kind) >= 0) {
+              open += (e - k + zkgpu::kLdsRowOps - 1) / zkgpu::kLdsRowOps;
+            } else if (open) {
+              level_rows.push_back(open);
+              open = 0;
+            }
+            k = e;
+          }
+          if (open) level_rows.push_back(open);
+        }
+        uint64_t best = ~0ull;
+        for (uint32_t br = 3; br <= (uint32_t)zkgpu::kLdsMaxBlockRows; ++br) {
+          if (!zkgpu::bool_lds_has_block_rows(br)) continue;
+          uint64_t cost = 0;
+          for (uint32_t n : level_rows) cost += (uint64_t)((n + br - 1) / br) * (br + 1);
+          if (cost < best) {
+            best = cost;
+            block_rows = br;
+          }
+        }
+      }
+      if (const char* br = getenv("ZKGPU_LDS_BLOCK_ROWS"))   // tuning experiments (tools/c4_diag.py)
+        if (zkgpu::bool_lds_has_block_rows((uint32_t)atoi(br))) block_rows = (uint32_t)atoi(br);
+      lds_block_rows_ = block_rows;
+      std::vector<uint32_t> open_kinds;
+      uint32_t open_first = 0;
+      auto close_blocks = [&](bool barrier) {
+        for (size_t r = 0; r < open_kinds.size(); r += block_rows) {
+          const size_t n = std::min<size_t>(block_rows, open_kinds.size() - r);
+          uint32_t desc = (uint32_t)n;
+          for (size_t j = 0; j < n; ++j) desc |= open_kinds[r + j] << (zkgpu::kLdsBlockKindShift + 2 * j);
+          if (barrier && r + n >= open_kinds.size()) desc |= 1u << 4;
+          const uint32_t id = (uint32_t)(blocks.size() / 2);
+          blocks.push_back(desc);
+          blocks.push_back(open_first + (uint32_t)r * 1024u);
+          // consecutive blocks form one run (one chunk)
+          if (ln.size() >= 4 && ((ln[ln.size() - 2] >> 10) & 1) && ln[ln.size() - 4] + ln[ln.size() - 1] == id)
+            ++ln[ln.size() - 1];
+          else
+            ln.insert(ln.end(), {id, 0u, 1u << 10, 1u});
+        }
+        open_kinds.clear();
+      };
       for (const Launch& L : s.launches) {
         if (L.sequential) {
           const uint32_t first = (uint32_t)lo.size();
@@ -377,75 +445,52 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
           ln.insert(ln.end(), {first, L.count, (1u << 9) | (1u << 8), 0u});
           continue;
         }
-        // ops of a level arrive sorted by kind (schedule.cpp): one padded run per kind
+        // ops of a level arrive sorted by kind (schedule.cpp): whole rows per kind
         uint32_t k = 0;
         while (k < L.count) {
           const uint32_t kind = s.ops[L.first + k].kind;
           uint32_t e = k;
           while (e < L.count && s.ops[L.first + e].kind == kind) ++e;
-          const bool simple = kind == zkgpu::OP_XOR || kind == zkgpu::OP_AND || kind == zkgpu::OP_NOT || kind == zkgpu::OP_COPY;
-          // padding: simple kinds re-do a harmless op into the scratch slot; others are NOPs
-          const zkgpu::LdsOp pad{scratch, 0, 0, (unsigned short)(simple ? kind : (uint32_t)zkgpu::OP_NOP)};
-          uint32_t first, rows;
-          if (simple) {
-            // three u16 per op (the kind is the chunk's): {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16} per two ops
-            first = (uint32_t)(lo6.size() / 6);   // in 12-byte thread records
+          const bool last_kind = e >= L.count;
+          const int rk = row_kind(kind);
+          if (rk >= 0) {
+            if (open_kinds.empty()) open_first = (uint32_t)(lo6.size() / 6);   // in 12-byte thread records
             size_t n = 0;
-            auto put6 = [&](const zkgpu::LdsOp& o) {
-              lo6.push_back(o.dst);
-              lo6.push_back(o.a);
-              lo6.push_back(o.b);
+            auto put6 = [&](unsigned short dst, unsigned short a, unsigned short b) {
+              lo6.push_back(dst);
+              lo6.push_back(a);
+              // a unary row still issues its four LDS reads (the kernel counts them): slot 0 for the absent operand
+              lo6.push_back(rk == (int)zkgpu::kLdsXor || rk == (int)zkgpu::kLdsAnd ? b : (unsigned short)0);
               ++n;
             };
-            for (uint32_t q = k; q < e; ++q) put6(encode(s.ops[L.first + q]));
-            // padding ops write 32 scratch slots, one per bank and lane group (the op at position n runs on lane
-            // (n / 2) % 64): 32 lanes storing to ONE address would serialise in the LDS
-            while (n % zkgpu::kLdsRowOps) {
-              zkgpu::LdsOp q = pad;
-              q.dst = (unsigned short)(scratch + (n / 2) % 32);
-              put6(q);
+            for (uint32_t q = k; q < e; ++q) {
+              const zkgpu::LdsOp o = encode(s.ops[L.first + q]);
+              put6(o.dst, o.a, o.b);
             }
-            rows = (uint32_t)(n / zkgpu::kLdsRowOps);
+            // padding ops re-do a harmless op into 32 scratch slots, one per bank and lane group (the op at position
+            // n runs on lane (n / 2) % 64): 32 lanes storing to ONE address would serialise in the LDS
+            while (n % zkgpu::kLdsRowOps) put6((unsigned short)(scratch + (n / 2) % 32), 0, 0);
+            for (size_t r = 0; r < n / zkgpu::kLdsRowOps; ++r) open_kinds.push_back((uint32_t)rk);
+            if (last_kind) close_blocks(true);
           } else {
-            if (lo.size() & 1) lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});  // 16-B aligned rows
-            first = (uint32_t)lo.size();
+            close_blocks(false);   // rows so far run before this kind's chunk (same level: no barrier needed)
+            const zkgpu::LdsOp pad{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP};
+            if (lo.size() & 1) lo.push_back(pad);  // 16-B aligned rows
+            const uint32_t first = (uint32_t)lo.size();
             for (uint32_t q = k; q < e; ++q) lo.push_back(encode(s.ops[L.first + q]));
             while ((lo.size() - first) % zkgpu::kLdsRowOps) lo.push_back(pad);
-            rows = ((uint32_t)lo.size() - first) / zkgpu::kLdsRowOps;
-          }
-          const bool last_kind = e >= L.count;
-          for (uint32_t r = 0; r < rows; r += zkgpu::kLdsRows) {
-            const uint32_t n = std::min<uint32_t>(zkgpu::kLdsRows, rows - r);
-            const uint32_t barrier = (last_kind && r + n >= rows) ? 1u : 0u;
-            // a row is kLdsRowOps ops = 1024 thread records of a kind-uniform chunk
-            ln.insert(ln.end(), {first + r * (simple ? 1024u : (uint32_t)zkgpu::kLdsRowOps), n, kind | (barrier << 8), 0u});
+            const uint32_t rows = ((uint32_t)lo.size() - first) / zkgpu::kLdsRowOps;
+            ln.insert(ln.end(), {first, rows, kind | ((last_kind ? 1u : 0u) << 8), 0u});
           }
           k = e;
         }
       }
-      // chunk field 3: for the first chunk of a run of simple chunks, the run length; 0 = generic chunk
-      {
-        const size_t nc = ln.size() / 4;
-        auto is_simple = [&](size_t c) {
-          const uint32_t f = ln[4 * c + 2], kind = f & 0xFF;
-          return !((f >> 9) & 1) && (kind == zkgpu::OP_XOR || kind == zkgpu::OP_AND || kind == zkgpu::OP_NOT ||
-                                     kind == zkgpu::OP_COPY);
-        };
-        for (size_t c = 0; c < nc;) {
-          if (!is_simple(c)) { ln[4 * c + 3] = 0; ++c; continue; }
-          size_t e = c;
-          while (e < nc && is_simple(e)) ++e;
-          ln[4 * c + 3] = (uint32_t)(e - c);
-          for (size_t q = c + 1; q < e; ++q) ln[4 * q + 3] = 0;
-          c = e;
-        }
-        // rows past a short chunk are fetched (and ignored): keep them inside the allocation
-        for (int k = 0; k < zkgpu::kLdsRows * zkgpu::kLdsRowOps; ++k) {
-          lo.push_back(zkgpu::LdsOp{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP});
-          lo6.insert(lo6.end(), {scratch, 0, 0});
-        }
-        n_lds_chunks_ = (uint32_t)nc;
-      }
+      n_lds_chunks_ = (uint32_t)(ln.size() / 4);
+      // every block fetches block_rows rows whatever it holds: keep the rows past the last one inside the allocation
+      lo6.insert(lo6.end(), (size_t)block_rows * zkgpu::kLdsRowOps * 3, scratch);
+      dfree(d_lds_blocks_);
+      HIP_OK(hipMalloc(&d_lds_blocks_, std::max<size_t>(blocks.size() * 4, 64)));
+      if (!blocks.empty()) HIP_OK(hipMemcpy(d_lds_blocks_, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice));
       HIP_OK(hipMalloc(&d_lds_ops_, std::max<size_t>(lo.size() * sizeof(zkgpu::LdsOp), 64)));
       if (!lo.empty()) HIP_OK(hipMemcpy(d_lds_ops_, lo.data(), lo.size() * sizeof(zkgpu::LdsOp), hipMemcpyHostToDevice));
       dfree(d_lds_ops6_);
@@ -821,6 +866,8 @@ void Engine::enqueue_replay(bool time_each_launch) {
     memset(&a, 0, sizeof a);
     a.ops = (const zkgpu::LdsOp*)d_lds_ops_;
     a.ops6 = (const zkgpu::u32*)d_lds_ops6_;
+    a.blocks = (const zkgpu::u32*)d_lds_blocks_;
+    a.block_rows = lds_block_rows_;
     a.chunks = (const zkgpu::u32*)d_launches_;
     a.n_chunks = n_lds_chunks_;
     a.n_slots = sched_.n_slots + 32;  // + scratch slots of the padding ops (one per bank)

@@ -167,7 +167,9 @@ class Engine {
   uint32_t extra_slots_ = 0, table_slots_ = 0;
   float last_r1cs_ms_ = 0.f;
   void* d_lds_ops_ = nullptr;       // 8-byte program entries of the LDS-resident GF(2) kernel (generic chunks)
-  void* d_lds_ops6_ = nullptr;      // its kind-uniform chunks: 6 bytes per op
+  void* d_lds_ops6_ = nullptr;      // its rows of xor / and / not / copy ops: 6 bytes per op
+  void* d_lds_blocks_ = nullptr;    // block headers of those rows
+  uint32_t lds_block_rows_ = 0;     // rows per block (selects the kernel instantiation)
   void* d_launches_ = nullptr;
   uint32_t n_lds_chunks_ = 0;
   int bool_path_ = 0;

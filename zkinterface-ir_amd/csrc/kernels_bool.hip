@@ -17,12 +17,32 @@ void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a) {
   bool_replay_kernel<<<grid, 256, 0, st>>>(a);
 }
 
+#define ZKGPU_LDS_BLOCK_ROWS(X) X(4) X(6) X(8) X(9) X(10) X(12)
+
 hipError_t bool_lds_set_max_shared(int bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&bool_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#define X(BR)                                                                                                          \
+  if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bool_lds_kernel<BR>),                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, bytes))                           \
+    return e;
+  ZKGPU_LDS_BLOCK_ROWS(X)
+#undef X
+  return hipSuccess;
+}
+
+bool bool_lds_has_block_rows(u32 rows) {
+#define X(BR) if (rows == BR) return true;
+  ZKGPU_LDS_BLOCK_ROWS(X)
+#undef X
+  return false;
 }
 
 void launch_bool_lds(u32 n_cols, size_t lds_bytes, hipStream_t st, const BoolLdsArgs& a) {
-  bool_lds_kernel<<<n_cols, 1024, lds_bytes, st>>>(a);
+  switch (a.block_rows) {
+#define X(BR) case BR: bool_lds_kernel<BR><<<n_cols, 1024, lds_bytes, st>>>(a); break;
+    ZKGPU_LDS_BLOCK_ROWS(X)
+#undef X
+    default: break;   // Engine::load_program only picks sizes bool_lds_has_block_rows() accepts
+  }
 }
 
 void launch_bool_dump(dim3 grid, hipStream_t st, const u64* table, u32 n_slots, const u32* slots, u32 n_dump, u32 batch,
