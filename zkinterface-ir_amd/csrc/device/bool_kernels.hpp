@@ -244,9 +244,9 @@ __device__ __forceinline__ void ldsp_op_write(u32 kind) {
                : "v"(r0), "v"(r1), "s"(2u), "n"(P), "n"(P + 1)
                : "memory");
 }
-template <int R>   // this thread's 12 bytes of a row -> the registers of row R
-__device__ __forceinline__ void ldsp_gload(const u32* p) {
-  asm volatile("global_load_dwordx3 v[%1:%2], %0, off" : : "v"(p), "n"(kRegP + 4 * R), "n"(kRegP + 4 * R + 2) : "memory");
+template <int R>   // this thread's 12 bytes of a row -> the registers of row R (row base in SGPRs: no address VALU work)
+__device__ __forceinline__ void ldsp_gload(const u32* row, u32 thread_byte) {
+  asm volatile("global_load_dwordx3 v[%2:%3], %0, %1" : : "v"(thread_byte), "s"(row), "n"(kRegP + 4 * R), "n"(kRegP + 4 * R + 2) : "memory");
 }
 __device__ __forceinline__ void ldsp_gload_header(const u32* p) {
   asm volatile("global_load_dwordx2 v[%1:%2], %0, off" : : "v"(p), "n"(kRegH), "n"(kRegH + 1) : "memory");
@@ -254,7 +254,7 @@ __device__ __forceinline__ void ldsp_gload_header(const u32* p) {
 
 // One block of N rows, straight-line (one instantiation per N: every wait is a constant).
 template <int BR, int N, int R>
-__device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next) {
+__device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next, u32 thread_byte) {
   if constexpr (R < BR) {
     if constexpr (R < N) {
       constexpr int w = 2 * (R < 2 ? R : 2);                       // writes of the last two rows, behind the reads
@@ -266,24 +266,24 @@ __device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next) {
       ldsp_wait_lds<4 * ahead + w>();
       ldsp_op_write<R>((desc >> (kLdsBlockKindShift + 2 * R)) & 3);
     }
-    ldsp_gload<R>(src_next + R * (3 * 1024));
-    ldsp_rows<BR, N, R + 1>(desc, src_next);
+    ldsp_gload<R>(src_next + R * (3 * 1024), thread_byte);
+    ldsp_rows<BR, N, R + 1>(desc, src_next, thread_byte);
   }
 }
 template <int BR, int N>
-__device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 desc, const u32* src_next) {
+__device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 desc, const u32* src_next, u32 thread_byte) {
   if constexpr (N <= BR) {
     ldsp_read<0>();
     if constexpr (N > 1) ldsp_read<1>();
     ldsp_gload_header(hdr_next3);
-    ldsp_rows<BR, N, 0>(desc, src_next);
+    ldsp_rows<BR, N, 0>(desc, src_next, thread_byte);
   }
 }
 template <int BR, int R>
-__device__ __forceinline__ void ldsp_gload_all(const u32* src) {
+__device__ __forceinline__ void ldsp_gload_all(const u32* src, u32 thread_byte) {
   if constexpr (R < BR) {
-    ldsp_gload<R>(src + R * (3 * 1024));
-    ldsp_gload_all<BR, R + 1>(src);
+    ldsp_gload<R>(src + R * (3 * 1024), thread_byte);
+    ldsp_gload_all<BR, R + 1>(src, thread_byte);
   }
 }
 
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
   const u32 lane0 = col * 32;
   const u32 valid_mask = lane0 >= args.batch ? 0u
                          : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
-  const u32* __restrict__ prog = args.ops6 + 3 * tid;   // this thread's 12-byte record of a row
+  const u32 thread_byte = 12 * tid;   // this thread's 12-byte record within a row
   u32 c = 0;
   while (c < args.n_chunks) {
     c = __builtin_amdgcn_readfirstlane(c);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
     u32 d_cur = lds_sload(hdr, 0), f_cur = lds_sload(hdr, 1);
     u32 d_nxt = lds_sload(hdr, 2 * min(1u, last)), f_nxt = lds_sload(hdr, 2 * min(1u, last) + 1);
     ldsp_gload_header(hdr + 2 * min(2u, last));
-    ldsp_gload_all<BR, 0>(prog + 3 * (size_t)f_cur);
+    ldsp_gload_all<BR, 0>(args.ops6 + 3 * (size_t)f_cur, thread_byte);
     // the scalar loads above have to be over: none may be in flight below (naming the values orders the loads before)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d_cur), "+s"(f_cur), "+s"(d_nxt), "+s"(f_nxt) : : "memory");
     for (u32 k = 0; k < run; ++k) {
@@ -332,20 +332,20 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
       u32 d_n2, f_n2;
       asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
       const u32* hdr_next3 = hdr + 2 * min(k + 3, last);
-      const u32* src_next = prog + 3 * (size_t)f_nxt;   // past the last block: re-reads it (never used)
+      const u32* src_next = args.ops6 + 3 * (size_t)f_nxt;   // past the last block: re-reads it (never used)
       switch (n) {
-        case 1: ldsp_block<BR, 1>(hdr_next3, d_cur, src_next); break;
-        case 2: ldsp_block<BR, 2>(hdr_next3, d_cur, src_next); break;
-        case 3: ldsp_block<BR, 3>(hdr_next3, d_cur, src_next); break;
-        case 4: ldsp_block<BR, 4>(hdr_next3, d_cur, src_next); break;
-        case 5: ldsp_block<BR, 5>(hdr_next3, d_cur, src_next); break;
-        case 6: ldsp_block<BR, 6>(hdr_next3, d_cur, src_next); break;
-        case 7: ldsp_block<BR, 7>(hdr_next3, d_cur, src_next); break;
-        case 8: ldsp_block<BR, 8>(hdr_next3, d_cur, src_next); break;
-        case 9: ldsp_block<BR, 9>(hdr_next3, d_cur, src_next); break;
-        case 10: ldsp_block<BR, 10>(hdr_next3, d_cur, src_next); break;
-        case 11: ldsp_block<BR, 11>(hdr_next3, d_cur, src_next); break;
-        default: ldsp_block<BR, 12>(hdr_next3, d_cur, src_next); break;
+        case 1: ldsp_block<BR, 1>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 2: ldsp_block<BR, 2>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 3: ldsp_block<BR, 3>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 4: ldsp_block<BR, 4>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 5: ldsp_block<BR, 5>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 6: ldsp_block<BR, 6>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 7: ldsp_block<BR, 7>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 8: ldsp_block<BR, 8>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 9: ldsp_block<BR, 9>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 10: ldsp_block<BR, 10>(hdr_next3, d_cur, src_next, thread_byte); break;
+        case 11: ldsp_block<BR, 11>(hdr_next3, d_cur, src_next, thread_byte); break;
+        default: ldsp_block<BR, 12>(hdr_next3, d_cur, src_next, thread_byte); break;
       }
       if ((d_cur >> 4) & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
       d_cur = d_nxt;
