@@ -126,11 +126,13 @@ struct LdsOp {  // 8-byte program entry; wide fields are split over the halves t
 // indexes `ops`.  A chunk with bit 10 set is a run of `run` BLOCKS starting at block `first`: the xor / and / not /
 // copy ops of a level as rows of kLdsRowOps ops of one kind, 12 bytes per thread and row in `ops6`
 // (device/bool_kernels.hpp).  Block header (two u32 in `blocks`):
-//   { rows (1..block_rows) | barrier_after << 4 | kind of row r << (kLdsBlockKindShift + 2 r),  first thread record }
+//   { rows (1..block_rows) | barrier_after << 4 | (row r is xor) << (kLdsBlockKindShift + r),  first thread record }
+// Rows know two kinds only, and / xor: `not a` is stored as a xor ONES and a copy as a xor ZERO, two constant slots
+// behind the kLdsScratchSlots scratch slots of the padding ops (the table holds n_slots + kLdsExtraSlots words).
 constexpr int kLdsRowOps = 2048;
 constexpr int kLdsMaxBlockRows = 12;   // block_rows: 4, 6, 8, 9, 10 or 12 (one kernel instantiation each)
 constexpr int kLdsBlockKindShift = 5;
-constexpr u32 kLdsXor = 0, kLdsAnd = 1, kLdsNot = 2, kLdsCopy = 3;   // row kinds in a block header
+constexpr u32 kLdsScratchSlots = 32, kLdsZeroSlot = 32, kLdsOnesSlot = 33, kLdsExtraSlots = 34;   // offsets past the real slots
 
 struct BoolLdsArgs {
   const LdsOp* ops;         // generic chunks (inputs, constants, asserts, sequential segments): 8-byte entries
@@ -139,7 +141,7 @@ struct BoolLdsArgs {
   u32 block_rows;           // rows per block of this program = rows every block fetches
   const u32* chunks;
   u32 n_chunks;
-  u32 n_slots;              // including the 32 scratch slots of the padding ops
+  u32 n_slots;              // including the kLdsExtraSlots scratch / constant slots
   u32 batch;
   u32 n_cols;               // 32-witness slices in the batch
   u32 total_words64;        // 64 * lane blocks (layout of the packed inputs)

@@ -175,8 +175,8 @@ __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
 // computed and written: the LDS queue of a wave always holds the reads of the next two rows and the writes of the last
 // two, and the waves' address arithmetic and gate instructions run while the LDS pipe works.  (With the reads of a
 // chunk of four rows issued, waited for and only then followed by its writes, all 16 waves of the workgroup sat in the
-// same phase and the LDS pipe idled 60 % of the time: 1.27 ms for C4.)  Every row is exactly 4 reads + 2 writes (a
-// unary row reads slot 0 for its absent operands) and the LDS instructions of a wave complete in order, hence "row r
+// same phase and the LDS pipe idled 60 % of the time: 1.27 ms for C4.)  Every row is exactly 4 reads + 2 writes (`not`
+// and copy are xors with a constant slot, args.hpp) and the LDS instructions of a wave complete in order, hence "row r
 // has arrived" is `s_waitcnt lgkmcnt(#LDS instructions issued after its last read)`, a constant per unrolled step.
 // The program words arrive the same way: every block issues the same global loads in the same order -- the header of
 // block k + 3, then after the writes of row r the 12 bytes of row r of block k + 1 into the registers row r just left,
@@ -193,15 +193,20 @@ __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
 // travel on the vector path.  The slot fields become LDS byte addresses by ONE SDWA shift each (the 16-bit half is the
 // shifted operand; the wire table starts at LDS address 0: the kernel has no static LDS).
 constexpr int kLdsCompilerVgprs = 64;
-constexpr int kRegP = 64, kRegV = kRegP + 4 * kLdsMaxBlockRows, kRegH = kRegV + 12;
-static_assert(kRegH + 2 <= 128, "a 1024-thread workgroup has 128 registers per lane");
+#ifndef ZKGPU_LDS_AHEAD
+#define ZKGPU_LDS_AHEAD 2   // rows whose operand reads are in flight behind the row being computed
+#endif
+constexpr int kLdsAhead = ZKGPU_LDS_AHEAD;
+constexpr int kRegP = 64, kRegH = 124;
+template <int BR> constexpr int kRegV = kRegP + 4 * BR;   // value sets follow the BR rows of program words
+template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1) <= kRegH;
 
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
 #define ZKGPU_SDWA_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
 
-template <int R>   // issue the four operand reads of row R
+template <int BR, int R>   // issue the four operand reads of row R
 __device__ __forceinline__ void ldsp_read() {
-  constexpr int P = kRegP + 4 * R, V = kRegV + 4 * (R % 3);
+  constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
   u32 a0, a1, b0, b1;
   asm volatile("v_lshlrev_b32_sdwa %0, %4, v[%5]" ZKGPU_SDWA_HI
                "v_lshlrev_b32_sdwa %1, %4, v[%7]" ZKGPU_SDWA_LO
@@ -221,28 +226,31 @@ __device__ __forceinline__ void ldsp_wait_lds() {
 }
 template <int BR>
 __device__ __forceinline__ void ldsp_wait_row() {
-  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - 2) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - kLdsAhead) : "memory");
 }
-template <int R>   // the two gates of row R (operands arrived) and their writes
-__device__ __forceinline__ void ldsp_op_write(u32 kind) {
-  constexpr int P = kRegP + 4 * R, V = kRegV + 4 * (R % 3);
-  u32 r0, r1;
-  if (kind == kLdsXor)
-    asm volatile("v_xor_b32 %0, v[%2], v[%4]\n\tv_xor_b32 %1, v[%3], v[%5]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3));
-  else if (kind == kLdsAnd)
-    asm volatile("v_and_b32 %0, v[%2], v[%4]\n\tv_and_b32 %1, v[%3], v[%5]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3));
-  else if (kind == kLdsNot)
-    asm volatile("v_not_b32 %0, v[%2]\n\tv_not_b32 %1, v[%3]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1));
-  else
-    asm volatile("v_mov_b32 %0, v[%2]\n\tv_mov_b32 %1, v[%3]" : "=v"(r0), "=v"(r1) : "n"(V), "n"(V + 1));
-  u32 d0, d1;
-  asm volatile("v_lshlrev_b32_sdwa %0, %4, v[%5]" ZKGPU_SDWA_LO
-               "v_lshlrev_b32_sdwa %1, %4, v[%6]" ZKGPU_SDWA_HI
-               "ds_write_b32 %0, %2\n\t"
-               "ds_write_b32 %1, %3"
-               : "=&v"(d0), "=&v"(d1)
-               : "v"(r0), "v"(r1), "s"(2u), "n"(P), "n"(P + 1)
-               : "memory");
+template <int BR, int R>   // the two gates of row R (operands arrived) and their writes
+__device__ __forceinline__ void ldsp_op_write(u32 desc) {
+  constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
+  // and / xor by the row's bit of the block header: two scalar instructions and one taken branch (what hipcc makes of
+  // a C++ if-chain here is a dozen scalar instructions and up to five branches per row -- at one issue slot per wave
+  // every four cycles that, not the LDS, was what bounded the kernel)
+  u32 r0, r1, d0, d1;
+  asm volatile("s_bitcmp1_b32 %4, %5\n\t"
+               "s_cbranch_scc1 1f\n\t"
+               "v_and_b32 %0, v[%6], v[%8]\n\t"
+               "v_and_b32 %1, v[%7], v[%9]\n\t"
+               "s_branch 2f\n"
+               "1:\n\t"
+               "v_xor_b32 %0, v[%6], v[%8]\n\t"
+               "v_xor_b32 %1, v[%7], v[%9]\n"
+               "2:\n\t"
+               "v_lshlrev_b32_sdwa %2, %10, v[%11]" ZKGPU_SDWA_LO
+               "v_lshlrev_b32_sdwa %3, %10, v[%12]" ZKGPU_SDWA_HI
+               "ds_write_b32 %2, %0\n\t"
+               "ds_write_b32 %3, %1"
+               : "=&v"(r0), "=&v"(r1), "=&v"(d0), "=&v"(d1)
+               : "s"(desc), "n"(kLdsBlockKindShift + R), "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3), "s"(2u), "n"(P), "n"(P + 1)
+               : "memory", "scc");
 }
 template <int R>   // this thread's 12 bytes of a row -> the registers of row R (row base in SGPRs: no address VALU work)
 __device__ __forceinline__ void ldsp_gload(const u32* row, u32 thread_byte) {
@@ -257,14 +265,14 @@ template <int BR, int N, int R>
 __device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next, u32 thread_byte) {
   if constexpr (R < BR) {
     if constexpr (R < N) {
-      constexpr int w = 2 * (R < 2 ? R : 2);                       // writes of the last two rows, behind the reads
-      constexpr int ahead = N - 1 - R < 2 ? N - 1 - R : 2;         // rows whose reads are behind those of row R
-      if constexpr (R + 2 < N) {
+      constexpr int w = 2 * (R < kLdsAhead ? R : kLdsAhead);                        // writes behind the reads of row R
+      constexpr int ahead = N - 1 - R < kLdsAhead ? N - 1 - R : kLdsAhead;         // rows whose reads are behind them
+      if constexpr (R + kLdsAhead < N) {
         ldsp_wait_row<BR>();
-        ldsp_read<R + 2>();
+        ldsp_read<BR, R + kLdsAhead>();
       }
-      ldsp_wait_lds<4 * ahead + w>();
-      ldsp_op_write<R>((desc >> (kLdsBlockKindShift + 2 * R)) & 3);
+      ldsp_wait_lds<(4 * ahead + w < 15 ? 4 * ahead + w : 15)>();   // lgkmcnt counts to 15: beyond, wait for a little more
+      ldsp_op_write<BR, R>(desc);
     }
     ldsp_gload<R>(src_next + R * (3 * 1024), thread_byte);
     ldsp_rows<BR, N, R + 1>(desc, src_next, thread_byte);
@@ -273,8 +281,9 @@ __device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next, u32 thr
 template <int BR, int N>
 __device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 desc, const u32* src_next, u32 thread_byte) {
   if constexpr (N <= BR) {
-    ldsp_read<0>();
-    if constexpr (N > 1) ldsp_read<1>();
+    ldsp_read<BR, 0>();
+    if constexpr (N > 1 && kLdsAhead > 1) ldsp_read<BR, 1>();
+    if constexpr (N > 2 && kLdsAhead > 2) ldsp_read<BR, 2>();
     ldsp_gload_header(hdr_next3);
     ldsp_rows<BR, N, 0>(desc, src_next, thread_byte);
   }
@@ -290,7 +299,7 @@ __device__ __forceinline__ void ldsp_gload_all(const u32* src, u32 thread_byte) 
 // BR: rows every block fetches (the host picks the instantiation that fetches least for the program at hand)
 template <int BR>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVgprs))) void bool_lds_kernel(const BoolLdsArgs args) {
-  static_assert(BR >= 3 && BR <= kLdsMaxBlockRows, "block rows");
+  static_assert(BR > kLdsAhead && BR <= kLdsMaxBlockRows && kLdsAhead >= 1 && kLdsAhead <= 3 && kLdsFits<BR>, "block rows");
   extern __shared__ __attribute__((aligned(16))) u32 T[];
   asm volatile("" ::: "v125");   // the highest hand-managed register: the kernel is allocated 126 (-> 128) registers
   const u32 tid = threadIdx.x;
@@ -299,6 +308,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
   const u32 valid_mask = lane0 >= args.batch ? 0u
                          : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
   const u32 thread_byte = 12 * tid;   // this thread's 12-byte record within a row
+  if (tid == 0) {
+    T[args.n_slots - kLdsExtraSlots + kLdsZeroSlot] = 0u;
+    T[args.n_slots - kLdsExtraSlots + kLdsOnesSlot] = ~0u;
+  }
+  __syncthreads();
   u32 c = 0;
   while (c < args.n_chunks) {
     c = __builtin_amdgcn_readfirstlane(c);
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
     // table[lane_block][slot][word64] as u32 halves: col -> (lane block, word64, half)
     const u32 lb = col / 128, w64 = (col % 128) / 2, half = col % 2;
     u32* out = reinterpret_cast<u32*>(args.table);
-    const u32 n_real = args.n_slots - 32;   // without the scratch slots of the padding ops
+    const u32 n_real = args.n_slots - kLdsExtraSlots;   // without the scratch / constant slots
     for (u32 s = tid; s < n_real; s += 1024)
       out[(((size_t)lb * n_real + s) * 64 + w64) * 2 + half] = T[s];
   }

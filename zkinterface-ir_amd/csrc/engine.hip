@@ -345,7 +345,8 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   constexpr uint32_t kLdsBytes = 160 * 1024;
   lds_path_ = false;
   if (boolean_ && bool_path_ != 1) {
-    const bool fits = ((uint64_t)s.n_slots + 32) * 4 + 64 <= kLdsBytes && s.n_slots + 32 < 0xFFFF;   // + 32 scratch slots
+    const bool fits = ((uint64_t)s.n_slots + zkgpu::kLdsExtraSlots) * 4 + 64 <= kLdsBytes &&
+                      s.n_slots + zkgpu::kLdsExtraSlots < 0xFFFF;   // + scratch and constant slots
     if (fits) {
       // program of the LDS kernel (device/args.hpp): generic chunks of 8-byte entries, and for the xor / and / not /
       // copy ops of a level rows of 2048 ops of one kind, gathered into blocks of <= block_rows rows
@@ -366,12 +367,11 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
         }
         return o;
       };
-      auto row_kind = [](uint32_t kind) -> int {
+      // rows know and / xor only: `not a` = a xor ONES, copy = a xor ZERO (constant slots behind the scratch slots)
+      auto row_kind = [](uint32_t kind) -> int {   // 1 xor, 0 and, -1 not a row kind
         switch (kind) {
-          case zkgpu::OP_XOR: return (int)zkgpu::kLdsXor;
-          case zkgpu::OP_AND: return (int)zkgpu::kLdsAnd;
-          case zkgpu::OP_NOT: return (int)zkgpu::kLdsNot;
-          case zkgpu::OP_COPY: return (int)zkgpu::kLdsCopy;
+          case zkgpu::OP_XOR: case zkgpu::OP_NOT: case zkgpu::OP_COPY: return 1;
+          case zkgpu::OP_AND: return 0;
           default: return -1;
         }
       };
@@ -425,7 +425,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
         for (size_t r = 0; r < open_kinds.size(); r += block_rows) {
           const size_t n = std::min<size_t>(block_rows, open_kinds.size() - r);
           uint32_t desc = (uint32_t)n;
-          for (size_t j = 0; j < n; ++j) desc |= open_kinds[r + j] << (zkgpu::kLdsBlockKindShift + 2 * j);
+          for (size_t j = 0; j < n; ++j) desc |= open_kinds[r + j] << (zkgpu::kLdsBlockKindShift + j);
           if (barrier && r + n >= open_kinds.size()) desc |= 1u << 4;
           const uint32_t id = (uint32_t)(blocks.size() / 2);
           blocks.push_back(desc);
@@ -459,17 +459,17 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
             auto put6 = [&](unsigned short dst, unsigned short a, unsigned short b) {
               lo6.push_back(dst);
               lo6.push_back(a);
-              // a unary row still issues its four LDS reads (the kernel counts them): slot 0 for the absent operand
-              lo6.push_back(rk == (int)zkgpu::kLdsXor || rk == (int)zkgpu::kLdsAnd ? b : (unsigned short)0);
+              lo6.push_back(b);
               ++n;
             };
+            const unsigned short zero = (unsigned short)(scratch + zkgpu::kLdsZeroSlot), ones = (unsigned short)(scratch + zkgpu::kLdsOnesSlot);
             for (uint32_t q = k; q < e; ++q) {
               const zkgpu::LdsOp o = encode(s.ops[L.first + q]);
-              put6(o.dst, o.a, o.b);
+              put6(o.dst, o.a, kind == zkgpu::OP_NOT ? ones : kind == zkgpu::OP_COPY ? zero : o.b);
             }
-            // padding ops re-do a harmless op into 32 scratch slots, one per bank and lane group (the op at position
-            // n runs on lane (n / 2) % 64): 32 lanes storing to ONE address would serialise in the LDS
-            while (n % zkgpu::kLdsRowOps) put6((unsigned short)(scratch + (n / 2) % 32), 0, 0);
+            // padding ops write 32 scratch slots, one per bank and lane group (the op at position n runs on lane
+            // (n / 2) % 64): 32 lanes storing to ONE address would serialise in the LDS
+            while (n % zkgpu::kLdsRowOps) put6((unsigned short)(scratch + (n / 2) % zkgpu::kLdsScratchSlots), zero, zero);
             for (size_t r = 0; r < n / zkgpu::kLdsRowOps; ++r) open_kinds.push_back((uint32_t)rk);
             if (last_kind) close_blocks(true);
           } else {
@@ -870,7 +870,7 @@ void Engine::enqueue_replay(bool time_each_launch) {
     a.block_rows = lds_block_rows_;
     a.chunks = (const zkgpu::u32*)d_launches_;
     a.n_chunks = n_lds_chunks_;
-    a.n_slots = sched_.n_slots + 32;  // + scratch slots of the padding ops (one per bank)
+    a.n_slots = sched_.n_slots + zkgpu::kLdsExtraSlots;  // + scratch slots of the padding ops (one per bank), ZERO, ONES
     a.batch = batch_;
     a.n_cols = (batch_ + 31) / 32;
     a.total_words64 = lane_blocks_ * 64;
@@ -880,7 +880,7 @@ void Engine::enqueue_replay(bool time_each_launch) {
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.table = (zkgpu::u64*)d_table_;
     a.writeback = (lds_writeback_ || force_writeback_) ? 1 : 0;
-    const size_t lds_bytes = (((size_t)sched_.n_slots + 32) * 4 + 15) / 16 * 16;
+    const size_t lds_bytes = (((size_t)sched_.n_slots + zkgpu::kLdsExtraSlots) * 4 + 15) / 16 * 16;
     zkgpu::launch_bool_lds(a.n_cols, lds_bytes, st, a);
   }
   uint32_t group_blocks = lane_blocks_;
