@@ -126,7 +126,7 @@ struct LdsOp {  // 8-byte program entry; wide fields are split over the halves t
 // indexes `ops`.  A chunk with bit 10 set is a run of `run` BLOCKS starting at block `first`: the xor / and / not /
 // copy ops of a level as rows of kLdsRowOps ops of one kind, 12 bytes per thread and row in `ops6`
 // (device/bool_kernels.hpp).  Block header (two u32 in `blocks`):
-//   { rows (1..block_rows) | barrier_after << 4 | (row r is xor) << (kLdsBlockKindShift + r),  first thread record }
+//   { rows (1..block_rows) | barrier_after << 4 | (row r is xor) << (kLdsBlockKindShift + r),  byte offset of the block's first row in ops6 }
 // Rows know two kinds only, and / xor: `not a` is stored as a xor ONES and a copy as a xor ZERO, two constant slots
 // behind the kLdsScratchSlots scratch slots of the padding ops (the table holds n_slots + kLdsExtraSlots words).
 constexpr int kLdsRowOps = 2048;

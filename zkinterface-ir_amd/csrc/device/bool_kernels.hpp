@@ -204,7 +204,12 @@ template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1)
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
 #define ZKGPU_SDWA_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
 
-template <int BR, int R>   // issue the four operand reads of row R
+// The kernel is bound by instruction issue (a wave gets one slot every four cycles, and the 16 waves of the workgroup
+// fill every SIMD's slots): a row step is ONE asm statement, so that nothing but what is written here is issued --
+// 8 VALU (six address shifts, two gates), 6 LDS, 1 VMEM, and 3.5 scalar (a vmcnt wait every other row, the lgkmcnt wait,
+// s_bitcmp1 + one taken branch for and / xor).  What hipcc makes of a C++ if-chain over the row kind is a dozen scalar
+// instructions and up to five branches per row; between asm statements it also puts hazard nops and address adds.
+template <int BR, int R>   // issue the four operand reads of row R (block start: rows 0 .. kLdsAhead - 1)
 __device__ __forceinline__ void ldsp_read() {
   constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
   u32 a0, a1, b0, b1;
@@ -220,79 +225,109 @@ __device__ __forceinline__ void ldsp_read() {
                : "s"(2u), "n"(P), "n"(P + 1), "n"(P + 2), "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3)
                : "memory");
 }
-template <int N>
-__device__ __forceinline__ void ldsp_wait_lds() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory");
-}
 template <int BR>
 __device__ __forceinline__ void ldsp_wait_row() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - kLdsAhead) : "memory");
 }
-template <int BR, int R>   // the two gates of row R (operands arrived) and their writes
-__device__ __forceinline__ void ldsp_op_write(u32 desc) {
-  constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
-  // and / xor by the row's bit of the block header: two scalar instructions and one taken branch (what hipcc makes of
-  // a C++ if-chain here is a dozen scalar instructions and up to five branches per row -- at one issue slot per wave
-  // every four cycles that, not the LDS, was what bounded the kernel)
-  u32 r0, r1, d0, d1;
-  asm volatile("s_bitcmp1_b32 %4, %5\n\t"
-               "s_cbranch_scc1 1f\n\t"
-               "v_and_b32 %0, v[%6], v[%8]\n\t"
-               "v_and_b32 %1, v[%7], v[%9]\n\t"
-               "s_branch 2f\n"
-               "1:\n\t"
-               "v_xor_b32 %0, v[%6], v[%8]\n\t"
-               "v_xor_b32 %1, v[%7], v[%9]\n"
-               "2:\n\t"
-               "v_lshlrev_b32_sdwa %2, %10, v[%11]" ZKGPU_SDWA_LO
-               "v_lshlrev_b32_sdwa %3, %10, v[%12]" ZKGPU_SDWA_HI
-               "ds_write_b32 %2, %0\n\t"
-               "ds_write_b32 %3, %1"
-               : "=&v"(r0), "=&v"(r1), "=&v"(d0), "=&v"(d1)
-               : "s"(desc), "n"(kLdsBlockKindShift + R), "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3), "s"(2u), "n"(P), "n"(P + 1)
-               : "memory", "scc");
+// the tail of a step: gates of row R (by its bit of the block header), their writes, and the refill of the row's registers
+#define ZKGPU_LDS_STEP_TAIL                                          \
+  "s_bitcmp1_b32 %[desc], %[bit]\n\t"                                \
+  "s_cbranch_scc1 1f\n\t"                                            \
+  "v_and_b32 %[t2], v[%[v0]], v[%[v2]]\n\t"                          \
+  "v_and_b32 %[t3], v[%[v1]], v[%[v3]]\n\t"                          \
+  "s_branch 2f\n"                                                    \
+  "1:\n\t"                                                           \
+  "v_xor_b32 %[t2], v[%[v0]], v[%[v2]]\n\t"                          \
+  "v_xor_b32 %[t3], v[%[v1]], v[%[v3]]\n"                            \
+  "2:\n\t"                                                           \
+  "ds_write_b32 %[t0], %[t2]\n\t"                                    \
+  "ds_write_b32 %[t1], %[t3]\n\t"                                    \
+  "global_load_dwordx3 v[%[px]:%[pz]], %[voff], %[base]"
+#define ZKGPU_LDS_STEP_DST                                           \
+  "v_lshlrev_b32_sdwa %[t0], %[two], v[%[px]]" ZKGPU_SDWA_LO         \
+  "v_lshlrev_b32_sdwa %[t1], %[two], v[%[py]]" ZKGPU_SDWA_HI
+
+// step R of a block of N rows: [reads of row R + kLdsAhead] -> wait for row R -> gates, writes -> refill
+template <int BR, int N, int R>
+__device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 voff) {
+  constexpr int S = kLdsAhead + 1;
+  constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % S);
+  constexpr int w = 2 * (R < kLdsAhead ? R : kLdsAhead);                        // writes behind the reads of row R
+  constexpr int ahead = N - 1 - R < kLdsAhead ? N - 1 - R : kLdsAhead;         // rows whose reads are behind them
+  constexpr int lg = 4 * ahead + w < 15 ? 4 * ahead + w : 15;                  // lgkmcnt counts to 15: beyond, wait for a little more
+  u32 t0, t1, t2, t3;
+  if constexpr (R + kLdsAhead < N) {
+    constexpr int A = R + kLdsAhead, PA = kRegP + 4 * A, VA = kRegV<BR> + 4 * (A % S);
+    // program words of rows A and A + 1 have arrived: one vmcnt wait per two rows
+    constexpr int vm = BR - kLdsAhead - 1;
+#define ZKGPU_LDS_STEP_AHEAD                                           \
+  "v_lshlrev_b32_sdwa %[t0], %[two], v[%[ax]]" ZKGPU_SDWA_HI           \
+  "v_lshlrev_b32_sdwa %[t1], %[two], v[%[az]]" ZKGPU_SDWA_LO           \
+  "v_lshlrev_b32_sdwa %[t2], %[two], v[%[ay]]" ZKGPU_SDWA_LO           \
+  "v_lshlrev_b32_sdwa %[t3], %[two], v[%[az]]" ZKGPU_SDWA_HI           \
+  "ds_read_b32 v[%[a0]], %[t0]\n\t"                                    \
+  "ds_read_b32 v[%[a1]], %[t1]\n\t"                                    \
+  "ds_read_b32 v[%[a2]], %[t2]\n\t"                                    \
+  "ds_read_b32 v[%[a3]], %[t3]\n\t"                                    \
+  ZKGPU_LDS_STEP_DST                                                   \
+  "s_waitcnt lgkmcnt(%[lg])\n\t"                                       \
+  ZKGPU_LDS_STEP_TAIL
+#define ZKGPU_LDS_STEP_AHEAD_OPERANDS                                                                                      \
+  : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)                                                         \
+  : [two] "s"(2u), [desc] "s"(desc), [voff] "v"(voff), [base] "s"(src_next), [bit] "n"(kLdsBlockKindShift + R),            \
+    [vm] "n"(vm), [lg] "n"(lg), [ax] "n"(PA), [ay] "n"(PA + 1), [az] "n"(PA + 2), [a0] "n"(VA), [a1] "n"(VA + 1),          \
+    [a2] "n"(VA + 2), [a3] "n"(VA + 3), [px] "n"(P), [py] "n"(P + 1), [pz] "n"(P + 2), [v0] "n"(V), [v1] "n"(V + 1),       \
+    [v2] "n"(V + 2), [v3] "n"(V + 3)                                                                                       \
+  : "memory", "scc"
+    if constexpr (R % 2 == 0) asm volatile("s_waitcnt vmcnt(%[vm])\n\t" ZKGPU_LDS_STEP_AHEAD ZKGPU_LDS_STEP_AHEAD_OPERANDS);
+    else asm volatile(ZKGPU_LDS_STEP_AHEAD ZKGPU_LDS_STEP_AHEAD_OPERANDS);
+  } else {
+    asm volatile(ZKGPU_LDS_STEP_DST
+                 "s_waitcnt lgkmcnt(%[lg])\n\t"
+                 ZKGPU_LDS_STEP_TAIL
+                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+                 : [two] "s"(2u), [desc] "s"(desc), [voff] "v"(voff), [base] "s"(src_next), [bit] "n"(kLdsBlockKindShift + R),
+                   [lg] "n"(lg), [px] "n"(P), [py] "n"(P + 1), [pz] "n"(P + 2), [v0] "n"(V), [v1] "n"(V + 1), [v2] "n"(V + 2),
+                   [v3] "n"(V + 3)
+                 : "memory", "scc");
+  }
 }
-template <int R>   // this thread's 12 bytes of a row -> the registers of row R (row base in SGPRs: no address VALU work)
-__device__ __forceinline__ void ldsp_gload(const u32* row, u32 thread_byte) {
-  asm volatile("global_load_dwordx3 v[%2:%3], %0, %1" : : "v"(thread_byte), "s"(row), "n"(kRegP + 4 * R), "n"(kRegP + 4 * R + 2) : "memory");
+template <int R>   // this thread's 12 bytes of a row -> the registers of row R; voff = byte offset of (thread, row R) in a block
+__device__ __forceinline__ void ldsp_gload(const u32* block, u32 voff) {
+  asm volatile("global_load_dwordx3 v[%2:%3], %0, %1" : : "v"(voff), "s"(block), "n"(kRegP + 4 * R), "n"(kRegP + 4 * R + 2) : "memory");
 }
-__device__ __forceinline__ void ldsp_gload_header(const u32* p) {
-  asm volatile("global_load_dwordx2 v[%1:%2], %0, off" : : "v"(p), "n"(kRegH), "n"(kRegH + 1) : "memory");
+__device__ __forceinline__ void ldsp_gload_header(const u32* p, u32 vzero) {   // p is wave-uniform: SGPR base, zero offset
+  const unsigned long long a = (unsigned long long)p;
+  // (the builtin returns int: without the casts the low word would be sign-extended over the high one)
+  p = (const u32*)(((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((u32)(a >> 32)) << 32) |
+                   (unsigned long long)(u32)__builtin_amdgcn_readfirstlane((u32)a));
+  asm volatile("global_load_dwordx2 v[%2:%3], %0, %1" : : "v"(vzero), "s"(p), "n"(kRegH), "n"(kRegH + 1) : "memory");
 }
 
 // One block of N rows, straight-line (one instantiation per N: every wait is a constant).
 template <int BR, int N, int R>
-__device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next, u32 thread_byte) {
+__device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next, const u32 (&voff)[BR]) {
   if constexpr (R < BR) {
-    if constexpr (R < N) {
-      constexpr int w = 2 * (R < kLdsAhead ? R : kLdsAhead);                        // writes behind the reads of row R
-      constexpr int ahead = N - 1 - R < kLdsAhead ? N - 1 - R : kLdsAhead;         // rows whose reads are behind them
-      if constexpr (R + kLdsAhead < N) {
-        ldsp_wait_row<BR>();
-        ldsp_read<BR, R + kLdsAhead>();
-      }
-      ldsp_wait_lds<(4 * ahead + w < 15 ? 4 * ahead + w : 15)>();   // lgkmcnt counts to 15: beyond, wait for a little more
-      ldsp_op_write<BR, R>(desc);
-    }
-    ldsp_gload<R>(src_next + R * (3 * 1024), thread_byte);
-    ldsp_rows<BR, N, R + 1>(desc, src_next, thread_byte);
+    if constexpr (R < N) ldsp_step<BR, N, R>(desc, src_next, voff[R]);
+    else ldsp_gload<R>(src_next, voff[R]);
+    ldsp_rows<BR, N, R + 1>(desc, src_next, voff);
   }
 }
 template <int BR, int N>
-__device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 desc, const u32* src_next, u32 thread_byte) {
+__device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 vzero, u32 desc, const u32* src_next, const u32 (&voff)[BR]) {
   if constexpr (N <= BR) {
     ldsp_read<BR, 0>();
     if constexpr (N > 1 && kLdsAhead > 1) ldsp_read<BR, 1>();
     if constexpr (N > 2 && kLdsAhead > 2) ldsp_read<BR, 2>();
-    ldsp_gload_header(hdr_next3);
-    ldsp_rows<BR, N, 0>(desc, src_next, thread_byte);
+    ldsp_gload_header(hdr_next3, vzero);
+    ldsp_rows<BR, N, 0>(desc, src_next, voff);
   }
 }
 template <int BR, int R>
-__device__ __forceinline__ void ldsp_gload_all(const u32* src, u32 thread_byte) {
+__device__ __forceinline__ void ldsp_gload_all(const u32* src, const u32 (&voff)[BR]) {
   if constexpr (R < BR) {
-    ldsp_gload<R>(src + R * (3 * 1024), thread_byte);
-    ldsp_gload_all<BR, R + 1>(src, thread_byte);
+    ldsp_gload<R>(src, voff[R]);
+    ldsp_gload_all<BR, R + 1>(src, voff);
   }
 }
 
@@ -307,7 +342,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
   const u32 lane0 = col * 32;
   const u32 valid_mask = lane0 >= args.batch ? 0u
                          : (args.batch - lane0 >= 32 ? ~0u : ((1u << (args.batch - lane0)) - 1));
-  const u32 thread_byte = 12 * tid;   // this thread's 12-byte record within a row
+  u32 vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));   // (opaque to hipcc: stays a register, the SGPR-base form of a load needs one)
+  u32 voff[BR];   // byte offset of this thread's 12-byte record of row r within a block of the stream
+#pragma unroll
+  for (int r = 0; r < BR; ++r) voff[r] = 12 * tid + r * (12 * 1024);
   if (tid == 0) {
     T[args.n_slots - kLdsExtraSlots + kLdsZeroSlot] = 0u;
     T[args.n_slots - kLdsExtraSlots + kLdsOnesSlot] = ~0u;
@@ -330,36 +369,42 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
       if ((flags >> 8) & 1) __syncthreads();
       continue;
     }
-    // A run of `run` blocks starting with block `first`.
+    // A run of `run` blocks starting with block `first`.  Header = {descriptor, BYTE offset of the block in ops6}.
     const u32* hdr = args.blocks + 2 * (size_t)first;
-    const u32 last = run - 1;
+    const u32 last = __builtin_amdgcn_readfirstlane(run - 1);
     u32 d_cur = lds_sload(hdr, 0), f_cur = lds_sload(hdr, 1);
     u32 d_nxt = lds_sload(hdr, 2 * min(1u, last)), f_nxt = lds_sload(hdr, 2 * min(1u, last) + 1);
-    ldsp_gload_header(hdr + 2 * min(2u, last));
-    ldsp_gload_all<BR, 0>(args.ops6 + 3 * (size_t)f_cur, thread_byte);
+    const char* stream = reinterpret_cast<const char*>(args.ops6);
+    ldsp_gload_header(hdr + 2 * min(2u, last), vzero);
+    ldsp_gload_all<BR, 0>(reinterpret_cast<const u32*>(stream + f_cur), voff);
     // the scalar loads above have to be over: none may be in flight below (naming the values orders the loads before)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d_cur), "+s"(f_cur), "+s"(d_nxt), "+s"(f_nxt) : : "memory");
     for (u32 k = 0; k < run; ++k) {
       const u32 n = d_cur & 15;
-      // rows 0, 1 and the header of block k + 2 (issued a block ago) have arrived
+      // rows 0 .. kLdsAhead - 1 and the header of block k + 2 (issued a block ago) have arrived
       ldsp_wait_row<BR>();
       u32 d_n2, f_n2;
       asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
-      const u32* hdr_next3 = hdr + 2 * min(k + 3, last);
-      const u32* src_next = args.ops6 + 3 * (size_t)f_nxt;   // past the last block: re-reads it (never used)
-      switch (n) {
-        case 1: ldsp_block<BR, 1>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 2: ldsp_block<BR, 2>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 3: ldsp_block<BR, 3>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 4: ldsp_block<BR, 4>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 5: ldsp_block<BR, 5>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 6: ldsp_block<BR, 6>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 7: ldsp_block<BR, 7>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 8: ldsp_block<BR, 8>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 9: ldsp_block<BR, 9>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 10: ldsp_block<BR, 10>(hdr_next3, d_cur, src_next, thread_byte); break;
-        case 11: ldsp_block<BR, 11>(hdr_next3, d_cur, src_next, thread_byte); break;
-        default: ldsp_block<BR, 12>(hdr_next3, d_cur, src_next, thread_byte); break;
+      const u32* hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
+      const u32* src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
+      if (n == BR) {   // the engine sizes the blocks to the program: nearly all are full
+        ldsp_block<BR, BR>(hdr_next3, vzero, d_cur, src_next, voff);
+      } else {
+        u32 m = n;
+        asm volatile("" : "+s"(m));   // (keeps hipcc from folding the test above into one balanced tree with this switch)
+        switch (m) {
+          case 1: ldsp_block<BR, 1>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 2: ldsp_block<BR, 2>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 3: ldsp_block<BR, 3>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 4: ldsp_block<BR, 4>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 5: ldsp_block<BR, 5>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 6: ldsp_block<BR, 6>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 7: ldsp_block<BR, 7>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 8: ldsp_block<BR, 8>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 9: ldsp_block<BR, 9>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          case 10: ldsp_block<BR, 10>(hdr_next3, vzero, d_cur, src_next, voff); break;
+          default: ldsp_block<BR, 11>(hdr_next3, vzero, d_cur, src_next, voff); break;
+        }
       }
       if ((d_cur >> 4) & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
       d_cur = d_nxt;

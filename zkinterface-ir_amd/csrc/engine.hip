@@ -377,7 +377,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
       };
       std::vector<zkgpu::LdsOp> lo;
       std::vector<unsigned short> lo6;   // rows: u16 {dst, a, b} per op
-      std::vector<uint32_t> blocks;      // block headers {descriptor, first thread record}
+      std::vector<uint32_t> blocks;      // block headers {descriptor, byte offset of the first row}
       std::vector<uint32_t> ln;          // chunks
       lo.reserve(s.ops.size() / 8 + 4096);
       lo6.reserve(s.ops.size() * 3 + 3 * 4096 * s.launches.size());
@@ -429,7 +429,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
           if (barrier && r + n >= open_kinds.size()) desc |= 1u << 4;
           const uint32_t id = (uint32_t)(blocks.size() / 2);
           blocks.push_back(desc);
-          blocks.push_back(open_first + (uint32_t)r * 1024u);
+          blocks.push_back((open_first + (uint32_t)r * 1024u) * 12u);   // byte offset (the stream is far below 4 GiB)
           // consecutive blocks form one run (one chunk)
           if (ln.size() >= 4 && ((ln[ln.size() - 2] >> 10) & 1) && ln[ln.size() - 4] + ln[ln.size() - 1] == id)
             ++ln[ln.size() - 1];
