@@ -188,18 +188,19 @@ __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
 // compiled for kLdsCompilerVgprs registers (amdgpu_num_vgpr) and the registers above are named in the asm text:
 //   v[kRegP + 4 r .. + 2]  program words of row r: {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}
 //   v[kRegV + 4 s .. + 3]  operand values a0, a1, b0, b1 of the row in value set s (row r uses set r mod 3)
+//   v[kRegT .. + 3]        address / result temporaries of a row step
 //   v[kRegH .. + 1]        block header in flight
 // No scalar load may be in flight inside a run (they share lgkmcnt with the LDS and return out of order): block headers
 // travel on the vector path.  The slot fields become LDS byte addresses by ONE SDWA shift each (the 16-bit half is the
 // shifted operand; the wire table starts at LDS address 0: the kernel has no static LDS).
 constexpr int kLdsCompilerVgprs = 64;
 #ifndef ZKGPU_LDS_AHEAD
-#define ZKGPU_LDS_AHEAD 2   // rows whose operand reads are in flight behind the row being computed
+#define ZKGPU_LDS_AHEAD 1   // rows whose operand reads are in flight behind the row being computed (2 measured the same)
 #endif
 constexpr int kLdsAhead = ZKGPU_LDS_AHEAD;
-constexpr int kRegP = 64, kRegH = 124;
+constexpr int kRegP = 64, kRegH = 124, kRegT = kRegH - 4;   // kRegT .. + 3: address / result temporaries of a step
 template <int BR> constexpr int kRegV = kRegP + 4 * BR;   // value sets follow the BR rows of program words
-template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1) <= kRegH;
+template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1) <= kRegT;
 
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
 #define ZKGPU_SDWA_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
@@ -212,83 +213,96 @@ template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1)
 template <int BR, int R>   // issue the four operand reads of row R (block start: rows 0 .. kLdsAhead - 1)
 __device__ __forceinline__ void ldsp_read() {
   constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
-  u32 a0, a1, b0, b1;
-  asm volatile("v_lshlrev_b32_sdwa %0, %4, v[%5]" ZKGPU_SDWA_HI
-               "v_lshlrev_b32_sdwa %1, %4, v[%7]" ZKGPU_SDWA_LO
-               "v_lshlrev_b32_sdwa %2, %4, v[%6]" ZKGPU_SDWA_LO
-               "v_lshlrev_b32_sdwa %3, %4, v[%7]" ZKGPU_SDWA_HI
-               "ds_read_b32 v[%8], %0\n\t"
-               "ds_read_b32 v[%9], %1\n\t"
-               "ds_read_b32 v[%10], %2\n\t"
-               "ds_read_b32 v[%11], %3"
-               : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
-               : "s"(2u), "n"(P), "n"(P + 1), "n"(P + 2), "n"(V), "n"(V + 1), "n"(V + 2), "n"(V + 3)
+  asm volatile("v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[ax]]" ZKGPU_SDWA_HI
+               "v_lshlrev_b32_sdwa v[%[t1]], %[two], v[%[az]]" ZKGPU_SDWA_LO
+               "v_lshlrev_b32_sdwa v[%[t2]], %[two], v[%[ay]]" ZKGPU_SDWA_LO
+               "v_lshlrev_b32_sdwa v[%[t3]], %[two], v[%[az]]" ZKGPU_SDWA_HI
+               "ds_read_b32 v[%[a0]], v[%[t0]]\n\t"
+               "ds_read_b32 v[%[a1]], v[%[t1]]\n\t"
+               "ds_read_b32 v[%[a2]], v[%[t2]]\n\t"
+               "ds_read_b32 v[%[a3]], v[%[t3]]"
+               :
+               : [two] "s"(2u), [ax] "n"(P), [ay] "n"(P + 1), [az] "n"(P + 2), [a0] "n"(V), [a1] "n"(V + 1), [a2] "n"(V + 2),
+                 [a3] "n"(V + 3), [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2), [t3] "n"(kRegT + 3)
                : "memory");
 }
 template <int BR>
 __device__ __forceinline__ void ldsp_wait_row() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - kLdsAhead) : "memory");
 }
-// the tail of a step: gates of row R (by its bit of the block header), their writes, and the refill of the row's registers
-#define ZKGPU_LDS_STEP_TAIL                                          \
-  "s_bitcmp1_b32 %[desc], %[bit]\n\t"                                \
-  "s_cbranch_scc1 1f\n\t"                                            \
-  "v_and_b32 %[t2], v[%[v0]], v[%[v2]]\n\t"                          \
-  "v_and_b32 %[t3], v[%[v1]], v[%[v3]]\n\t"                          \
-  "s_branch 2f\n"                                                    \
-  "1:\n\t"                                                           \
-  "v_xor_b32 %[t2], v[%[v0]], v[%[v2]]\n\t"                          \
-  "v_xor_b32 %[t3], v[%[v1]], v[%[v3]]\n"                            \
-  "2:\n\t"                                                           \
-  "ds_write_b32 %[t0], %[t2]\n\t"                                    \
-  "ds_write_b32 %[t1], %[t3]\n\t"                                    \
-  "global_load_dwordx3 v[%[px]:%[pz]], %[voff], %[base]"
+// A statement that DEFINES a register (an output, a clobbered flag) makes hipcc put an s_nop behind it on gfx940+ (it
+// cannot see inside and assumes a forwarding hazard): the steps therefore define nothing -- their four temporaries are
+// registers of the hand-managed range (kRegT), and the and / xor decision is an `if` in C++ around two statements, which
+// hipcc turns into s_bitcmp1 + one branch.
 #define ZKGPU_LDS_STEP_DST                                           \
-  "v_lshlrev_b32_sdwa %[t0], %[two], v[%[px]]" ZKGPU_SDWA_LO         \
-  "v_lshlrev_b32_sdwa %[t1], %[two], v[%[py]]" ZKGPU_SDWA_HI
+  "v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[px]]" ZKGPU_SDWA_LO      \
+  "v_lshlrev_b32_sdwa v[%[t1]], %[two], v[%[py]]" ZKGPU_SDWA_HI
+#define ZKGPU_LDS_STEP_AHEAD                                           \
+  "v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[ax]]" ZKGPU_SDWA_HI        \
+  "v_lshlrev_b32_sdwa v[%[t1]], %[two], v[%[az]]" ZKGPU_SDWA_LO        \
+  "v_lshlrev_b32_sdwa v[%[t2]], %[two], v[%[ay]]" ZKGPU_SDWA_LO        \
+  "v_lshlrev_b32_sdwa v[%[t3]], %[two], v[%[az]]" ZKGPU_SDWA_HI        \
+  "ds_read_b32 v[%[a0]], v[%[t0]]\n\t"                                 \
+  "ds_read_b32 v[%[a1]], v[%[t1]]\n\t"                                 \
+  "ds_read_b32 v[%[a2]], v[%[t2]]\n\t"                                 \
+  "ds_read_b32 v[%[a3]], v[%[t3]]\n\t"
+#define ZKGPU_LDS_STEP_TEMPS [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2), [t3] "n"(kRegT + 3)
 
 // step R of a block of N rows: [reads of row R + kLdsAhead] -> wait for row R -> gates, writes -> refill
-template <int BR, int N, int R>
+template <int BR, int N, int R, int KIND>
 __device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 voff) {
   constexpr int S = kLdsAhead + 1;
   constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % S);
   constexpr int w = 2 * (R < kLdsAhead ? R : kLdsAhead);                        // writes behind the reads of row R
   constexpr int ahead = N - 1 - R < kLdsAhead ? N - 1 - R : kLdsAhead;         // rows whose reads are behind them
   constexpr int lg = 4 * ahead + w < 15 ? 4 * ahead + w : 15;                  // lgkmcnt counts to 15: beyond, wait for a little more
-  u32 t0, t1, t2, t3;
   if constexpr (R + kLdsAhead < N) {
     constexpr int A = R + kLdsAhead, PA = kRegP + 4 * A, VA = kRegV<BR> + 4 * (A % S);
     // program words of rows A and A + 1 have arrived: one vmcnt wait per two rows
     constexpr int vm = BR - kLdsAhead - 1;
-#define ZKGPU_LDS_STEP_AHEAD                                           \
-  "v_lshlrev_b32_sdwa %[t0], %[two], v[%[ax]]" ZKGPU_SDWA_HI           \
-  "v_lshlrev_b32_sdwa %[t1], %[two], v[%[az]]" ZKGPU_SDWA_LO           \
-  "v_lshlrev_b32_sdwa %[t2], %[two], v[%[ay]]" ZKGPU_SDWA_LO           \
-  "v_lshlrev_b32_sdwa %[t3], %[two], v[%[az]]" ZKGPU_SDWA_HI           \
-  "ds_read_b32 v[%[a0]], %[t0]\n\t"                                    \
-  "ds_read_b32 v[%[a1]], %[t1]\n\t"                                    \
-  "ds_read_b32 v[%[a2]], %[t2]\n\t"                                    \
-  "ds_read_b32 v[%[a3]], %[t3]\n\t"                                    \
-  ZKGPU_LDS_STEP_DST                                                   \
-  "s_waitcnt lgkmcnt(%[lg])\n\t"                                       \
-  ZKGPU_LDS_STEP_TAIL
 #define ZKGPU_LDS_STEP_AHEAD_OPERANDS                                                                                      \
-  : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)                                                         \
-  : [two] "s"(2u), [desc] "s"(desc), [voff] "v"(voff), [base] "s"(src_next), [bit] "n"(kLdsBlockKindShift + R),            \
-    [vm] "n"(vm), [lg] "n"(lg), [ax] "n"(PA), [ay] "n"(PA + 1), [az] "n"(PA + 2), [a0] "n"(VA), [a1] "n"(VA + 1),          \
-    [a2] "n"(VA + 2), [a3] "n"(VA + 3), [px] "n"(P), [py] "n"(P + 1), [pz] "n"(P + 2), [v0] "n"(V), [v1] "n"(V + 1),       \
-    [v2] "n"(V + 2), [v3] "n"(V + 3)                                                                                       \
-  : "memory", "scc"
-    if constexpr (R % 2 == 0) asm volatile("s_waitcnt vmcnt(%[vm])\n\t" ZKGPU_LDS_STEP_AHEAD ZKGPU_LDS_STEP_AHEAD_OPERANDS);
-    else asm volatile(ZKGPU_LDS_STEP_AHEAD ZKGPU_LDS_STEP_AHEAD_OPERANDS);
+  :                                                                                                                        \
+  : [two] "s"(2u), [vm] "n"(vm), [lg] "n"(lg), [ax] "n"(PA), [ay] "n"(PA + 1), [az] "n"(PA + 2), [a0] "n"(VA),              \
+    [a1] "n"(VA + 1), [a2] "n"(VA + 2), [a3] "n"(VA + 3), [px] "n"(P), [py] "n"(P + 1), ZKGPU_LDS_STEP_TEMPS               \
+  : "memory"
+    if constexpr (R % 2 == 0)
+      asm volatile("s_waitcnt vmcnt(%[vm])\n\t" ZKGPU_LDS_STEP_AHEAD ZKGPU_LDS_STEP_DST "s_waitcnt lgkmcnt(%[lg])" ZKGPU_LDS_STEP_AHEAD_OPERANDS);
+    else
+      asm volatile(ZKGPU_LDS_STEP_AHEAD ZKGPU_LDS_STEP_DST "s_waitcnt lgkmcnt(%[lg])" ZKGPU_LDS_STEP_AHEAD_OPERANDS);
   } else {
-    asm volatile(ZKGPU_LDS_STEP_DST
-                 "s_waitcnt lgkmcnt(%[lg])\n\t"
-                 ZKGPU_LDS_STEP_TAIL
-                 : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-                 : [two] "s"(2u), [desc] "s"(desc), [voff] "v"(voff), [base] "s"(src_next), [bit] "n"(kLdsBlockKindShift + R),
-                   [lg] "n"(lg), [px] "n"(P), [py] "n"(P + 1), [pz] "n"(P + 2), [v0] "n"(V), [v1] "n"(V + 1), [v2] "n"(V + 2),
-                   [v3] "n"(V + 3)
+    asm volatile(ZKGPU_LDS_STEP_DST "s_waitcnt lgkmcnt(%[lg])"
+                 :
+                 : [two] "s"(2u), [lg] "n"(lg), [px] "n"(P), [py] "n"(P + 1), ZKGPU_LDS_STEP_TEMPS
+                 : "memory");
+  }
+  // gates of row R, their writes, and the refill of the row's registers.  KIND 0 / 1: the row is known to be and / xor
+  // (a full block whose rows are `A` and-rows followed by xor-rows: one instantiation per A, no decision per row);
+  // KIND 2: by the row's bit of the block header (s_bitcmp1 + a branch inside the statement, which then clobbers scc).
+#define ZKGPU_LDS_STEP_WRITE                                         \
+  "ds_write_b32 v[%[t0]], v[%[t2]]\n\t"                              \
+  "ds_write_b32 v[%[t1]], v[%[t3]]\n\t"                              \
+  "global_load_dwordx3 v[%[px]:%[pz]], %[voff], %[base]"
+#define ZKGPU_LDS_STEP_GATES(OP)                                     \
+  OP " v[%[t2]], v[%[v0]], v[%[v2]]\n\t"                             \
+  OP " v[%[t3]], v[%[v1]], v[%[v3]]\n\t"
+#define ZKGPU_LDS_STEP_TAIL_OPERANDS                                                                                 \
+  [voff] "v"(voff), [base] "s"(src_next), [px] "n"(P), [pz] "n"(P + 2), [v0] "n"(V), [v1] "n"(V + 1), [v2] "n"(V + 2), \
+      [v3] "n"(V + 3), ZKGPU_LDS_STEP_TEMPS
+  if constexpr (KIND == 0) {
+    asm volatile(ZKGPU_LDS_STEP_GATES("v_and_b32") ZKGPU_LDS_STEP_WRITE : : ZKGPU_LDS_STEP_TAIL_OPERANDS : "memory");
+  } else if constexpr (KIND == 1) {
+    asm volatile(ZKGPU_LDS_STEP_GATES("v_xor_b32") ZKGPU_LDS_STEP_WRITE : : ZKGPU_LDS_STEP_TAIL_OPERANDS : "memory");
+  } else {
+    asm volatile("s_bitcmp1_b32 %[desc], %[bit]\n\t"
+                 "s_cbranch_scc1 1f\n\t"
+                 ZKGPU_LDS_STEP_GATES("v_and_b32")
+                 "s_branch 2f\n"
+                 "1:\n\t"
+                 ZKGPU_LDS_STEP_GATES("v_xor_b32")
+                 "2:\n\t"
+                 ZKGPU_LDS_STEP_WRITE
+                 :
+                 : [desc] "s"(desc), [bit] "n"(kLdsBlockKindShift + R), ZKGPU_LDS_STEP_TAIL_OPERANDS
                  : "memory", "scc");
   }
 }
@@ -304,23 +318,24 @@ __device__ __forceinline__ void ldsp_gload_header(const u32* p, u32 vzero) {   /
   asm volatile("global_load_dwordx2 v[%2:%3], %0, %1" : : "v"(vzero), "s"(p), "n"(kRegH), "n"(kRegH + 1) : "memory");
 }
 
-// One block of N rows, straight-line (one instantiation per N: every wait is a constant).
-template <int BR, int N, int R>
+// One block of N rows, straight-line (one instantiation per N: every wait is a constant).  A >= 0: the first A rows
+// are and-rows, the rest xor-rows; A < 0: every row decides by its header bit.
+template <int BR, int N, int A, int R>
 __device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next, const u32 (&voff)[BR]) {
   if constexpr (R < BR) {
-    if constexpr (R < N) ldsp_step<BR, N, R>(desc, src_next, voff[R]);
+    if constexpr (R < N) ldsp_step<BR, N, R, (A < 0 ? 2 : (R < A ? 0 : 1))>(desc, src_next, voff[R]);
     else ldsp_gload<R>(src_next, voff[R]);
-    ldsp_rows<BR, N, R + 1>(desc, src_next, voff);
+    ldsp_rows<BR, N, A, R + 1>(desc, src_next, voff);
   }
 }
-template <int BR, int N>
+template <int BR, int N, int A>
 __device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 vzero, u32 desc, const u32* src_next, const u32 (&voff)[BR]) {
-  if constexpr (N <= BR) {
+  if constexpr (N <= BR && A <= N) {
     ldsp_read<BR, 0>();
     if constexpr (N > 1 && kLdsAhead > 1) ldsp_read<BR, 1>();
     if constexpr (N > 2 && kLdsAhead > 2) ldsp_read<BR, 2>();
     ldsp_gload_header(hdr_next3, vzero);
-    ldsp_rows<BR, N, 0>(desc, src_next, voff);
+    ldsp_rows<BR, N, A, 0>(desc, src_next, voff);
   }
 }
 template <int BR, int R>
@@ -387,24 +402,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
       asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
       const u32* hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
       const u32* src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
-      if (n == BR) {   // the engine sizes the blocks to the program: nearly all are full
-        ldsp_block<BR, BR>(hdr_next3, vzero, d_cur, src_next, voff);
-      } else {
-        u32 m = n;
-        asm volatile("" : "+s"(m));   // (keeps hipcc from folding the test above into one balanced tree with this switch)
-        switch (m) {
-          case 1: ldsp_block<BR, 1>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 2: ldsp_block<BR, 2>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 3: ldsp_block<BR, 3>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 4: ldsp_block<BR, 4>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 5: ldsp_block<BR, 5>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 6: ldsp_block<BR, 6>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 7: ldsp_block<BR, 7>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 8: ldsp_block<BR, 8>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 9: ldsp_block<BR, 9>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          case 10: ldsp_block<BR, 10>(hdr_next3, vzero, d_cur, src_next, voff); break;
-          default: ldsp_block<BR, 11>(hdr_next3, vzero, d_cur, src_next, voff); break;
+      // The engine sizes the blocks to the program, so nearly all are full, and a level's rows come sorted by kind: a
+      // full block of `a` and-rows followed by xor-rows (header bits 17..21 = a + 1, 0 = some other order) runs code
+      // that knows every row's kind.
+      const u32 a1 = (d_cur >> kLdsBlockAndShift) & 31;
+      if (a1) {   // (set for full blocks only)
+#define ZKGPU_LDS_FULL(A) case A + 1: ldsp_block<BR, BR, A>(hdr_next3, vzero, d_cur, src_next, voff); break;
+        switch (a1) {
+          ZKGPU_LDS_FULL(0) ZKGPU_LDS_FULL(1) ZKGPU_LDS_FULL(2) ZKGPU_LDS_FULL(3) ZKGPU_LDS_FULL(4) ZKGPU_LDS_FULL(5) ZKGPU_LDS_FULL(6)
+          ZKGPU_LDS_FULL(7) ZKGPU_LDS_FULL(8) ZKGPU_LDS_FULL(9) ZKGPU_LDS_FULL(10) ZKGPU_LDS_FULL(11) ZKGPU_LDS_FULL(12)
+          default: break;
         }
+#undef ZKGPU_LDS_FULL
+      } else {
+#define ZKGPU_LDS_ANY(N) case N: ldsp_block<BR, N, -1>(hdr_next3, vzero, d_cur, src_next, voff); break;
+        switch (n) {
+          ZKGPU_LDS_ANY(1) ZKGPU_LDS_ANY(2) ZKGPU_LDS_ANY(3) ZKGPU_LDS_ANY(4) ZKGPU_LDS_ANY(5) ZKGPU_LDS_ANY(6)
+          ZKGPU_LDS_ANY(7) ZKGPU_LDS_ANY(8) ZKGPU_LDS_ANY(9) ZKGPU_LDS_ANY(10) ZKGPU_LDS_ANY(11)
+          default: ldsp_block<BR, 12, -1>(hdr_next3, vzero, d_cur, src_next, voff); break;
+        }
+#undef ZKGPU_LDS_ANY
       }
       if ((d_cur >> 4) & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
       d_cur = d_nxt;

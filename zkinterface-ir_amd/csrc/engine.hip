@@ -427,6 +427,13 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
           uint32_t desc = (uint32_t)n;
           for (size_t j = 0; j < n; ++j) desc |= open_kinds[r + j] << (zkgpu::kLdsBlockKindShift + j);
           if (barrier && r + n >= open_kinds.size()) desc |= 1u << 4;
+          {   // a full block of `a` and-rows followed by xor-rows?
+            size_t a = 0;
+            while (a < n && open_kinds[r + a] == 0) ++a;
+            bool sorted = true;
+            for (size_t j = a; j < n; ++j) sorted = sorted && open_kinds[r + j] == 1;
+            if (sorted && n == block_rows) desc |= (uint32_t)(a + 1) << zkgpu::kLdsBlockAndShift;   // full blocks only
+          }
           const uint32_t id = (uint32_t)(blocks.size() / 2);
           blocks.push_back(desc);
           blocks.push_back((open_first + (uint32_t)r * 1024u) * 12u);   // byte offset (the stream is far below 4 GiB)
