@@ -78,14 +78,20 @@ def main():
               'waves_parked_frac': lds.get('SQ_WAIT_ANY', 0) / max(lds.get('SQ_WAVE_CYCLES', 1), 1),
               'lds_issue_stall_frac': lds.get('SQ_WAIT_INST_LDS', 0) / max(lds.get('SQ_WAVE_CYCLES', 1), 1),
               'valu_insts_per_gate_and_wave': lds.get('SQ_INSTS_VALU', 0) / max(lds.get('SQ_INSTS_LDS', 1) / 3.0, 1),
-              'reading': 'one workgroup = one CU walks all 10.5 M ops (128 of 256 CUs at batch 4096).  With the bank-aware schedule '
-                         'the conflict cycles fall from 0.67 to 0.13 of the LDS cycles and the kernel from 1.99 to 1.49 ms; '
-                         'a conflict-free wiring of the same size runs in the same 1.51 ms, and so does a program stream a quarter '
-                         'smaller (6-byte entries): neither conflicts nor the stream bound it any more.  The waves are parked on '
-                         's_waitcnt / s_barrier about half of their cycles: what is left is the dependent chain program word -> '
-                         'address -> LDS read -> op -> LDS write inside each of the 644 barrier-separated levels (16 ops per thread '
-                         'and level)',
+              'reading': 'one workgroup = one CU walks all 10.5 M ops (128 of 256 CUs at batch 4096).  The kernel is bound by '
+                         'instruction issue: a SIMD hands out one issue slot every four cycles, the 16 waves of the workgroup '
+                         '(4 per SIMD) fill them, and a wave spends ~17 instructions per row of 2 gates per lane (8 VALU: six '
+                         'address shifts + two gates; 6 LDS; 1 VMEM; the waits) -- instructions per wave x 4 waves x 4 cycles '
+                         'accounts for the kernel time (issue_bound_ms below).  The LDS pipe is busy about half of the time, '
+                         'bank conflicts are 0.13 of its cycles (0.67 before the bank-aware schedule), the program stream '
+                         'is 63 MB per workgroup from L2',
               'sources': ['profiles/%s_pmc_c4_lds_counters.json' % tag]}
+        sq4 = load(d, '%s_pmc_c4_sq_counters.json' % tag)
+        if sq4 and sq4.get('SQ_WAVES'):
+            per_wave = sum(sq4.get(k, 0) for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_SMEM')) / sq4['SQ_WAVES']
+            ev['instructions_per_wave'] = {k: sq4.get(k, 0) / sq4['SQ_WAVES'] for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_SMEM')}
+            ev['issue_bound_ms'] = per_wave * 4 * 4 / 2.4e9 * 1e3   # 4 waves per SIMD, one slot per SIMD every 4 cycles, 2.4 GHz
+            ev['sources'].append('profiles/%s_pmc_c4_sq_counters.json' % tag)
         if lds0:
             ev['before_bank_aware_schedule'] = {'lds_bank_conflict_cycles_over_lds_active_cycles': ratio(lds0),
                                                 'lds_active_cycles': lds0.get('SQ_LDS_IDX_ACTIVE'),
@@ -95,7 +101,7 @@ def main():
             ev['kernel_ms_under_pmc'] = lds.get('avg_ns', 0) / 1e6
         if ident:
             ev['conflict_free_wiring_same_program_size_ms'] = ident['ms_per_step']
-        json.dump({'workload': 'c4', 'kernel': 'bool_lds_kernel', 'binding': 'lds latency (waits and level barriers), not LDS bandwidth', 'evidence': ev},
+        json.dump({'workload': 'c4', 'kernel': 'bool_lds_kernel', 'binding': 'instruction issue (one slot per SIMD every four cycles)', 'evidence': ev},
                   open(os.path.join(d, 'binding_c4.json'), 'w'), indent=1)
     # ---- C5
     bench = load(d, '%s_bench_c5.json' % tag)

@@ -64,6 +64,8 @@ elif [ $WHAT = pmc_c45 ]; then
   LDS="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU"
   pmc c4_lds $LDS -- $C4
   python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_lds.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_lds_counters.json
+  pmc c4_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -- $C4
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_sq.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_sq_counters.json
   export ZKI_BANK_AWARE=0   # the slot numbering of round 1, for the before / after of the bank-aware schedule
   pmc c4_lds_unbanked $LDS -- $C4
   unset ZKI_BANK_AWARE

@@ -140,7 +140,8 @@ __device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const Fi
 
 // A run of K accumulations as ONE asm statement: hipcc's hazard recogniser treats every asm statement as if it could
 // be a wide store and puts an `s_nop 0` between two statements that touch the same VGPR -- one per word product when
-// each product is a statement of its own.  madc_run<K, SC>(lo, hi, x, y): (hi : lo) += sum_{j < K} x[j] * y[-j]
+// each product is a statement of its own, and on gfx940+ one behind EVERY statement that defines a register: up to
+// eight products (18 operands) per statement.  madc_run<K, SC>(lo, hi, x, y): (hi : lo) += sum_{j < K} x[j] * y[-j]
 // (y walks DOWN, as the operand of a column of a product does); SC: y is wave-uniform and goes in SGPRs.
 #define ZKGPU_MT(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
 template <int K, bool SC>
@@ -152,9 +153,13 @@ __device__ __forceinline__ void madc_run(u64& lo, u32& hi, const u32* x, const u
   else if constexpr (K == 2) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1) : "vcc"); }
   else if constexpr (K == 3) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2) : "vcc"); }
   else if constexpr (K == 4) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3) : "vcc"); }
-  else {  // longer runs: four at a time
-    madc_run<4, SC>(lo, hi, x, y);
-    madc_run<K - 4, SC>(lo, hi, x + 4, y - 4);
+  else if constexpr (K == 5) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4) : "vcc"); }
+  else if constexpr (K == 6) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5) : "vcc"); }
+  else if constexpr (K == 7) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6) : "vcc"); }
+  else if constexpr (K == 8) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6), ZKGPU_IS(7) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6), ZKGPU_IN(7) : "vcc"); }
+  else {  // longer runs: eight at a time
+    madc_run<8, SC>(lo, hi, x, y);
+    madc_run<K - 8, SC>(lo, hi, x + 8, y - 8);
   }
 #undef ZKGPU_IN
 #undef ZKGPU_IS
