@@ -64,7 +64,7 @@ def main():
     lds0 = load(d, '%s_pmc_c4_lds_counters_bank_unaware.json' % tag)
     ident = load(d, '%s_bench_c4_identity_wiring.json' % tag)
     if bench and lds:
-        prog_bytes = 8.0 * bench['config']['backend_ops_per_witness']
+        prog_bytes = 6.0 * bench['config']['backend_ops_per_witness']   # rows: three u16 per op (generic entries, 8 B, are a sliver)
         wgs = 4096 // 32
         ms = bench['ms_per_step']
 
@@ -81,10 +81,12 @@ def main():
               'reading': 'one workgroup = one CU walks all 10.5 M ops (128 of 256 CUs at batch 4096).  The kernel is bound by '
                          'instruction issue: a SIMD hands out one issue slot every four cycles, the 16 waves of the workgroup '
                          '(4 per SIMD) fill them, and a wave spends ~17 instructions per row of 2 gates per lane (8 VALU: six '
-                         'address shifts + two gates; 6 LDS; 1 VMEM; the waits) -- instructions per wave x 4 waves x 4 cycles '
-                         'accounts for the kernel time (issue_bound_ms below).  The LDS pipe is busy about half of the time, '
-                         'bank conflicts are 0.13 of its cycles (0.67 before the bank-aware schedule), the program stream '
-                         'is 63 MB per workgroup from L2',
+                         'address shifts + two gates; 6 LDS; 1 VMEM; the waits).  issue_bound_ms = counted instructions per wave '
+                         '(waits, branches and barriers are not in these counters: about a tenth more) x 4 waves x 4 cycles at '
+                         '2.4 GHz: three quarters of the kernel time, the rest is the drain -> barrier -> refill of the 644 '
+                         'levels.  At every step of the rebuild the kernel time followed the instruction count, not the LDS '
+                         'traffic (unchanged), the conflicts (0.13 of the LDS cycles, 0.67 before the bank-aware schedule) or the '
+                         'program stream (63 MB per workgroup from L2)',
               'sources': ['profiles/%s_pmc_c4_lds_counters.json' % tag]}
         sq4 = load(d, '%s_pmc_c4_sq_counters.json' % tag)
         if sq4 and sq4.get('SQ_WAVES'):
