@@ -122,7 +122,8 @@ def test_full_size_c4_against_the_cpu_checker_and_the_oracle_digests(c4_referenc
     ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
     assert ev.uses_lds_path() == (path == 'lds')
     if path == 'lds':
-        assert (info['slots'] + 32) * 4 <= 160 * 1024     # the whole wire table of a 32-witness slice in one CU's LDS
+        assert (info['slots'] + 34) * 4 <= 160 * 1024     # the whole wire table of a 32-witness slice (+ scratch and
+                                                          # constant slots) in one CU's LDS
     ev.replay()
     ev.synchronize()
     assert ev.counts() == (workloads.expected_satisfied(batch), n_bad) == (4053, 43)
@@ -137,6 +138,49 @@ def test_full_size_c4_against_the_cpu_checker_and_the_oracle_digests(c4_referenc
     ev.replay()
     ev.synchronize()
     assert ev.counts() == (4052, 44) and int(ev.lane_results(batch)[0][98]) == 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('block_rows', [None, 4, 6, 8, 9, 10, 12])
+def test_lds_kernel_block_shapes_against_the_cpu_checker(block_rows, monkeypatch):
+    """The LDS-resident kernel has one instantiation per block size and, inside it, one code path per number of rows of
+    a block and per position of the and -> xor change in a full block; the engine picks the block size per program.
+    A relation with 11 rows per level (18,432 gates: 5 and-rows, 5 xor-rows, 1 row of nots) run with every block size
+    forced (ZKGPU_LDS_BLOCK_ROWS, a tuning switch of the engine) walks levels of 1 to 3 blocks, full and short, with the
+    kind change in different rows: all output wires of all lanes against the CPU checker, ragged batch."""
+    if block_rows is None:
+        monkeypatch.delenv('ZKGPU_LDS_BLOCK_ROWS', raising=False)
+    else:
+        monkeypatch.setenv('ZKGPU_LDS_BLOCK_ROWS', str(block_rows))
+    wl = workloads.BoolLayered(W=18432, D=5, n_instance0=64, n_out=48, seed=0xB10C + (block_rows or 0))
+    batch = 75
+    inst, wit = wl.inputs(batch)
+    outs = cpu_checkers.bool_layered_outputs(wl, inst, wit)
+    assert 0.15 < outs.mean() < 0.85
+    inst = inst.copy()
+    n_bad = wl.set_expected_outputs(inst, outs, corrupt_every=7)
+    ev = zk.Evaluator()
+    ev.set_option('bool_path', 'lds')
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in wl.relation_messages():
+        ev.ingest_message(m)
+    ev.finalize()
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    assert ev.uses_lds_path()
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (batch - n_bad, n_bad)
+    first, flags = ev.lane_results(batch)
+    assert np.array_equal(first, np.where(np.arange(batch) % 7 == 0, 0, zk.NO_FAIL).astype(np.uint32)) and not flags.any()
+    # every output bit, not only "all equal": flip one expected bit per lane and see exactly that assert fail
+    for lane in range(batch):
+        inst[lane, wl.n_instance0, 0] = outs[lane, 0]                       # undo the damage of set_expected_outputs
+        inst[lane, wl.n_instance0 + lane % wl.n_out, 0] ^= 1
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (0, batch)
+    assert ev.lane_results(batch)[0].tolist() == [lane % wl.n_out for lane in range(batch)]
 
 
 @pytest.mark.gpu
