@@ -55,11 +55,9 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restr
   bool bad = false;
   u32 k = k0;
   if ((n_vals & 15) == 0 && ((size_t)raw & 15) == 0) {
-    for (; k + 16 <= k1; k += 16) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (valid) v = *reinterpret_cast<const uint4*>(row + k);
+    auto pack16 = [&](const uint4 v, u32 kk) {
       const u32 w[4] = {v.x, v.y, v.z, v.w};
-      const uint4 sm = *reinterpret_cast<const uint4*>(strict + k);   // 0x00 / 0xFF per position (padded to 16)
+      const uint4 sm = *reinterpret_cast<const uint4*>(strict + kk);   // 0x00 / 0xFF per position (padded to 16)
       bad |= (((v.x & sm.x) | (v.y & sm.y) | (v.z & sm.z) | (v.w & sm.w)) & 0xFEFEFEFEu) != 0;
       u64 mine = 0;
 #pragma unroll
@@ -67,8 +65,18 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restr
         const u64 m = __ballot((w[b >> 2] >> (8 * (b & 3))) & 1);
         if (lane == (u32)b) mine = m;
       }
-      if (lane < 16) packed[(size_t)(k + lane) * total_words + word] = mine;
+      if (lane < 16) packed[(size_t)(kk + lane) * total_words + word] = mine;
+    };
+    // a lane's row is its own: 64 lanes touch 64 different cache lines per load.  Four loads (64 bytes of the row) are
+    // issued together so that the lines are used while they are in the L1, not fetched again per 16 bytes
+    for (; k + 64 <= k1; k += 64) {
+      uint4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = valid ? *reinterpret_cast<const uint4*>(row + k + 16 * q) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pack16(v[q], k + 16 * q);
     }
+    for (; k + 16 <= k1; k += 16) pack16(valid ? *reinterpret_cast<const uint4*>(row + k) : make_uint4(0, 0, 0, 0), k);
   }
   for (; k < k1; ++k) {
     const uint8_t v = valid ? row[k] : 0;
@@ -378,6 +386,26 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
       if ((flags >> 9) & 1) {
         if (tid == 0)
           for (u32 i = 0; i < rows; ++i) lds_exec(args.ops[first + i], T, args, col, valid_mask);
+      } else if ((flags & 0xFF) == OP_INSTANCE || (flags & 0xFF) == OP_WITNESS) {
+        // input loads, eight at a time: entries, then the packed words (a 4-byte gather each), then the LDS stores --
+        // one after the other every op paid two global latencies (16 ops per thread at C4: 25 us of a 0.93 ms replay)
+        const u32 kind = flags & 0xFF;
+        const u32* __restrict__ src = kind == OP_INSTANCE ? args.packed_inst : args.packed_wit;
+        for (u32 j0 = 0; j0 < 2 * rows; j0 += 8) {
+          LdsOp o[8];
+          u32 v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            o[q] = LdsOp{0, 0, 0, (unsigned short)OP_NOP};
+            if (j0 + q < 2 * rows) o[q] = args.ops[first + (j0 + q) * 1024 + tid];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            v[q] = o[q].kind == kind ? src[(size_t)(o[q].a | ((u32)o[q].b << 16)) * (2 * args.total_words64) + col] : 0u;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (o[q].kind == kind) T[o[q].dst] = v[q];
+        }
       } else {
         for (u32 j = 0; j < 2 * rows; ++j) lds_exec(args.ops[first + j * 1024 + tid], T, args, col, valid_mask);
       }
