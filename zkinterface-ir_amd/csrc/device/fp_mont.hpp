@@ -144,22 +144,25 @@ __device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const Fi
 // eight products (18 operands) per statement.  madc_run<K, SC>(lo, hi, x, y): (hi : lo) += sum_{j < K} x[j] * y[-j]
 // (y walks DOWN, as the operand of a column of a product does); SC: y is wave-uniform and goes in SGPRs.
 #define ZKGPU_MT(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
-template <int K, bool SC>
+// the first accumulation of a column: the carry word is DEFINED here (0 + 0 + carry), not added to -- see the end of
+// mont_reduce_column
+#define ZKGPU_MT0(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc\n\t"
+template <int K, bool SC, bool FIRST = false>
 __device__ __forceinline__ void madc_run(u64& lo, u32& hi, const u32* x, const u32* y) {
   static_assert(K >= 1 && K <= 12, "");
 #define ZKGPU_IN(j) "v"(x[j]), "v"(y[-(j)])
 #define ZKGPU_IS(j) "v"(x[j]), "s"(y[-(j)])
-  if constexpr (K == 1) { if constexpr (SC) asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0) : "vcc"); else asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0) : "vcc"); }
-  else if constexpr (K == 2) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1) : "vcc"); }
-  else if constexpr (K == 3) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2) : "vcc"); }
-  else if constexpr (K == 4) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3) : "vcc"); }
-  else if constexpr (K == 5) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4) : "vcc"); }
-  else if constexpr (K == 6) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5) : "vcc"); }
-  else if constexpr (K == 7) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6) : "vcc"); }
-  else if constexpr (K == 8) { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6), ZKGPU_IS(7) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6), ZKGPU_IN(7) : "vcc"); }
+  if constexpr (K == 1) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0) : "vcc"); else asm(ZKGPU_MT0(2, 3) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0) : "vcc"); else asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0) : "vcc"); } }
+  else if constexpr (K == 2) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1) : "vcc"); else asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1) : "vcc"); } }
+  else if constexpr (K == 3) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2) : "vcc"); else asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2) : "vcc"); } }
+  else if constexpr (K == 4) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3) : "vcc"); else asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3) : "vcc"); } }
+  else if constexpr (K == 5) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4) : "vcc"); else asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4) : "vcc"); } }
+  else if constexpr (K == 6) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5) : "vcc"); else asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5) : "vcc"); } }
+  else if constexpr (K == 7) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6) : "vcc"); else asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6) : "vcc"); } }
+  else if constexpr (K == 8) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6), ZKGPU_IS(7) : "vcc"); else asm(ZKGPU_MT0(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6), ZKGPU_IN(7) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0), ZKGPU_IS(1), ZKGPU_IS(2), ZKGPU_IS(3), ZKGPU_IS(4), ZKGPU_IS(5), ZKGPU_IS(6), ZKGPU_IS(7) : "vcc"); else asm(ZKGPU_MT(2, 3) ZKGPU_MT(4, 5) ZKGPU_MT(6, 7) ZKGPU_MT(8, 9) ZKGPU_MT(10, 11) ZKGPU_MT(12, 13) ZKGPU_MT(14, 15) ZKGPU_MT(16, 17) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0), ZKGPU_IN(1), ZKGPU_IN(2), ZKGPU_IN(3), ZKGPU_IN(4), ZKGPU_IN(5), ZKGPU_IN(6), ZKGPU_IN(7) : "vcc"); } }
   else {  // longer runs: eight at a time
-    madc_run<8, SC>(lo, hi, x, y);
-    madc_run<K - 8, SC>(lo, hi, x + 8, y - 8);
+    madc_run<8, SC, FIRST>(lo, hi, x, y);
+    madc_run<K - 8, SC, false>(lo, hi, x + 8, y - 8);
   }
 #undef ZKGPU_IN
 #undef ZKGPU_IS
@@ -168,12 +171,13 @@ __device__ __forceinline__ void madc_run(u64& lo, u32& hi, const u32* x, const u
 // Montgomery product a*b*R^{-1} mod p, product-scanning (column by column) form, canonical out.
 // Per column k: acc += sum a[i]*b[k-i] + sum m[i]*p[k-i]; m[k] = acc * n0inv makes the low word 0;
 // the accumulator then shifts down one word.  2*N^2 + N word products, 2 instructions each.
-template <int N, int k, bool SC>
+// FIRST: these are the first products of column k (every column below 2N - 1 has some): they define the carry word
+template <int N, int k, bool SC, bool FIRST>
 __device__ __forceinline__ void mont_products(u64& lo, u32& hi, const u32* x, const u32* y) {
   if constexpr (k < N) {
-    madc_run<k + 1, SC>(lo, hi, x, y + k);                       // x[i] * y[k - i], i = 0..k
+    madc_run<k + 1, SC, FIRST>(lo, hi, x, y + k);                       // x[i] * y[k - i], i = 0..k
   } else if constexpr (k - N + 1 < N) {
-    madc_run<2 * N - 1 - k, SC>(lo, hi, x + (k - N + 1), y + (N - 1));   // i = k-N+1 .. N-1
+    madc_run<2 * N - 1 - k, SC, FIRST>(lo, hi, x + (k - N + 1), y + (N - 1));   // i = k-N+1 .. N-1
   }
 }
 template <int N, int k>
@@ -186,15 +190,17 @@ __device__ __forceinline__ void mont_reduce_column(u64& lo, u32& hi, u32 (&m)[N]
     if constexpr (k - N + 1 < N) madc_run<2 * N - 1 - k, true>(lo, hi, &m[k - N + 1], &fp.p[N - 1]);
     t[k - N] = (u32)lo;
   }
+  // The accumulator moves down one word.  Its new top word is not zeroed: the first accumulation of the next column
+  // defines it (ZKGPU_MT0), and the carry word of this column becomes the high half of the new pair -- one register
+  // move per column (the 64-bit operand of v_mad_u64_u32 has to be an aligned pair) instead of three.
   lo = (lo >> 32) | ((u64)hi << 32);
-  hi = 0;
 }
 
 template <int N, int k>
 __device__ __forceinline__ void fp_mul_columns(u64& lo, u32& hi, const Fp<N>& a, const Fp<N>& b, u32 (&m)[N], u32 (&t)[N + 1],
                                                const FieldParams& fp) {
   if constexpr (k < 2 * N) {
-    mont_products<N, k, false>(lo, hi, a.w, b.w);
+    mont_products<N, k, false, true>(lo, hi, a.w, b.w);
     mont_reduce_column<N, k>(lo, hi, m, t, fp);
     fp_mul_columns<N, k + 1>(lo, hi, a, b, m, t, fp);
   }
@@ -247,10 +253,10 @@ template <int N, int K, int k>
 __device__ __forceinline__ void fp_dot_columns(u64& lo, u32& hi, const Fp<N> (&v)[K], const FpS<N> (&c)[K], u32 (&m)[N],
                                                u32 (&t)[N + 1], const FieldParams& fp) {
   if constexpr (k < 2 * N) {
-    mont_products<N, k, true>(lo, hi, v[0].w, c[0].w);
-    if constexpr (K > 1) mont_products<N, k, true>(lo, hi, v[1].w, c[1].w);
-    if constexpr (K > 2) mont_products<N, k, true>(lo, hi, v[2].w, c[2].w);
-    if constexpr (K > 3) mont_products<N, k, true>(lo, hi, v[3].w, c[3].w);
+    mont_products<N, k, true, true>(lo, hi, v[0].w, c[0].w);
+    if constexpr (K > 1) mont_products<N, k, true, false>(lo, hi, v[1].w, c[1].w);
+    if constexpr (K > 2) mont_products<N, k, true, false>(lo, hi, v[2].w, c[2].w);
+    if constexpr (K > 3) mont_products<N, k, true, false>(lo, hi, v[3].w, c[3].w);
     mont_reduce_column<N, k>(lo, hi, m, t, fp);
     fp_dot_columns<N, K, k + 1>(lo, hi, v, c, m, t, fp);
   }
