@@ -346,7 +346,8 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   lds_path_ = false;
   if (boolean_ && bool_path_ != 1) {
     const bool fits = ((uint64_t)s.n_slots + zkgpu::kLdsExtraSlots) * 4 + 64 <= kLdsBytes &&
-                      s.n_slots + zkgpu::kLdsExtraSlots < 0xFFFF;   // + scratch and constant slots
+                      s.n_slots + zkgpu::kLdsExtraSlots < 0xFFFF &&   // + scratch and constant slots
+                      (uint64_t)s.ops.size() * 6 + s.launches.size() * 24576ull + (1u << 22) < (1ull << 32);   // block headers carry 32-bit byte offsets into the row stream
     if (fits) {
       // program of the LDS kernel (device/args.hpp): generic chunks of 8-byte entries, and for the xor / and / not /
       // copy ops of a level rows of 2048 ops of one kind, gathered into blocks of <= block_rows rows
