@@ -166,10 +166,10 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
   T[op.dst] = r;
 }
 
-// The xor / and / not / copy ops of a level are stored as ROWS of 2048 ops of one kind (the host sorts a level by kind
-// and pads each kind to whole rows with ops on scratch slots), without their kind: three u16 per op, two ops = 12 bytes
-// per thread and row -- {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}; unary kinds store b = 0.  Consecutive rows of
-// a level form BLOCKS of at most BR rows (args.hpp: block header).
+// The xor / and / not / copy ops of a level are stored as ROWS of 2048 ops of one kind -- and or xor: `not a` is stored
+// as a xor ONES, a copy as a xor ZERO (args.hpp) -- padded to whole rows with ops on scratch slots, without their kind:
+// three u16 per op, two ops = 12 bytes per thread and row -- {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}.
+// Consecutive rows of a level form BLOCKS of at most BR rows (args.hpp: block header).
 
 // wave-uniform table read on the scalar path (s_load)
 __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
@@ -179,23 +179,20 @@ __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
 }
 
 // ---- the block pipeline --------------------------------------------------------------------------------------------
-// All rows of a level are independent, so the operand reads of row r + 2 are issued BEFORE the results of row r are
-// computed and written: the LDS queue of a wave always holds the reads of the next two rows and the writes of the last
-// two, and the waves' address arithmetic and gate instructions run while the LDS pipe works.  (With the reads of a
-// chunk of four rows issued, waited for and only then followed by its writes, all 16 waves of the workgroup sat in the
-// same phase and the LDS pipe idled 60 % of the time: 1.27 ms for C4.)  Every row is exactly 4 reads + 2 writes (`not`
-// and copy are xors with a constant slot, args.hpp) and the LDS instructions of a wave complete in order, hence "row r
-// has arrived" is `s_waitcnt lgkmcnt(#LDS instructions issued after its last read)`, a constant per unrolled step.
-// The program words arrive the same way: every block issues the same global loads in the same order -- the header of
-// block k + 3, then after the writes of row r the 12 bytes of row r of block k + 1 into the registers row r just left,
-// for all BR rows (the kernel's template parameter) whatever the blocks hold -- so "row r + 2 of this block has arrived" is always
-// vmcnt(BR - 2): one block of program words in flight.
+// All rows of a level are independent, so the operand reads of the next kLdsAhead rows are issued BEFORE the results of
+// row r are computed and written: a wave's LDS queue holds reads and writes of neighbouring rows, and its address
+// arithmetic and gate instructions run while the LDS pipe works.  Every row is exactly 4 reads + 2 writes and the LDS
+// instructions of a wave complete in order, hence "row r has arrived" is `s_waitcnt lgkmcnt(#LDS instructions issued
+// after its last read)`, a constant per unrolled step.  The program words arrive the same way: every block issues the
+// same global loads in the same order -- the header of block k + 3, then after the writes of row r the 12 bytes of row
+// r of block k + 1 into the registers row r just left, for all BR rows (the kernel's template parameter) whatever the
+// blocks hold -- so "the rows this step reads are there" is always the same vmcnt: one block of program words in flight.
 //
 // hipcc cannot be told that a register is waiting for a load: it is free to copy it (at a branch join, say) before the
 // data is there.  So everything that is in flight lives in registers the compiler does not own -- the kernel is
 // compiled for kLdsCompilerVgprs registers (amdgpu_num_vgpr) and the registers above are named in the asm text:
 //   v[kRegP + 4 r .. + 2]  program words of row r: {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}
-//   v[kRegV + 4 s .. + 3]  operand values a0, a1, b0, b1 of the row in value set s (row r uses set r mod 3)
+//   v[kRegV + 4 s .. + 3]  operand values a0, a1, b0, b1 of the row in value set s (row r uses set r mod (kLdsAhead + 1))
 //   v[kRegT .. + 3]        address / result temporaries of a row step
 //   v[kRegH .. + 1]        block header in flight
 // No scalar load may be in flight inside a run (they share lgkmcnt with the LDS and return out of order): block headers
