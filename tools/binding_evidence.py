@@ -115,9 +115,15 @@ def main():
               'word_products_per_row': 664, 'v_mad_u64_u32_plus_addc_per_row': 1328,
               'waves_parked_on_memory_frac': sq.get('SQ_WAIT_ANY', 0) / max(sq.get('SQ_WAVE_CYCLES', 1), 1),
               'round1_valu_insts_per_row_and_wave': 2270,
-              'reading': 'v_mad_u64_u32 issues at about a third of the full VALU rate (profiles/r01_valu_rates.txt): 664 of them '
-                         'per row are ~41 ms at 2.4 GHz over 1024 SIMDs; the HBM floor of the 240.5 GB of gathers is 38 ms at 6.3 TB/s',
+              'reading': 'at the instruction rates measured on this chip (profiles/r01_valu_rates.txt: v_mad_u64_u32 26.6 T lane-ops/s, '
+                         'add-with-carry 68 T, other 32-bit integer ops about 35 T) the 664 + 664 + ~190 VALU instructions of a row '
+                         'are valu_pipe_ms of VALU pipe per check over 1024 witnesses: the kernel time is that pipe busy '
+                         'valu_pipe_busy_frac of the time.  The HBM floor of the 240.5 GB of gathers is 38 ms at 6.3 TB/s',
               'sources': ['profiles/%s_pmc_c5_sq_counters.json' % tag]}
+        other = max(ev['valu_insts_per_row_and_wave'] - 1328, 0)
+        units = (664 / 26.6 + 664 / 67.9 + other / 35.0) * (bench['config'].get('rows', 1 << 20) * 1024 / 1e12)   # seconds
+        ev['valu_pipe_ms'] = units * 1e3
+        ev['valu_pipe_busy_frac'] = units * 1e3 / bench['ms_per_step']
         if tr:
             ev['traffic_over_algorithmic'] = tr['traffic_bytes_per_launch'] / bench['roofline']['algorithmic_bytes_per_launch']
             ev['sources'].append('profiles/pmc_traffic_c5.json')
