@@ -47,6 +47,15 @@ def main():
             wc = sq.get('SQ_WAVE_CYCLES') or 1
             ev['waves_parked_on_memory_frac'] = sq.get('SQ_WAIT_ANY', 0) / wc
             ev['valu_insts_per_wave'] = sq.get('SQ_INSTS_VALU', 0) / max(sq.get('SQ_WAVES', 1), 1)
+            # the second resource: the VALU pipe at this chip's measured rates (r01_valu_rates.txt).  A wave = one program
+            # entry x 64 witnesses; half of the relation's gates are multiplications of 136 v_mad_u64_u32 + v_addc pairs
+            cfg = bench['config']
+            entries, gates = cfg.get('program_entries'), cfg.get('backend_ops_per_witness')
+            if entries and gates:
+                mads = 136.0 * 0.5 * (1 << 20) / entries
+                other = max(ev['valu_insts_per_wave'] - 2 * mads, 0)
+                ev['valu_pipe_ms'] = (mads / 26.6 + mads / 67.9 + other / 35.0) * entries * 1024 / 1e12 * 1e3
+                ev['valu_pipe_busy_frac'] = ev['valu_pipe_ms'] / bench['ms_per_step']
             ev['sources'].append('profiles/%s_pmc_c2_sq_counters.json' % tag)
         if hv and r.get('hbm_variant'):
             h = r['hbm_variant']
