@@ -317,10 +317,32 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda', dist
             out['cpu_baseline'] = {'value': n_rows * sample / secs, 'unit': 'row-checks/s', 'cores': threads, 'kind': 'port',
                                    'sample': '%d witnesses of the same %d-row system, 4x64 Montgomery row check on %d '
                                              'threads, %.1f s wall (witness generation excluded)' % (sample, n_rows, threads, secs)}
-        print(json.dumps(out))
+        emit_json_line(out)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (gloo announces its peers on stdout, RCCL can
+    be told to log): from here on file descriptor 1 goes to stderr, and only emit_json_line() writes to the real stdout."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json_line(out):
+    line = (json.dumps(out) + '\n').encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
 
 
 def launch_ranks(n):
@@ -375,6 +397,7 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))   # nothing in this process has touched torch or the GPU
 
+    keep_stdout_for_the_result()
     import torch
     import torch.distributed as dist
 
@@ -610,7 +633,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates, ev)
-        print(json.dumps(out))
+        emit_json_line(out)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
