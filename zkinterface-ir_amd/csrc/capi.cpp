@@ -49,6 +49,7 @@ struct StreamState {
   uint32_t windows_done = 0;
   double busy_s = 0;     // time the worker spent scheduling + uploading
   bool upload = true;    // send finished windows to the GPU (switched off when no GPU can be opened)
+  int device = -2;       // the engine's device: the first listed one, or the RECORDING thread's current device (-2: not asked yet)
 };
 
 struct zkgpu_session {
@@ -205,7 +206,7 @@ void stream_worker(zkgpu_session* s) {
       if (st.upload) {
         // the window's entries go to HBM now; without a GPU (the CPU test tier) they are sent by the first replay call
         try {
-          if (!s->engine) s->engine.reset(new Engine());
+          if (!s->engine) s->engine.reset(new Engine(st.device));
         } catch (const std::exception&) {
           st.upload = false;
         }
@@ -228,6 +229,8 @@ void stream_worker(zkgpu_session* s) {
 void stream_enqueue(zkgpu_session* s, uint32_t hi, bool final) {
   StreamState& st = *s->stream;
   const Tape& t = s->backend.tape();
+  // the worker thread opens the engine: on the device the caller works on, not on the worker's own default
+  if (st.device == -2) st.device = s->devices.empty() ? current_device() : s->devices[0];
   WindowJob job;
   job.lo = st.next_lo;
   job.hi = hi;
@@ -315,7 +318,7 @@ void per_engine(const std::vector<size_t>& which, F&& f) {
 void need_engine(zkgpu_session* s) {
   if (!s->finalized) throw std::runtime_error("zkgpu_finalize() has not been called");
   if (!s->engine || !s->engine_loaded) {
-    const int dev0 = s->devices.empty() ? -1 : s->devices[0];
+    const int dev0 = s->devices.empty() ? current_device() : s->devices[0];   // -1 without a GPU: Engine() says so
     // a streamed ingest opened the first engine already (on the current device)
     std::unique_ptr<Engine> e = (s->engine && s->engine->device() == dev0) ? std::move(s->engine) : std::unique_ptr<Engine>(new Engine(dev0));
     s->engine.reset();

@@ -93,6 +93,9 @@ Engine::Engine(int device) : device_(device) {
   HIP_OK(hipGetDeviceCount(&n));
   if (n <= 0) throw std::runtime_error("HIP: no GPU visible (no CPU fallback exists for the replay path)");
   if (device >= n) throw std::runtime_error("Engine: device " + std::to_string(device) + " of " + std::to_string(n) + " visible");
+  // "the current device" is a property of the calling THREAD: it is resolved once, here, and every entry point sets it
+  // again (use_device), whichever host thread it is called from (the streaming worker, the per-device threads)
+  if (device_ < 0) HIP_OK(hipGetDevice(&device_));
   use_device();
   hipStream_t st;
   HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -1138,6 +1141,15 @@ void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>
   HIP_OK(hipMemcpy(out->data(), d_out, out->size(), hipMemcpyDeviceToHost));
   (void)hipFree(d_slots);
   (void)hipFree(d_out);
+}
+
+int current_device() {
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return d;
 }
 
 int visible_devices() {

@@ -188,6 +188,7 @@ class Engine {
 // every engine's own stream behind its replay; afterwards every device holds the totals.  RCCL is loaded on first
 // use (dlopen: the library takes no link-time dependency on it).  Throws when RCCL cannot be loaded or a call fails.
 int visible_devices();   // hipGetDeviceCount, or -1 when the HIP runtime finds no GPU
+int current_device();    // hipGetDevice of the calling thread, or -1 without a GPU
 
 class CountReducer {
  public:
