@@ -123,6 +123,15 @@ int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]);
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
                         uint32_t* slot_of);
 
+/* GF(2) relations: the program of the LDS-resident kernel (csrc/device/lds_layout.hpp) for this schedule, with blocks
+ * of `block_rows` rows (4, 6, 8, 9, 10, 12; 0 = the size the engine would pick).  Host work only (no GPU is touched):
+ * host-logic tests interpret it.  sizes[6] = {entries of 8 bytes, u16 words of the row stream, block headers, chunks,
+ * block_rows used, words of the LDS table}; call once with the array pointers NULL for the sizes, then with buffers
+ * (ops8: 4 u16 per entry {dst, a, b, kind}; rows: u16; blocks: 2 u32 per block; chunks: 4 u32 per chunk).  Returns 2
+ * (and an error text) when the relation is not Boolean or does not fit the kernel. */
+int zkgpu_lds_program(zkgpu_session* s, uint32_t block_rows, uint64_t sizes[6], uint16_t* ops8, uint16_t* rows,
+                      uint32_t* blocks, uint32_t* chunks);
+
 /* inputs: [batch][n_instance][elem_bytes] and [batch][n_witness][elem_bytes], little-endian */
 int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* witnesses, uint32_t batch);
 int zkgpu_set_inputs_device(zkgpu_session* s, const void* d_instances, const void* d_witnesses, uint32_t batch);

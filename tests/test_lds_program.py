@@ -1,0 +1,144 @@
+"""CPU tier: the program of the LDS-resident GF(2) kernel (csrc/lds_program.cpp, layout csrc/device/lds_layout.hpp) is
+host work -- it is built here for every block size the kernel is instantiated for and INTERPRETED in numpy, 32
+witnesses per word like the kernel: the verdicts must be the oracle's / the CPU checker's, and the structural
+promises the kernel's hand-counted waits rest on must hold (whole rows, a level never reads what it writes, the
+`a and-rows then xor-rows` field only on full blocks that are exactly that)."""
+import numpy as np
+import pytest
+
+import cpu_checkers
+import zkinterface_ir_amd as zk
+from helpers import golden_buffers
+from oracle_lib import OracleRun
+from zkinterface_ir_amd import workloads
+
+ROW = 2048
+K_COPY, K_CONST, K_INSTANCE, K_WITNESS, K_ASSERT, K_AND, K_XOR, K_NOT = 5, 6, 7, 8, 9, 10, 11, 12
+NO_FAIL = 0xFFFFFFFF
+
+
+def pack32(bits):
+    """bits[lane][pos] (0/1, <= 32 lanes) -> u32 word per position"""
+    lanes = bits.shape[0]
+    return (bits.astype(np.uint32) << np.arange(lanes, dtype=np.uint32)[:, None]).sum(axis=0, dtype=np.uint64).astype(np.uint32)
+
+
+def interpret(prog, consts, inst_bits, wit_bits):
+    """-> first failing assert sequence per lane (32 lanes at most); checks the structural promises on the way"""
+    lanes = inst_bits.shape[0] if inst_bits.size else wit_bits.shape[0]
+    valid = np.uint32((1 << lanes) - 1) if lanes < 32 else np.uint32(0xFFFFFFFF)
+    words = prog['table_words']
+    T = np.zeros(words, dtype=np.uint32)
+    real = words - 34
+    T[real + 33] = 0xFFFFFFFF
+    pi = pack32(inst_bits) if inst_bits.size else np.zeros(0, np.uint32)
+    pw = pack32(wit_bits) if wit_bits.size else np.zeros(0, np.uint32)
+    first = np.full(32, NO_FAIL, dtype=np.uint64)
+    rows, blocks, ops8, br = prog['rows'], prog['blocks'], prog['ops8'], prog['block_rows']
+
+    def exec_entry(e):
+        dst, a, b, kind = (int(x) for x in e)
+        if kind == K_XOR: T[dst] = T[a] ^ T[b]
+        elif kind == K_AND: T[dst] = T[a] & T[b]
+        elif kind == K_NOT: T[dst] = ~T[a]
+        elif kind == K_COPY: T[dst] = T[a]
+        elif kind == K_CONST: T[dst] = 0xFFFFFFFF if consts[a] else 0
+        elif kind == K_INSTANCE: T[dst] = pi[a | (b << 16)]
+        elif kind == K_WITNESS: T[dst] = pw[a | (b << 16)]
+        elif kind == K_ASSERT:
+            nz = int(T[a] & valid)
+            seq = dst | (b << 16)
+            for lane in range(32):
+                if (nz >> lane) & 1:
+                    first[lane] = min(first[lane], seq)
+
+    for first_w, nrows, flags, run in prog['chunks']:
+        first_w, nrows, flags, run = int(first_w), int(nrows), int(flags), int(run)
+        if flags & (1 << 10):
+            level_reads, level_writes = set(), set()
+            for blk in range(first_w, first_w + run):
+                desc, off = int(blocks[blk, 0]), int(blocks[blk, 1])
+                n = desc & 15
+                assert 1 <= n <= br and off % 12 == 0
+                kinds = [(desc >> (5 + r)) & 1 for r in range(n)]
+                a1 = (desc >> 17) & 31
+                if a1:
+                    assert n == br and kinds == [0] * (a1 - 1) + [1] * (n - a1 + 1), 'the kind-known path would run other gates'
+                assert (off // 2) + br * ROW * 3 <= len(rows), 'a block fetches block_rows rows: they must lie in the stream'
+                for r in range(n):
+                    rec = rows[off // 2 + r * ROW * 3: off // 2 + (r + 1) * ROW * 3].reshape(ROW, 3).astype(np.int64)
+                    dst, a, b = rec[:, 0], rec[:, 1], rec[:, 2]
+                    assert dst.max() < real + 32 and a.max() < words and b.max() < words
+                    real_dst = dst[dst < real]
+                    assert len(np.unique(real_dst)) == len(real_dst), 'two ops of a row write one slot'
+                    level_reads.update(a[a < real].tolist())
+                    level_reads.update(b[b < real].tolist())
+                    assert not (level_writes & set(real_dst.tolist())), 'two rows of a level write one slot'
+                    level_writes.update(real_dst.tolist())
+                    x, y = T[a], T[b]                      # all reads of the row before its writes, like the kernel
+                    T[dst] = (x ^ y) if kinds[r] else (x & y)
+                    T[real + 32] = 0
+                    T[real + 33] = 0xFFFFFFFF              # (padding ops only ever write the 32 scratch slots)
+                if desc & 16:
+                    assert not (level_reads & level_writes), 'a level reads a slot it writes: the rows are not independent'
+                    level_reads, level_writes = set(), set()
+            assert not level_reads or (int(blocks[first_w + run - 1, 0]) & 16), 'a run ends inside a level'
+        elif flags & (1 << 9):
+            for e in ops8[first_w: first_w + nrows]:
+                exec_entry(e)
+        else:
+            for e in ops8[first_w: first_w + nrows * ROW]:
+                exec_entry(e)
+    return first[:lanes]
+
+
+def session(msgs, n_instance, n_witness):
+    ev = zk.Evaluator()
+    ev.declare_inputs(n_instance, n_witness)
+    for m in msgs:
+        ev.ingest_message(m)
+    ev.finalize()
+    return ev
+
+
+@pytest.mark.parametrize('block_rows', [0, 4, 6, 8, 9, 10, 12])
+def test_lds_program_interpreted_matches_the_cpu_checker(block_rows):
+    wl = workloads.BoolLayered(W=4608, D=5, n_instance0=64, n_out=40, seed=0x1D5 + block_rows)   # 5 rows per level
+    batch = 23
+    inst, wit = wl.inputs(batch)
+    outs = cpu_checkers.bool_layered_outputs(wl, inst, wit)
+    inst = inst.copy()
+    wl.set_expected_outputs(inst, outs, corrupt_every=0)
+    want = np.full(batch, NO_FAIL, dtype=np.uint64)
+    for lane in range(0, batch, 2):                      # damage one expected output on every other lane
+        inst[lane, wl.n_instance0 + lane % wl.n_out, 0] ^= 1
+        want[lane] = lane % wl.n_out
+    ev = session(wl.relation_messages(), wl.n_instance, wl.n_witness)
+    prog = ev.lds_program(block_rows)
+    assert prog['block_rows'] == (block_rows or prog['block_rows']) and prog['block_rows'] in (4, 6, 8, 9, 10, 12)
+    if block_rows == 0:
+        assert prog['block_rows'] == 4                   # levels of 4 and 5 rows: 4-row blocks fetch least (5 + 5 + 10 + ...)
+    _, _, consts, _ = ev.schedule_dump()
+    got = interpret(prog, consts, inst[:, :, 0], wit[:, :, 0])
+    assert got.tolist() == want.tolist()
+
+
+@pytest.mark.parametrize('name', ['bool_correct', 'bool_incorrect'])
+def test_lds_program_of_the_reference_examples(name):
+    """the reference's Boolean example (functions, a for loop, a switch): mostly sequential segments and short rows"""
+    bufs = golden_buffers(name)
+    ev = zk.Evaluator.from_messages(bufs)
+    ev.finalize()
+    ref = OracleRun(buffers=bufs)
+    inst = np.array([[v[0] if v else 0 for v in ev.message_values(False)]], dtype=np.uint8)
+    wit = np.array([[v[0] if v else 0 for v in ev.message_values(True)]], dtype=np.uint8)
+    _, _, consts, _ = ev.schedule_dump()
+    got = interpret(ev.lds_program(), consts, inst, wit)
+    assert (int(got[0]) == NO_FAIL) == (ref.violations == [])
+
+
+def test_lds_program_refuses_a_field_that_is_not_gf2():
+    ev = zk.Evaluator.from_messages(golden_buffers('arith_101_correct'))
+    ev.finalize()
+    with pytest.raises(zk.ZkGpuError):
+        ev.lds_program()

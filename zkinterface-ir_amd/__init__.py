@@ -82,6 +82,7 @@ def lib():
         'zkgpu_n_witness': (u32, [vp]),
         'zkgpu_schedule_info': (ci, [vp, u64p]),
         'zkgpu_schedule_dump': (ci, [vp, vp, vp, vp, vp]),
+        'zkgpu_lds_program': (ci, [vp, u32, u64p, vp, vp, vp, vp]),
         'zkgpu_set_inputs': (ci, [vp, vp, vp, u32]),
         'zkgpu_set_inputs_device': (ci, [vp, vp, vp, u32]),
         'zkgpu_set_inputs_from_messages': (ci, [vp]),
@@ -367,6 +368,23 @@ class Evaluator:
         self._ck(self.L.zkgpu_schedule_dump(self.h, ops.ctypes.data, launches.ctypes.data, consts.ctypes.data,
                                             slot_of.ctypes.data))
         return ops, launches, consts[:info['const_words']], slot_of[:self.L.zkgpu_tape_len(self.h)]
+
+    def lds_program(self, block_rows=0):
+        """GF(2): the program of the LDS-resident kernel for this schedule (host work, no GPU): dict with `ops8`
+        [n][4] u16 {dst, a, b, kind}, `rows` u16 stream, `blocks` [n][2] u32, `chunks` [n][4] u32, `block_rows`,
+        `table_words` (csrc/device/lds_layout.hpp)."""
+        import numpy as np
+        sizes = (ctypes.c_uint64 * 6)()
+        self._ck(self.L.zkgpu_lds_program(self.h, block_rows, sizes, None, None, None, None))
+        n_ops, n_rows, n_blocks, n_chunks, br, words = [int(x) for x in sizes]
+        ops8 = np.zeros((max(n_ops, 1), 4), dtype=np.uint16)
+        rows = np.zeros(max(n_rows, 1), dtype=np.uint16)
+        blocks = np.zeros((max(n_blocks, 1), 2), dtype=np.uint32)
+        chunks = np.zeros((max(n_chunks, 1), 4), dtype=np.uint32)
+        self._ck(self.L.zkgpu_lds_program(self.h, block_rows, sizes, ops8.ctypes.data, rows.ctypes.data, blocks.ctypes.data,
+                                          chunks.ctypes.data))
+        return {'ops8': ops8[:n_ops], 'rows': rows[:n_rows], 'blocks': blocks[:n_blocks], 'chunks': chunks[:n_chunks],
+                'block_rows': br, 'table_words': words}
 
     def set_inputs(self, instances, witnesses, batch):
         """instances / witnesses: bytes-like of [batch][n][elem_bytes] (or None when n == 0), or the integer address

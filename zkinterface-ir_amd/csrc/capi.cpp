@@ -14,6 +14,7 @@
 
 #include "../../include/zkgpu.h"
 #include "engine.hpp"
+#include "lds_program.hpp"
 #include "evaluator.hpp"
 #include "r1cs.hpp"
 #include "schedule.hpp"
@@ -812,6 +813,24 @@ int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]) {
   out[6] = s->sched.const_words.size();
   out[7] = s->sched.words_per_const;
   return 0;
+}
+
+int zkgpu_lds_program(zkgpu_session* s, uint32_t block_rows, uint64_t sizes[6], uint16_t* ops8, uint16_t* rows,
+                      uint32_t* blocks, uint32_t* chunks) {
+  return guarded(s, [&] {
+    if (!s->finalized) throw std::runtime_error("zkgpu_finalize() has not been called");
+    if (!s->backend.field().is_two) throw std::runtime_error("the LDS-resident kernel runs GF(2) relations only");
+    if (!lds_program_fits(s->sched)) throw std::runtime_error("the relation does not fit the LDS-resident GF(2) kernel");
+    const LdsProgram P = build_lds_program(s->sched, {4, 6, 8, 9, 10, 12}, block_rows);
+    if (sizes) {
+      const uint64_t v[6] = {P.ops.size(), P.rows.size(), P.blocks.size() / 2, P.chunks.size() / 4, P.block_rows, P.n_slots};
+      memcpy(sizes, v, sizeof v);
+    }
+    if (ops8 && !P.ops.empty()) memcpy(ops8, P.ops.data(), P.ops.size() * sizeof(zkgpu::LdsOp));
+    if (rows && !P.rows.empty()) memcpy(rows, P.rows.data(), P.rows.size() * 2);
+    if (blocks && !P.blocks.empty()) memcpy(blocks, P.blocks.data(), P.blocks.size() * 4);
+    if (chunks && !P.chunks.empty()) memcpy(chunks, P.chunks.data(), P.chunks.size() * 4);
+  });
 }
 
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lds_layout.hpp"
+
 namespace zkgpu {
 
 typedef uint32_t u32;
@@ -117,24 +119,7 @@ struct BoolReplayArgs {
   u32* first_fail;
 };
 
-struct LdsOp {  // 8-byte program entry; wide fields are split over the halves that the kind leaves unused
-  unsigned short dst, a, b, kind;
-};
-
-// The program of the LDS-resident kernel.  chunk = {first, rows, kind | barrier_after << 8 | sequential << 9 |
-// blocks << 10, run}.  A generic chunk (inputs, constants, asserts, sequential segments) holds 8-byte entries: `first`
-// indexes `ops`.  A chunk with bit 10 set is a run of `run` BLOCKS starting at block `first`: the xor / and / not /
-// copy ops of a level as rows of kLdsRowOps ops of one kind, 12 bytes per thread and row in `ops6`
-// (device/bool_kernels.hpp).  Block header (two u32 in `blocks`):
-//   { rows (1..block_rows) | barrier_after << 4 | (row r is xor) << (kLdsBlockKindShift + r) | (a + 1) << kLdsBlockAndShift
-//     when the block is full and its rows are `a` and-rows followed by xor-rows (0 otherwise),  byte offset of the block's first row in ops6 }
-// Rows know two kinds only, and / xor: `not a` is stored as a xor ONES and a copy as a xor ZERO, two constant slots
-// behind the kLdsScratchSlots scratch slots of the padding ops (the table holds n_slots + kLdsExtraSlots words).
-constexpr int kLdsRowOps = 2048;
-constexpr int kLdsMaxBlockRows = 12;   // block_rows: 4, 6, 8, 9, 10 or 12 (one kernel instantiation each)
-constexpr int kLdsBlockKindShift = 5, kLdsBlockAndShift = 17;
-constexpr u32 kLdsScratchSlots = 32, kLdsZeroSlot = 32, kLdsOnesSlot = 33, kLdsExtraSlots = 34;   // offsets past the real slots
-
+// (LdsOp, the chunk and block headers and the row constants of the LDS-resident kernel: lds_layout.hpp)
 struct BoolLdsArgs {
   const LdsOp* ops;         // generic chunks (inputs, constants, asserts, sequential segments): 8-byte entries
   const u32* ops6;          // rows: 12 bytes per thread and row (two ops of three u16 each)

@@ -11,6 +11,7 @@
 
 #include "device/args.hpp"
 #include "engine.hpp"
+#include "lds_program.hpp"
 
 namespace zki {
 namespace {
@@ -348,157 +349,19 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   constexpr uint32_t kLdsBytes = 160 * 1024;
   lds_path_ = false;
   if (boolean_ && bool_path_ != 1) {
-    const bool fits = ((uint64_t)s.n_slots + zkgpu::kLdsExtraSlots) * 4 + 64 <= kLdsBytes &&
-                      s.n_slots + zkgpu::kLdsExtraSlots < 0xFFFF &&   // + scratch and constant slots
-                      (uint64_t)s.ops.size() * 6 + s.launches.size() * 24576ull + (1u << 22) < (1ull << 32);   // block headers carry 32-bit byte offsets into the row stream
-    if (fits) {
-      // program of the LDS kernel (device/args.hpp): generic chunks of 8-byte entries, and for the xor / and / not /
-      // copy ops of a level rows of 2048 ops of one kind, gathered into blocks of <= block_rows rows
-      auto encode = [](const DevOp& d) {
-        zkgpu::LdsOp o;
-        o.kind = (unsigned short)d.kind;
-        o.dst = (unsigned short)d.dst;
-        o.a = (unsigned short)d.a;
-        o.b = (unsigned short)d.b;
-        if (d.kind == zkgpu::OP_INSTANCE || d.kind == zkgpu::OP_WITNESS) {  // 32-bit position in a | b << 16
-          o.a = (unsigned short)(d.a & 0xFFFF);
-          o.b = (unsigned short)(d.a >> 16);
-        } else if (d.kind == zkgpu::OP_ASSERT) {                            // 32-bit sequence in dst | b << 16
-          o.dst = (unsigned short)(d.b & 0xFFFF);
-          o.b = (unsigned short)(d.b >> 16);
-        } else if (d.kind == zkgpu::OP_CONST && d.a > 0xFFFF) {
-          throw std::runtime_error("Engine: too many constants for the LDS program encoding");
-        }
-        return o;
-      };
-      // rows know and / xor only: `not a` = a xor ONES, copy = a xor ZERO (constant slots behind the scratch slots)
-      auto row_kind = [](uint32_t kind) -> int {   // 1 xor, 0 and, -1 not a row kind
-        switch (kind) {
-          case zkgpu::OP_XOR: case zkgpu::OP_NOT: case zkgpu::OP_COPY: return 1;
-          case zkgpu::OP_AND: return 0;
-          default: return -1;
-        }
-      };
-      std::vector<zkgpu::LdsOp> lo;
-      std::vector<unsigned short> lo6;   // rows: u16 {dst, a, b} per op
-      std::vector<uint32_t> blocks;      // block headers {descriptor, byte offset of the first row}
-      std::vector<uint32_t> ln;          // chunks
-      lo.reserve(s.ops.size() / 8 + 4096);
-      lo6.reserve(s.ops.size() * 3 + 3 * 4096 * s.launches.size());
-      const unsigned short scratch = (unsigned short)s.n_slots;  // extra slots: targets of the padding ops
-      // Rows per block: every block fetches that many rows of the stream whatever it holds (the kernel counts its
-      // loads), and the fetch is what bounds the kernel -- pick the size that fetches least for this program (C4: a
-      // level is 9 rows; 12-row blocks would fetch a third more).  A block costs about a row of time by itself.
-      uint32_t block_rows = zkgpu::kLdsMaxBlockRows;
-      {
-        std::vector<uint32_t> level_rows;   // rows of every maximal sequence of xor / and / not / copy rows
-        for (const Launch& L : s.launches) {
-          if (L.sequential) continue;
-          uint32_t k = 0, open = 0;
-          while (k < L.count) {
-            const uint32_t kind = s.ops[L.first + k].kind;
-            uint32_t e = k;
-            while (e < L.count && s.ops[L.first + e].kind == kind) ++e;
-            if (row_kind(kind) >= 0) {
-              open += (e - k + zkgpu::kLdsRowOps - 1) / zkgpu::kLdsRowOps;
-            } else if (open) {
-              level_rows.push_back(open);
-              open = 0;
-            }
-            k = e;
-          }
-          if (open) level_rows.push_back(open);
-        }
-        uint64_t best = ~0ull;
-        for (uint32_t br = 3; br <= (uint32_t)zkgpu::kLdsMaxBlockRows; ++br) {
-          if (!zkgpu::bool_lds_has_block_rows(br)) continue;
-          uint64_t cost = 0;
-          for (uint32_t n : level_rows) cost += (uint64_t)((n + br - 1) / br) * (br + 1);
-          if (cost < best) {
-            best = cost;
-            block_rows = br;
-          }
-        }
-      }
-      if (const char* br = getenv("ZKGPU_LDS_BLOCK_ROWS"))   // tuning experiments (tools/c4_diag.py)
-        if (zkgpu::bool_lds_has_block_rows((uint32_t)atoi(br))) block_rows = (uint32_t)atoi(br);
-      lds_block_rows_ = block_rows;
-      std::vector<uint32_t> open_kinds;
-      uint32_t open_first = 0;
-      auto close_blocks = [&](bool barrier) {
-        for (size_t r = 0; r < open_kinds.size(); r += block_rows) {
-          const size_t n = std::min<size_t>(block_rows, open_kinds.size() - r);
-          uint32_t desc = (uint32_t)n;
-          for (size_t j = 0; j < n; ++j) desc |= open_kinds[r + j] << (zkgpu::kLdsBlockKindShift + j);
-          if (barrier && r + n >= open_kinds.size()) desc |= 1u << 4;
-          {   // a full block of `a` and-rows followed by xor-rows?
-            size_t a = 0;
-            while (a < n && open_kinds[r + a] == 0) ++a;
-            bool sorted = true;
-            for (size_t j = a; j < n; ++j) sorted = sorted && open_kinds[r + j] == 1;
-            if (sorted && n == block_rows) desc |= (uint32_t)(a + 1) << zkgpu::kLdsBlockAndShift;   // full blocks only
-          }
-          const uint32_t id = (uint32_t)(blocks.size() / 2);
-          blocks.push_back(desc);
-          blocks.push_back((open_first + (uint32_t)r * 1024u) * 12u);   // byte offset (the stream is far below 4 GiB)
-          // consecutive blocks form one run (one chunk)
-          if (ln.size() >= 4 && ((ln[ln.size() - 2] >> 10) & 1) && ln[ln.size() - 4] + ln[ln.size() - 1] == id)
-            ++ln[ln.size() - 1];
-          else
-            ln.insert(ln.end(), {id, 0u, 1u << 10, 1u});
-        }
-        open_kinds.clear();
-      };
-      for (const Launch& L : s.launches) {
-        if (L.sequential) {
-          const uint32_t first = (uint32_t)lo.size();
-          for (uint32_t k = 0; k < L.count; ++k) lo.push_back(encode(s.ops[L.first + k]));
-          ln.insert(ln.end(), {first, L.count, (1u << 9) | (1u << 8), 0u});
-          continue;
-        }
-        // ops of a level arrive sorted by kind (schedule.cpp): whole rows per kind
-        uint32_t k = 0;
-        while (k < L.count) {
-          const uint32_t kind = s.ops[L.first + k].kind;
-          uint32_t e = k;
-          while (e < L.count && s.ops[L.first + e].kind == kind) ++e;
-          const bool last_kind = e >= L.count;
-          const int rk = row_kind(kind);
-          if (rk >= 0) {
-            if (open_kinds.empty()) open_first = (uint32_t)(lo6.size() / 6);   // in 12-byte thread records
-            size_t n = 0;
-            auto put6 = [&](unsigned short dst, unsigned short a, unsigned short b) {
-              lo6.push_back(dst);
-              lo6.push_back(a);
-              lo6.push_back(b);
-              ++n;
-            };
-            const unsigned short zero = (unsigned short)(scratch + zkgpu::kLdsZeroSlot), ones = (unsigned short)(scratch + zkgpu::kLdsOnesSlot);
-            for (uint32_t q = k; q < e; ++q) {
-              const zkgpu::LdsOp o = encode(s.ops[L.first + q]);
-              put6(o.dst, o.a, kind == zkgpu::OP_NOT ? ones : kind == zkgpu::OP_COPY ? zero : o.b);
-            }
-            // padding ops write 32 scratch slots, one per bank and lane group (the op at position n runs on lane
-            // (n / 2) % 64): 32 lanes storing to ONE address would serialise in the LDS
-            while (n % zkgpu::kLdsRowOps) put6((unsigned short)(scratch + (n / 2) % zkgpu::kLdsScratchSlots), zero, zero);
-            for (size_t r = 0; r < n / zkgpu::kLdsRowOps; ++r) open_kinds.push_back((uint32_t)rk);
-            if (last_kind) close_blocks(true);
-          } else {
-            close_blocks(false);   // rows so far run before this kind's chunk (same level: no barrier needed)
-            const zkgpu::LdsOp pad{scratch, 0, 0, (unsigned short)zkgpu::OP_NOP};
-            if (lo.size() & 1) lo.push_back(pad);  // 16-B aligned rows
-            const uint32_t first = (uint32_t)lo.size();
-            for (uint32_t q = k; q < e; ++q) lo.push_back(encode(s.ops[L.first + q]));
-            while ((lo.size() - first) % zkgpu::kLdsRowOps) lo.push_back(pad);
-            const uint32_t rows = ((uint32_t)lo.size() - first) / zkgpu::kLdsRowOps;
-            ln.insert(ln.end(), {first, rows, kind | ((last_kind ? 1u : 0u) << 8), 0u});
-          }
-          k = e;
-        }
-      }
+    if (lds_program_fits(s)) {
+      // the program of the LDS kernel is host work (lds_program.cpp); here it is only uploaded
+      std::vector<uint32_t> sizes;
+      for (uint32_t br = 1; br <= (uint32_t)zkgpu::kLdsMaxBlockRows; ++br)
+        if (zkgpu::bool_lds_has_block_rows(br)) sizes.push_back(br);
+      const char* forced = getenv("ZKGPU_LDS_BLOCK_ROWS");   // tuning experiments (tools/c4_diag.py) and the block-shape test
+      const LdsProgram P = build_lds_program(s, sizes, forced ? (uint32_t)atoi(forced) : 0u);
+      lds_block_rows_ = P.block_rows;
+      const std::vector<zkgpu::LdsOp>& lo = P.ops;
+      const std::vector<uint16_t>& lo6 = P.rows;
+      const std::vector<uint32_t>& blocks = P.blocks;
+      const std::vector<uint32_t>& ln = P.chunks;
       n_lds_chunks_ = (uint32_t)(ln.size() / 4);
-      // every block fetches block_rows rows whatever it holds: keep the rows past the last one inside the allocation
-      lo6.insert(lo6.end(), (size_t)block_rows * zkgpu::kLdsRowOps * 3, scratch);
       dfree(d_lds_blocks_);
       HIP_OK(hipMalloc(&d_lds_blocks_, std::max<size_t>(blocks.size() * 4, 64)));
       if (!blocks.empty()) HIP_OK(hipMemcpy(d_lds_blocks_, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice));
