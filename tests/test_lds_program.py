@@ -8,7 +8,7 @@ import pytest
 
 import cpu_checkers
 import zkinterface_ir_amd as zk
-from helpers import golden_buffers
+from helpers import golden_buffers, oracle_lane
 from oracle_lib import OracleRun
 from zkinterface_ir_amd import workloads
 
@@ -52,10 +52,18 @@ def interpret(prog, consts, inst_bits, wit_bits):
                 if (nz >> lane) & 1:
                     first[lane] = min(first[lane], seq)
 
+    # a level = everything up to a barrier (a block with bit 4, a generic chunk with bit 8): it may hold blocks AND
+    # generic chunks (a level's inputs / constants sit between its copy rows and its and / xor rows)
+    level_reads, level_writes = set(), set()
+
+    def end_of_level():
+        assert not (level_reads & level_writes), 'a level reads a slot it writes: its ops are not independent'
+        level_reads.clear()
+        level_writes.clear()
+
     for first_w, nrows, flags, run in prog['chunks']:
         first_w, nrows, flags, run = int(first_w), int(nrows), int(flags), int(run)
         if flags & (1 << 10):
-            level_reads, level_writes = set(), set()
             for blk in range(first_w, first_w + run):
                 desc, off = int(blocks[blk, 0]), int(blocks[blk, 1])
                 n = desc & 15
@@ -80,15 +88,26 @@ def interpret(prog, consts, inst_bits, wit_bits):
                     T[real + 32] = 0
                     T[real + 33] = 0xFFFFFFFF              # (padding ops only ever write the 32 scratch slots)
                 if desc & 16:
-                    assert not (level_reads & level_writes), 'a level reads a slot it writes: the rows are not independent'
-                    level_reads, level_writes = set(), set()
-            assert not level_reads or (int(blocks[first_w + run - 1, 0]) & 16), 'a run ends inside a level'
+                    end_of_level()
         elif flags & (1 << 9):
-            for e in ops8[first_w: first_w + nrows]:
+            assert flags & (1 << 8)
+            end_of_level()                                 # (the chunk before ended its level)
+            for e in ops8[first_w: first_w + nrows]:       # one thread, in order: a dependent segment
                 exec_entry(e)
         else:
             for e in ops8[first_w: first_w + nrows * ROW]:
+                dst, a, b, kind = (int(x) for x in e)
+                if kind in (K_XOR, K_AND, K_NOT, K_COPY, K_ASSERT):
+                    level_reads.add(a)
+                    if kind in (K_XOR, K_AND):
+                        level_reads.add(b)
+                if kind in (K_XOR, K_AND, K_NOT, K_COPY, K_CONST, K_INSTANCE, K_WITNESS) and dst < real:
+                    assert dst not in level_writes, 'two ops of a level write one slot'
+                    level_writes.add(dst)
                 exec_entry(e)
+            if flags & (1 << 8):
+                end_of_level()
+    assert not level_reads and not level_writes, 'the program ends inside a level'
     return first[:lanes]
 
 
@@ -135,6 +154,34 @@ def test_lds_program_of_the_reference_examples(name):
     _, _, consts, _ = ev.schedule_dump()
     got = interpret(ev.lds_program(), consts, inst, wit)
     assert (int(got[0]) == NO_FAIL) == (ref.violations == [])
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_lds_program_of_random_structured_boolean_relations(seed):
+    """functions / for / switch / frees over GF(2) (the generator of the CPU- and GPU-tier fuzz): mostly sequential
+    segments and short rows, copies and constants -- which lanes fail, and at which assert first, against the oracle"""
+    from random_circuits import Gen
+    g = Gen(1000 + seed, 2, True)
+    rel, mod_le = g.relation(n_top=14)
+    lanes = 9
+    rows_i, rows_w = g.lane_inputs(lanes, seed + 77)
+    ev = zk.Evaluator()
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    ev.ingest_message(rel)
+    ev.finalize()
+    inst = np.array(rows_i, dtype=np.uint8).reshape(lanes, -1)
+    wit = np.array(rows_w, dtype=np.uint8).reshape(lanes, -1)
+    _, _, consts, _ = ev.schedule_dump()
+    got = interpret(ev.lds_program([0, 4, 12][seed % 3]), consts, inst, wit)
+    asserts = ev.assert_wires()
+    for lane in range(lanes):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32, trace=False)
+        if not ref.violations:
+            assert int(got[lane]) == NO_FAIL, (seed, lane)
+        else:
+            assert int(got[lane]) != NO_FAIL, (seed, lane)
+            # the reference names the first failing wire
+            assert ref.violations[0].startswith('Wire_%d ' % asserts[int(got[lane])]), (seed, lane)
 
 
 def test_lds_program_refuses_a_field_that_is_not_gf2():
