@@ -21,8 +21,9 @@ def run_bench(*args, timeout=600):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + [str(a) for a in args], env=env,
                          capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-4000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, out.stdout      # rank 0 prints ONE line
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout      # stdout carries ONE line: rank 0's JSON
+    # (library chatter -- gloo announces its peers on stdout -- is sent to stderr)
     return json.loads(lines[0])
 
 
