@@ -210,11 +210,10 @@ template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1)
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
 #define ZKGPU_SDWA_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
 
-// The kernel is bound by instruction issue (a wave gets one slot every four cycles, and the 16 waves of the workgroup
-// fill every SIMD's slots): a row step is ONE asm statement, so that nothing but what is written here is issued --
-// 8 VALU (six address shifts, two gates), 6 LDS, 1 VMEM, and 3.5 scalar (a vmcnt wait every other row, the lgkmcnt wait,
-// s_bitcmp1 + one taken branch for and / xor).  What hipcc makes of a C++ if-chain over the row kind is a dozen scalar
-// instructions and up to five branches per row; between asm statements it also puts hazard nops and address adds.
+// The kernel is bound by instruction issue (a SIMD hands out one slot every four cycles and the 16 waves of the
+// workgroup fill them): a row step is two asm statements holding nothing but 8 VALU (six address shifts, two gates),
+// 6 LDS, 1 VMEM and the waits (vmcnt every other row, lgkmcnt every row).  What hipcc makes of a C++ if-chain over the
+// row kind is a dozen scalar instructions and up to five branches per row, and between statements it puts address adds.
 template <int BR, int R>   // issue the four operand reads of row R (block start: rows 0 .. kLdsAhead - 1)
 __device__ __forceinline__ void ldsp_read() {
   constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
@@ -236,9 +235,8 @@ __device__ __forceinline__ void ldsp_wait_row() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - kLdsAhead) : "memory");
 }
 // A statement that DEFINES a register (an output, a clobbered flag) makes hipcc put an s_nop behind it on gfx940+ (it
-// cannot see inside and assumes a forwarding hazard): the steps therefore define nothing -- their four temporaries are
-// registers of the hand-managed range (kRegT), and the and / xor decision is an `if` in C++ around two statements, which
-// hipcc turns into s_bitcmp1 + one branch.
+// cannot see inside and assumes a forwarding hazard): the steps define nothing -- their four temporaries are registers
+// of the hand-managed range (kRegT) -- except the one form that decides and / xor at run time (it clobbers scc).
 #define ZKGPU_LDS_STEP_DST                                           \
   "v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[px]]" ZKGPU_SDWA_LO      \
   "v_lshlrev_b32_sdwa v[%[t1]], %[two], v[%[py]]" ZKGPU_SDWA_HI
