@@ -200,8 +200,9 @@ ZKGPU_DECLARE_WIDTH(12)
 
 void launch_verdict(dim3 grid, hipStream_t st, const u32* first_fail, const u32* lane_flags, u32 batch,
                     unsigned long long* counts);
-void launch_pack_inputs(dim3 grid, hipStream_t st, const uint8_t* raw, u32 n_vals, u32 batch, u32 total_words,
-                        u64* packed, u32* lane_flags, const uint8_t* strict);
+void launch_pack_inputs(hipStream_t st, const uint8_t* inst, u32 n_inst, const uint8_t* strict_inst, u64* packed_inst,
+                        const uint8_t* wit, u32 n_wit, const uint8_t* strict_wit, u64* packed_wit, u32 batch, u32 total_words,
+                        u32* lane_flags);
 void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a);
 hipError_t bool_lds_set_max_shared(int bytes);
 bool bool_lds_has_block_rows(u32 rows);

@@ -40,9 +40,21 @@ __global__ __launch_bounds__(256) void verdict_kernel(const u32* __restrict__ fi
 // wave ballot, and lane b keeps / stores the word of position k + b: one store per 16 positions.
 // strict[k] != 0: a value > 1 at position k flags the lane (it would reach assert_zero / not unreduced, see
 // schedule.cpp mark_strict_sources); elsewhere the low bit is the residue and that is all and / xor ever look at.
-__global__ __launch_bounds__(256) void pack_inputs_kernel(const uint8_t* __restrict__ raw, u32 n_vals, u32 batch,
-                                                          u32 total_words, u64* __restrict__ packed,
-                                                          u32* __restrict__ lane_flags, const uint8_t* __restrict__ strict) {
+// One launch packs both streams: blockIdx.z = 0 the instances, 1 the witnesses (grid.y covers the longer of the two).
+struct PackArgs {
+  const uint8_t* raw[2];
+  const uint8_t* strict[2];
+  u64* packed[2];
+  u32 n_vals[2];
+};
+__global__ __launch_bounds__(256) void pack_inputs_kernel(const PackArgs pa, u32 batch, u32 total_words,
+                                                          u32* __restrict__ lane_flags) {
+  const u32 z = blockIdx.z;
+  const uint8_t* __restrict__ raw = pa.raw[z];
+  const uint8_t* __restrict__ strict = pa.strict[z];
+  u64* __restrict__ packed = pa.packed[z];
+  const u32 n_vals = pa.n_vals[z];
+  if (blockIdx.y * 256 >= n_vals) return;
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   const u32 word = blockIdx.x * (blockDim.x >> 6) + wave;

@@ -728,12 +728,10 @@ void Engine::enqueue_replay(bool time_each_launch) {
   HIP_OK(hipMemsetAsync(d_counts_, 0, 16, st));
   if (boolean_) {
     const uint32_t words = lane_blocks_ * 64;
-    if (n_inst_)
-      zkgpu::launch_pack_inputs(dim3((words + 3) / 4, (n_inst_ + 255) / 256), st, (const uint8_t*)d_inst_, n_inst_, batch_,
-                                words, (zkgpu::u64*)d_packed_inst_, (zkgpu::u32*)d_flags_, (const uint8_t*)d_strict_inst_);
-    if (n_wit_)
-      zkgpu::launch_pack_inputs(dim3((words + 3) / 4, (n_wit_ + 255) / 256), st, (const uint8_t*)d_wit_, n_wit_, batch_,
-                                words, (zkgpu::u64*)d_packed_wit_, (zkgpu::u32*)d_flags_, (const uint8_t*)d_strict_wit_);
+    // both streams in one launch (blockIdx.z)
+    zkgpu::launch_pack_inputs(st, (const uint8_t*)d_inst_, n_inst_, (const uint8_t*)d_strict_inst_, (zkgpu::u64*)d_packed_inst_,
+                              (const uint8_t*)d_wit_, n_wit_, (const uint8_t*)d_strict_wit_, (zkgpu::u64*)d_packed_wit_, batch_,
+                              words, (zkgpu::u32*)d_flags_);
   }
   if (lds_path_) {
     zkgpu::BoolLdsArgs a;

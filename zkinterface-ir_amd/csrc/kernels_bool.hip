@@ -8,9 +8,15 @@ void launch_verdict(dim3 grid, hipStream_t st, const u32* first_fail, const u32*
   verdict_kernel<<<grid, 256, 0, st>>>(first_fail, lane_flags, batch, counts);
 }
 
-void launch_pack_inputs(dim3 grid, hipStream_t st, const uint8_t* raw, u32 n_vals, u32 batch, u32 total_words,
-                        u64* packed, u32* lane_flags, const uint8_t* strict) {
-  pack_inputs_kernel<<<grid, 256, 0, st>>>(raw, n_vals, batch, total_words, packed, lane_flags, strict);
+void launch_pack_inputs(hipStream_t st, const uint8_t* inst, u32 n_inst, const uint8_t* strict_inst, u64* packed_inst,
+                        const uint8_t* wit, u32 n_wit, const uint8_t* strict_wit, u64* packed_wit, u32 batch, u32 total_words,
+                        u32* lane_flags) {
+  PackArgs pa;
+  pa.raw[0] = inst;   pa.strict[0] = strict_inst;   pa.packed[0] = packed_inst;   pa.n_vals[0] = n_inst;
+  pa.raw[1] = wit;    pa.strict[1] = strict_wit;    pa.packed[1] = packed_wit;    pa.n_vals[1] = n_wit;
+  const u32 longest = n_inst > n_wit ? n_inst : n_wit;
+  if (!longest) return;
+  pack_inputs_kernel<<<dim3((total_words + 3) / 4, (longest + 255) / 256, 2), 256, 0, st>>>(pa, batch, total_words, lane_flags);
 }
 
 void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a) {
