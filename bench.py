@@ -426,8 +426,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    entry.build() if not os.path.exists(os.path.join(entry.PKG_DIR, 'lib', 'libzkgpu.so')) else None
-    zk = entry.load_package()
+    zk = entry.ensure_built()   # rebuilds when any source differs from what lib/libzkgpu.so was built from
     from zkinterface_ir_amd import workloads
 
     if args.workload == 'c5':

@@ -66,3 +66,17 @@ def test_evaluator_template_runs_as_verifier_with_a_stub_backend(tmp_path):
     out = subprocess.check_output([exe, str(tmp_path / 'i.sieve'), str(tmp_path / 'r.sieve')], text=True)
     # same backend-call count as the plaintext run (277 value calls, 6 asserts); all 6 witnesses absent
     assert out.strip() == 'calls 277 asserts 6 witnesses_without_value 6 violations 0'
+
+
+def test_library_is_built_from_the_sources_in_the_tree():
+    """lib/libzkgpu.so is git-ignored but travels to the GPU box: __graft_entry__.build() records a digest of the
+    sources it compiled, smoke() / bench.py rebuild when it differs (ensure_built), and no tier tests a stale library"""
+    import __graft_entry__ as entry
+    assert entry.library_is_current(), 'lib/libzkgpu.so was not built from these sources: run __graft_entry__.build()'
+    subprocess.check_call(['make', '-q', '-C', entry.PKG_DIR])      # nothing left for make to do
+
+
+@pytest.mark.gpu
+def test_library_on_the_gpu_box_is_built_from_the_sources_in_the_tree():
+    import __graft_entry__ as entry
+    assert entry.library_is_current()
