@@ -11,11 +11,24 @@ checks, the verdict reduction) and, for N > 1, the RCCL all-reduce of the
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+The default invocation (one GPU, C2) also measures the other three workloads -- BASELINE configs[3] (C4, GF(2)),
+configs[4] (C5, R1CS rows) and the structured For / Call / Switch relation -- and prints them under `secondary`, each
+with its own `roofline` and `cpu_baseline` (bounded samples; `--no-secondary` skips them).
+
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child processes, started
 before anything in this process touches the GPU); rank 0 prints the JSON line.  With fewer than N devices visible
 the ranks share the card and the count reduction runs over gloo (rehearsal of the same sharding; the line says so).
+
+Numbers in the line and where they come from:
+  * every time is measured in this run (wall clock around the timed steps; HIP events on the engine's stream for the
+    kernel time of a replay);
+  * every byte / instruction count that needs hardware counters comes from the committed `--pmc` passes of this same
+    command (profiles/binding_<workload>.json, written by tools/binding_evidence.py) and is only used when the program
+    it was counted on is the program that ran (same entries, same launches); every rate and fraction is computed here
+    from those counts and this run's times, so no figure appears twice with two values.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -38,31 +51,43 @@ BYTES_PER_OP_BOOL = {1: 0.375, 2: 0.375, 10: 0.375, 11: 0.375, 3: 0.25, 4: 0.25,
                      7: 1.125, 8: 1.125,            # one input byte read + one bit written
                      9: 0.125}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'pmc_traffic_latest.json')
 
 
-def pmc_traffic(width, batch, nwords_bytes, workload='c2'):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same command; tools/pmc_traffic.py
-    applies the gfx950 corrections).  Only valid for the grid it was measured on (the default sizes)."""
-    path = PMC_TRAFFIC_JSON if workload == 'c2' else os.path.join(ROOT, 'profiles', 'pmc_traffic_%s.json' % workload)
+def binding_constants(workload, program):
+    """Counter-derived, time-independent facts about the dominant kernel of a workload (profiles/binding_<workload>.json,
+    tools/binding_evidence.py): bytes crossing L2<->fabric per launch, instructions per wave, VALU pipe time.  Only valid
+    for the program they were counted on: `program` = {entries, launches, batch, ...} of this run must match."""
     try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None, None
-    default = {'c2': (4096, 1024), 'c4': (16384, 4096), 'c5': (1 << 20, 1024)}[workload]
-    if d.get('workload') != workload or (width, batch) != default:
-        return None, None
-    return d['traffic_bytes_per_launch'], os.path.relpath(path, ROOT)
-
-
-def binding_evidence(workload):
-    """Which resource binds the dominant kernel and the counters that say so: profiles/binding_<workload>.json, written
-    by tools/collect_profiles.sh from the --pmc passes of this same command (None before the first collection)."""
-    try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'binding_%s.json' % workload)))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'binding_%s.json' % workload)))
     except (OSError, ValueError):
         return None
+    want = d.get('program') or {}
+    if any(want.get(k) != program.get(k) for k in want):
+        return None
+    return d
+
+
+def golden_hashes(name):
+    """tests/golden/<name>_all_lanes.json: one 64-bit hash of the output wires per lane, made by the CPU checkers that are
+    pinned to the oracle (tests/golden/make_all_lanes.py).  Data only; None when the file is absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'tests', 'golden', '%s_all_lanes.json' % name)))['hashes']
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def check_probe_outputs(name, wl, outs, lane_offset):
+    """The expected outputs the measured relation compares against come from a GPU probe pass (a different schedule and
+    kernel from the measured one).  For the default sizes every lane of them is checked here against the committed
+    oracle-chain hashes, so a wrong but self-consistent device result cannot pass.  Returns how many lanes were checked."""
+    hashes = golden_hashes(name)
+    default = (name == 'c2' and (wl.W, wl.D) == (4096, 256)) or (name == 'c4' and (wl.W, wl.D) == (16384, 640))
+    if hashes is None or not default or lane_offset + len(outs) > len(hashes):
+        return 0
+    for lane in range(len(outs)):
+        h = hashlib.sha256(np.ascontiguousarray(outs[lane], dtype=np.uint8).tobytes()).hexdigest()[:16]
+        assert h == hashes[lane + lane_offset], 'lane %d: probe outputs differ from tests/golden/%s_all_lanes.json' % (lane + lane_offset, name)
+    return len(outs)
 
 
 class _DevU64x2:
@@ -105,16 +130,21 @@ def first_verdict_seconds(zk, wl, msgs, inst, wit, batch, stream, pinned):
             'worker_busy_s': round(info['worker_busy_s'], 4), 'satisfied': counts[0]}
 
 
-def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, streams=2):
+def build_session(zk, name, wl, batch, lane_offset, lane_group, bool_path=None, streams=2):
     """probe pass for the expected outputs, then the real session with resident inputs"""
     t0 = time.time()
     if hasattr(wl, 'N'):   # StructuredArith: the expected values are a closed form, no probe pass
         inst, wit, n_bad = wl.inputs(batch, lane_offset)
-        return finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, time.time())
+        return finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, time.time(), 0)
     inst, wit = wl.inputs(batch, lane_offset)
+    # The probe runs the relation without its epilogue on ANOTHER schedule and kernel than the measured session: the
+    # unfused program (`replay_kernel`) for GF(p), the HBM-table kernel for GF(2) when the LDS-resident one is measured.
+    # (It also keeps the kernels of the timed steps the only launches of their name in a rocprofv3 trace of this command.)
     probe = zk.Evaluator()
     if bool_path:
-        probe.set_option('bool_path', bool_path)
+        probe.set_option('bool_path', 'hbm' if bool_path != 'hbm' else 'auto')
+    else:
+        probe.set_option('fuse', '0')
     probe.declare_inputs(wl.n_instance0, wl.n_witness)
     for m in wl.relation_messages(with_epilogue=False, free_last=False):
         probe.ingest_message(m)
@@ -130,35 +160,25 @@ def build_session(zk, wl, batch, lane_offset, lane_group, bool_path=None, stream
     if wl.p == 2:
         outs = outs[:, :, 0]
     probe.close()
+    pinned_lanes = check_probe_outputs(name, wl, outs, lane_offset)
     n_bad = wl.set_expected_outputs(inst, outs, lane_offset)
-    return finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, time.time())
+    return finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, time.time(), pinned_lanes)
 
 
-def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, t1):
+def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, t1, pinned_lanes):
     msgs = wl.relation_messages()
     t2 = time.time()
     ev = zk.Evaluator()
     if bool_path:
         ev.set_option('bool_path', bool_path)
     ev.set_option('streams', str(streams))
-    ev.set_option('stream', os.environ.get('ZKI_STREAM', '0'))
-    ev.set_option('fuse', os.environ.get('ZKI_FUSE', '1'))
-    if os.environ.get('ZKI_OPW'):
-        ev.set_option('level_ops_per_wave', os.environ['ZKI_OPW'])
-    if os.environ.get('ZKI_HOT_WAVES'):
-        ev.set_option('hot_waves', os.environ['ZKI_HOT_WAVES'])
-    if os.environ.get('ZKI_GRAPH'):
-        ev.set_option('graph', os.environ['ZKI_GRAPH'])
-    if os.environ.get('ZKI_XCD_MAP'):
-        ev.set_option('xcd_map', os.environ['ZKI_XCD_MAP'])
-    if os.environ.get('ZKI_SORT_BY_OPERAND'):
-        ev.set_option('sort_by_operand', os.environ['ZKI_SORT_BY_OPERAND'])
-    if os.environ.get('ZKI_STRAND_WIDTH'):
-        ev.set_option('strand_width', os.environ['ZKI_STRAND_WIDTH'])
-    if os.environ.get('ZKI_BANK_AWARE'):
-        ev.set_option('bank_aware', os.environ['ZKI_BANK_AWARE'])
-    if os.environ.get('ZKI_FERMAT'):
-        ev.set_option('fermat', os.environ['ZKI_FERMAT'])
+    # developer switches for A/B runs (profiles/*_tuning_sweeps.txt); the metric is quoted on the defaults
+    for env, opt in (('ZKI_STREAM', 'stream'), ('ZKI_FUSE', 'fuse'), ('ZKI_OPW', 'level_ops_per_wave'), ('ZKI_HOT_WAVES', 'hot_waves'),
+                     ('ZKI_GRAPH', 'graph'), ('ZKI_XCD_MAP', 'xcd_map'), ('ZKI_SORT_BY_OPERAND', 'sort_by_operand'),
+                     ('ZKI_STRAND_WIDTH', 'strand_width'), ('ZKI_BANK_AWARE', 'bank_aware'), ('ZKI_FERMAT', 'fermat'),
+                     ('ZKI_PAIR', 'pair')):
+        if os.environ.get(env):
+            ev.set_option(opt, os.environ[env])
     ev.declare_inputs(wl.n_instance, wl.n_witness)
     for m in msgs:
         ev.ingest_message(m)
@@ -171,11 +191,12 @@ def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_b
     ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
     t5 = time.time()
     host = {'probe_s': t1 - t0, 'emit_sieve_s': t2 - t1, 'ingest_and_record_s': t3 - t2, 'schedule_s': t4 - t3,
-            'h2d_s': t5 - t4, 'relation_bytes': sum(len(m) for m in msgs), 'messages': len(msgs)}
+            'h2d_s': t5 - t4, 'relation_bytes': sum(len(m) for m in msgs), 'messages': len(msgs),
+            'lanes_checked_against_golden_hashes': pinned_lanes}
     return ev, inst, wit, n_bad, msgs, host
 
 
-def cpu_baseline(wl, msgs, inst, wit, gates, ev=None):
+def cpu_baseline(wl, msgs, inst, wit, gates, ev=None, budget_s=15.0, with_opt=True):
     """The oracle (literal restatement of the reference Evaluator + PlaintextBackend) on this
     box's host cores, on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -186,11 +207,11 @@ def cpu_baseline(wl, msgs, inst, wit, gates, ev=None):
                                 wl.width, 1, 1)
     per_lane = max(one[1], 1e-3)
     threads = min(cores, 64)
-    lanes = int(min(inst.shape[0], max(threads, min(4 * threads, (15.0 / per_lane) * threads))))
+    lanes = int(min(inst.shape[0], max(threads, min(4 * threads, (budget_s / per_lane) * threads))))
     ok, secs, ops = oracle_lib.eval_batch(rel, wl.mod_le, inst[:lanes].tobytes(), wl.n_instance,
                                           wit[:lanes].tobytes(), wl.n_witness, wl.width, lanes, threads)
     extra = {}
-    if wl.p != 2 and ev is not None:
+    if wl.p != 2 and ev is not None and with_opt:
         # BASELINE.md section 3 `cpu_opt`: flat array + 64-bit Montgomery on the recorded tape, same threads
         kinds, a, b = ev.tape()
         opt_lanes = int(min(inst.shape[0], 16 * threads))
@@ -200,8 +221,7 @@ def cpu_baseline(wl, msgs, inst, wit, gates, ev=None):
         extra = {'cpu_opt': {'value': gates * opt_lanes / osecs, 'unit': 'gate-ops/s', 'cores': threads,
                              'what': 'optimised CPU evaluator (flat wire array, 4x64 Montgomery, flattened tape), '
                                      '%d witnesses in %.1f s' % (opt_lanes, osecs)}}
-    # the oracle's verdicts on the sample are the check of the GPU counts: the expected outputs the session was
-    # built with come from a GPU probe pass, so without this a wrong but self-consistent kernel would pass
+    # the oracle's verdicts on the sample are a second check of the GPU counts (the first: check_probe_outputs)
     from zkinterface_ir_amd import workloads
     want = workloads.expected_satisfied(lanes)
     assert int(sum(ok)) == want, 'oracle: %d of %d sample lanes satisfied, expected %d' % (int(sum(ok)), lanes, want)
@@ -214,11 +234,61 @@ def cpu_baseline(wl, msgs, inst, wit, gates, ev=None):
             'satisfied_in_sample': int(sum(ok))}
 
 
-def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda', dist_on=False):
+def make_roofline(workload, kernel, launches, kernel_ms_per_step, algo_bytes_per_step, program, streams=1):
+    """The `roofline` object of one line.
+
+    frac_algorithmic = SURVEY.md 8(d) bytes of the step / HIP-event time of the step / the HBM spec peak: the figure the
+    north star asks for.  It can exceed 1 (a schedule that keeps values in registers and an on-die cache move fewer bytes,
+    from a faster memory, than that accounting assumes), so it is not the roofline: `bound` names the resource the committed
+    counters show the kernel is limited by, and achieved / peak / frac (<= 1) are against THAT resource.  `resources` holds
+    every candidate with its own fraction; `bound` is the largest."""
+    step_s = kernel_ms_per_step * 1e-3
+    algo_gbs = algo_bytes_per_step / step_s / 1e9
+    res = {}
+    out = {'kernel': kernel, 'launches_per_step': launches, 'concurrent_streams': streams,
+           'avg_launch_ms': kernel_ms_per_step / max(launches, 1),
+           'algorithmic_bytes_per_launch': algo_bytes_per_step / max(launches, 1),
+           'achieved_algorithmic': algo_gbs, 'frac_algorithmic': algo_gbs / HBM_PEAK_GBS, 'traffic': None, 'traffic_source': None}
+    bc = binding_constants(workload, program)
+    c = (bc or {}).get('constants', {})
+    if c.get('traffic_bytes_per_launch') is not None:
+        per_step = c['traffic_bytes_per_launch'] * c.get('traffic_launches_per_step', launches)
+        gbs = per_step / step_s / 1e9
+        res[c.get('memory_side', 'hbm')] = {'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                                            'bytes_per_step': per_step, 'over_algorithmic': per_step / algo_bytes_per_step}
+        out['traffic'] = c['traffic_bytes_per_launch']
+        out['traffic_source'] = c.get('traffic_source')
+    if c.get('valu_pipe_ms_per_step') is not None:
+        res['valu'] = {'achieved': c['valu_pipe_ms_per_step'], 'peak': kernel_ms_per_step,
+                       'unit': 'ms of VALU pipe per step (counted instructions x the rates of profiles/r01_valu_rates.txt) over ms per step',
+                       'frac': c['valu_pipe_ms_per_step'] / kernel_ms_per_step, 'valu_insts_per_wave': c.get('valu_insts_per_wave')}
+    if c.get('issue_ms_per_step') is not None:
+        res['issue'] = {'achieved': c['issue_ms_per_step'], 'peak': kernel_ms_per_step,
+                        'unit': 'ms of instruction issue per step (counted instructions per wave x 4 waves per SIMD x 4 cycles at 2.4 GHz) over ms per step',
+                        'frac': c['issue_ms_per_step'] / kernel_ms_per_step, 'insts_per_wave': c.get('insts_per_wave')}
+    if not res:
+        # no counters for this program: the algorithmic figure against HBM is all there is
+        res['hbm_algorithmic'] = {'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS}
+    bound = max(res, key=lambda k: res[k]['frac'])
+    out.update({'bound': bound, 'achieved': res[bound]['achieved'], 'peak': res[bound]['peak'], 'unit': res[bound]['unit'],
+                'frac': res[bound]['frac'], 'resources': res})
+    if bc:
+        out['binding'] = bc.get('binding')
+        out['counters'] = {k: v for k, v in c.items() if k not in ('traffic_bytes_per_launch', 'traffic_source', 'valu_pipe_ms_per_step',
+                                                                   'issue_ms_per_step', 'memory_side', 'traffic_launches_per_step')}
+        out['reading'] = bc.get('reading')
+        out['sources'] = bc.get('sources')
+    else:
+        out['binding'] = 'not profiled for this program (no matching profiles/binding_%s.json)' % workload
+    return out
+
+
+def bench_c5(args, zk, workloads, ctx, steps, warmup, cpu_budget_s=15.0):
     """BASELINE configs[4]: 2^20-row R1CS over BN254 (3+3+1 terms per row), witness batch 1024 per GPU.
     step = the row check <a,w>*<b,w> = <c,w> of every row for every lane + the count reduction."""
-    M = args.width or (1 << 20)
-    batch = args.batch_per_gpu or 1024
+    world, rank, dist, torch, red_dev, dist_on = ctx['world'], ctx['rank'], ctx['dist'], ctx['torch'], ctx['red_dev'], ctx['dist_on']
+    M = (args.width or (1 << 20)) if args.workload == 'c5' else (1 << 20)
+    batch = (args.batch_per_gpu or 1024) if args.workload == 'c5' else 1024
     t0 = time.time()
     wl = workloads.R1csSynthetic(M=M)
     ev = zk.Evaluator()
@@ -254,14 +324,14 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda', dist
         ev.r1cs_check()
         return ev.r1cs_results(batch)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     ts = time.perf_counter()
     ms = []
-    for _ in range(args.steps):
+    for _ in range(steps):
         ff, counts = step()
         ms.append(ev.r1cs_last_ms)
     torch.cuda.synchronize()
@@ -277,50 +347,245 @@ def bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev='cuda', dist
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         elapsed = float(tm.item())
     assert total[0] == workloads.expected_satisfied(batch * world) and total[1] == batch * world - total[0], total
+    out = None
     if rank == 0:
-        bytes_per_launch = 7.0 * wl.width * M * batch
         kernel_ms = float(np.mean(ms))
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         out = {
             'metric': 'row-checks/sec (whole node), 1M-constraint R1CS over BN254, batched witnesses',
-            'value': n_rows * batch * world / (elapsed / args.steps), 'unit': 'row-checks/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps,
+            'value': n_rows * batch * world / (elapsed / steps), 'unit': 'row-checks/s', 'n_gpus': world,
+            'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed * 1e3 / steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u64x4 (GF(p) Montgomery limbs, exact integer)', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[4]: %d-row R1CS (3+3+1 terms, random coefficients) over BN254, '
                                    'witness batch=%d per GPU, %d GPU(s)' % (M, batch, world),
-                       'variables': wl.n_base + 1 + M, 'dependency_levels': wl.n_levels,
+                       'batch_per_gpu': batch, 'variables': wl.n_base + 1 + M, 'dependency_levels': wl.n_levels, 'rows': n_rows,
                        'wire_table_GB': round(ev.table_bytes / 1e9, 2), 'satisfied': total[0], 'failed': total[1],
                        'host_seconds': {'build_s': round(t1 - t0, 2), 'witness_generation_s': round(t2 - t1, 2)}},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(M, batch, wl.width, 'c5')[0],
-                         'traffic_source': pmc_traffic(M, batch, wl.width, 'c5')[1], 'kernel': 'r1cs_row_kernel<8, false>',
-                         'launches_per_step': 1, 'avg_launch_ms': kernel_ms,
-                         'algorithmic_bytes_per_launch': bytes_per_launch},
+            'roofline': make_roofline('c5', 'r1cs_row_kernel<8, false>', 1, kernel_ms, 7.0 * wl.width * M * batch,
+                                      {'entries': n_rows, 'launches': 1, 'batch': batch}),
         }
-        tr = out['roofline']['traffic']
-        if tr is not None:
-            out['roofline']['frac_traffic'] = tr / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        be = binding_evidence('c5')
-        if be:
-            out['roofline']['binding'] = be.get('binding')
-            out['roofline']['binding_evidence'] = be.get('evidence')
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             # the row check on the host cores for a bounded sample of the same lanes (oracle/cpu_opt.cpp:
             # the mathematical definition -- the reference itself holds no row checker)
             sys.path.insert(0, os.path.join(ROOT, 'tests'))
             import oracle_lib
             threads = min(os.cpu_count() or 1, 64)
-            sample = min(batch, 4 * threads)
+            sample = min(batch, max(threads, int(4 * threads * min(1.0, cpu_budget_s / 15.0))))
             ff_cpu, secs = oracle_lib.r1cs_check(row_ptr, tv, tc, cb, wl.mod_le, w[:sample], wl.n_base + 1 + M, M, threads)
             assert np.array_equal(ff_cpu, np.asarray(ff[:sample])), 'CPU row check disagrees with the GPU'
             out['cpu_baseline'] = {'value': n_rows * sample / secs, 'unit': 'row-checks/s', 'cores': threads, 'kind': 'port',
                                    'sample': '%d witnesses of the same %d-row system, 4x64 Montgomery row check on %d '
                                              'threads, %.1f s wall (witness generation excluded)' % (sample, n_rows, threads, secs)}
-        emit_json_line(out)
+    ev.close()
+    return out
+
+
+def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budget_s=15.0):
+    """C2 (headline), C4 and the structured relation: one step = one replay of the recorded tape over the batch.
+    `headline`: the workload the command line names (its size flags apply; the extras of the headline line are measured)."""
+    world, rank, dist, torch, red_dev, dist_on = ctx['world'], ctx['rank'], ctx['dist'], ctx['torch'], ctx['red_dev'], ctx['dist_on']
+    named = name == args.workload      # --width / --depth / --batch-per-gpu describe the workload named on the command line
+    width, depth, bpg = (args.width, args.depth, args.batch_per_gpu) if named else (0, 0, 0)
+    lane_group = args.lane_group if named else 0
+    if name == 'c2':
+        mp = os.environ.get('ZKI_C2_MUL_PERCENT')  # developer sensitivity runs only; the metric is quoted on the default mix
+        wl = workloads.ArithLayered(W=width or 4096, D=depth or 256, mul_percent=int(mp) if mp else None)
+        batch = bpg or 1024
+        bytes_table, bool_path = BYTES_PER_OP, None
+    elif name == 'structured':
+        wl = workloads.StructuredArith(N=width or 1408, chained=args.chained)
+        batch = bpg or 1024
+        bytes_table, bool_path = BYTES_PER_OP, None
+    else:
+        wl = workloads.BoolLayered(W=width or 16384, D=depth or 640,
+                                   wiring=os.environ.get('ZKI_C4_WIRING', 'random'))
+        batch = bpg or 4096
+        bytes_table, bool_path = BYTES_PER_OP_BOOL, args.bool_path
+    lane_offset = rank * batch
+    ev, inst, wit, n_bad, msgs, host = build_session(zk, name, wl, batch, lane_offset, lane_group, bool_path, args.streams)
+    kinds, _, _ = ev.tape()
+    # structured: the unit of work is one backend call of the reference's evaluator (every value-returning call it
+    # makes for one witness, ladders and scope copies included) -- what the CPU baseline executes call by call
+    gates = wl.n_gates if hasattr(wl, 'n_gates') else int((kinds != 9).sum())
+    algo_bytes_per_lane = float(sum(bytes_table.get(int(k), 0) * int(c) for k, c in zip(*np.unique(kinds, return_counts=True))))
+    info = ev.schedule_info()
+    structured = name == 'structured'
+    if structured:
+        # the bytes of the program that runs (one entry = one gate's reads and write; 13 = the `x != 0` entry a ladder
+        # became): the backend calls the rewrite removed -- scope copies, ladder products -- move no bytes at all
+        pk = ev.schedule_dump()[0][:, 1] & 0xFF
+        algo_bytes_per_lane = float(sum({**BYTES_PER_OP, 13: 64}.get(int(k), 0) * int(c) for k, c in zip(*np.unique(pk, return_counts=True))))
+    lds = name == 'c4' and ev.uses_lds_path()
+    wide_launches = 1 if lds else info['launches'] - info['sequential_launches']
+
+    counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if dist_on else None
+    reduced = torch.zeros(2, dtype=torch.int64, device=red_dev) if dist_on else None
+
+    def step():
+        ev.replay()
+        ev.synchronize()                # verdict words and counts are final on the engine's stream
+        if dist_on:
+            reduced.copy_(counts_t)     # 16 bytes out of the engine's counter words
+            dist.all_reduce(reduced)    # RCCL over xGMI: {satisfied, failed}
+            # the collective runs on RCCL's stream: finish it before the next replay resets the counters
+            torch.cuda.current_stream().synchronize()
+
+    for _ in range(warmup):
+        step()
+    ev.synchronize()
+    torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
-        dist.destroy_process_group()
+    t0 = time.perf_counter()
+    ev_ms = []
+    for _ in range(steps):
+        step()
+        ev_ms.append(ev.last_replay_ms)
+    ev.synchronize()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    ranks_seen = None
+    if dist_on:
+        total = reduced.cpu().tolist()
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # who took part, from the process group itself: every rank's lane share and its own (un-reduced) counts
+        own = ev.counts()
+        mine = {'rank': rank, 'lane_offset': lane_offset, 'lanes': batch, 'device': ctx['dev_index'],
+                'satisfied': int(own[0]), 'failed': int(own[1])}
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        ranks_seen = sorted(gathered, key=lambda r: r['rank'])
+    else:
+        total = list(ev.counts())
+    exp_sat = workloads.expected_satisfied(batch * world)
+    assert total[0] == exp_sat and total[0] + total[1] == batch * world, (total, exp_sat)
+    if ranks_seen is not None:
+        assert [r['rank'] for r in ranks_seen] == list(range(world)), ranks_seen
+        for r in ranks_seen:
+            assert r['satisfied'] == workloads.expected_satisfied(r['lanes'], r['lane_offset']), r
+    # PCIe-inclusive figure (never `value`): the boundary hands over host buffers every step
+    pcie_ms = None
+    if world == 1 and headline and not structured and not args.timed_steps_only:
+        # page-locked host buffers (what a streaming caller would use): the DMA engine reads them directly
+        pin_i = torch.from_numpy(np.ascontiguousarray(inst).reshape(-1)).pin_memory()
+        pin_w = torch.from_numpy(np.ascontiguousarray(wit).reshape(-1)).pin_memory()
+        ib, wb = pin_i.data_ptr(), pin_w.data_ptr()
+        ev.set_inputs(ib, wb, batch)
+        ev.replay()
+        ev.synchronize()
+        tp = time.perf_counter()
+        for _ in range(6):   # batch k+1 is handed over while batch k replays (two input sets, copy stream)
+            ev.set_inputs(ib, wb, batch)
+            ev.replay()
+        ev.synchronize()
+        pcie_ms = (time.perf_counter() - tp) * 1e3 / 6
+        assert list(ev.counts()) == total, (ev.counts(), total)   # the handed-over batches give the resident answer
+    first_verdict = None
+    if world == 1 and name == 'c2' and headline and not args.no_first_verdict:
+        first_verdict = {}
+        for key, stream, pinned in (('at_finalize', 0, False), ('streamed', 1, False), ('streamed_pinned_inputs', 1, True)):
+            runs = [first_verdict_seconds(zk, wl, msgs, inst, wit, batch, stream, pinned) for _ in range(3)]
+            best = min(runs, key=lambda r: r['total_s'])
+            assert best['satisfied'] == exp_sat
+            first_verdict[key] = best
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / steps
+        value = gates * batch * world / (elapsed / steps)
+        step_kernel_ms = float(np.mean(ev_ms))      # HIP events on the engine's stream around the replay
+        fused = info['device_ops'] < len(kinds)
+        if name == 'c2':
+            metric = 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses'
+            dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
+            wl_name = ('BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
+                       'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
+            kernel = 'replay_fused_kernel<8, 0>' if fused else 'replay_kernel<8, false, false>'
+        elif structured:
+            metric = ('backend-ops/sec (whole node), 256-bit field, For/Call/Switch relation of ~1M backend calls, batched '
+                      'witnesses (one unit = one value-returning ZKBackend call of the reference evaluator)')
+            dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
+            wl_name = ('structured%s: For over a named function with a nested call and a 2-case Switch, %d iterations, '
+                       'BN254 (shape of producers/examples.rs:72-212), witness batch=%d per GPU, %d GPU(s)'
+                       % (' (chained: each iteration reads the previous result)' if wl.chained else '', wl.N, batch, world))
+            kernel = 'replay_fused_kernel<8, 0> + <8, 1>' if fused else 'replay_kernel<8, false, false>'
+        else:
+            metric = 'gate-ops/sec (whole node), GF(2), 10M-gate And/Xor/Not relation, bit-packed batched witnesses'
+            dtype = 'u1 (GF(2), %d witnesses per word)' % (32 if lds else 64)
+            wl_name = ('BASELINE configs[3]: GF(2), %d-gate And/Xor/Not relation (W=%d x D=%d), witness batch=%d '
+                       'per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
+            kernel = 'bool_lds_kernel (wire table resident in LDS)' if lds else 'bool_replay_kernel'
+        program = {'entries': int(info['device_ops']), 'launches': int(info['launches']), 'batch': batch,
+                   'lane_group': lane_group}
+        roofline = make_roofline(name, kernel, max(wide_launches, 1), step_kernel_ms, algo_bytes_per_lane * batch, program,
+                                 1 if lds else args.streams)
+        if structured and 'counters' not in roofline:
+            roofline['binding'] = 'launch latency'
+            roofline['reading'] = ('%d launches of a few thousand entries per replay: the kernels are shorter than the '
+                                   'dependent-launch boundary' % info['launches'])
+        n_dev = ctx['n_dev']
+        out = {
+            'metric': metric,
+            'value': value, 'unit': 'backend-ops/s' if structured else 'gate-ops/s', 'n_gpus': world, 'steps': steps,
+            'warmup': warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': dtype, 'data': 'synthetic',
+            'config': {'workload': wl_name, 'batch_per_gpu': batch,
+                       'relation_messages': host['messages'], 'relation_bytes': host['relation_bytes'],
+                       'backend_ops_per_witness': int(len(kinds)), 'levels': info['levels'],
+                       'launches_per_step': info['launches'], 'sequential_launches': info['sequential_launches'],
+                       'wire_table_slots': info['slots'],
+                       'program_entries': info['device_ops'],
+                       'backend_ops_without_an_entry_of_their_own': int(len(kinds)) - info['device_ops'],
+                       'wire_table_MB': round(ev.table_bytes / 1e6, 1), 'lane_group': lane_group,
+                       'parallelism': 'witness lanes sharded over %d rank(s) on %d device(s); one all-reduce of 2 x u64 (%s)'
+                                      % (world, min(world, n_dev), 'none' if world == 1 else 'RCCL' if ctx['backend'] == 'nccl' else ctx['backend'] + ' rehearsal'),
+                       'ranks_seen': ranks_seen,
+                       'pcie_inclusive_ms_per_step': None if pcie_ms is None else round(pcie_ms, 3),
+                       'satisfied': total[0], 'failed': total[1],
+                       'expected_outputs': ('closed form in Python integers' if structured else
+                                            'GPU probe pass on another schedule and kernel; %d of %d lanes checked against '
+                                            'tests/golden/%s_all_lanes.json (oracle chain)' % (host['lanes_checked_against_golden_hashes'], batch, name)),
+                       'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')},
+                       'flatten_backend_ops_per_s': round(len(kinds) / max(host['ingest_and_record_s'], 1e-9)),
+                       'relation_in_to_first_verdict': first_verdict, 'tape_windows': ev.stream_info()['windows']},
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
+            out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates, ev, cpu_budget_s, with_opt=headline)
+    ev.close()
+
+    if rank == 0 and world == 1 and name == 'c2' and headline and not args.no_hbm_variant and not width and not bpg:
+        # the same relation with 4096 witnesses replayed at once: a 1.05 GB wire table cannot sit in the 256 MiB
+        # Infinity Cache, so here the memory side IS HBM (the headline batch of 1024 keeps its 263 MB table on-die)
+        hb = 4096
+        hev, _, _, hbad, _, hhost = build_session(zk, name, wl, hb, 0, hb, None, args.streams)
+        for _ in range(2):
+            hev.replay()
+        hev.synchronize()
+        hms = []
+        for _ in range(8):
+            hev.replay()
+            hev.synchronize()
+            hms.append(hev.last_replay_ms)
+        assert list(hev.counts()) == [workloads.expected_satisfied(hb), hbad]
+        hinfo = hev.schedule_info()
+        hk = float(np.mean(hms))
+        rh = make_roofline('c2_hbm', out['roofline']['kernel'], hinfo['launches'] - hinfo['sequential_launches'], hk,
+                           algo_bytes_per_lane * hb, {'entries': int(hinfo['device_ops']), 'launches': int(hinfo['launches']),
+                                                      'batch': hb, 'lane_group': hb}, args.streams)
+        rh.update({'batch': hb, 'lane_group': hb, 'wire_table_MB': round(hev.table_bytes / 1e6, 1), 'ms_per_step': hk,
+                   'value': gates * hb / (hk * 1e-3), 'lanes_checked_against_golden_hashes': hhost['lanes_checked_against_golden_hashes'],
+                   'what': 'same program, all 4096 witnesses in flight (one lane group): the working set is 4x the Infinity '
+                           'Cache, so the memory side is HBM; ms_per_step is the HIP-event time of the replay'})
+        out['roofline_hbm'] = rh
+        hev.close()
+    return out
 
 
 _RESULT_FD = None
@@ -392,7 +657,13 @@ def main():
     ap.add_argument('--no-hbm-variant', action='store_true', help='c2: skip the 4096-witnesses-in-flight variant')
     ap.add_argument('--chained', action='store_true', help='structured: every iteration depends on the one before')
     ap.add_argument('--no-first-verdict', action='store_true', help='c2: skip the relation-in -> first-verdict-out sessions')
+    ap.add_argument('--no-secondary', action='store_true', help='c2 on one GPU: skip the c4 / c5 / structured lines')
+    ap.add_argument('--timed-steps-only', action='store_true',
+                    help='nothing but the probe, the warm-up and the timed steps (what a rocprofv3 trace of the timed region needs): '
+                         '= --no-cpu-baseline --no-hbm-variant --no-first-verdict --no-secondary and no PCIe-inclusive passes')
     args = ap.parse_args()
+    if args.timed_steps_only:
+        args.no_cpu_baseline = args.no_hbm_variant = args.no_first_verdict = args.no_secondary = True
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))   # nothing in this process has touched torch or the GPU
@@ -428,210 +699,24 @@ def main():
 
     zk = entry.ensure_built()   # rebuilds when any source differs from what lib/libzkgpu.so was built from
     from zkinterface_ir_amd import workloads
+    ctx = {'world': world, 'rank': rank, 'dist': dist, 'torch': torch, 'red_dev': red_dev, 'dist_on': dist_on,
+           'backend': backend, 'n_dev': n_dev, 'dev_index': dev_index}
 
     if args.workload == 'c5':
-        return bench_c5(args, zk, workloads, world, rank, dist, torch, red_dev, dist_on)
-    if args.workload == 'c2':
-        mp = os.environ.get('ZKI_C2_MUL_PERCENT')  # developer sensitivity runs only; the metric is quoted on the default mix
-        wl = workloads.ArithLayered(W=args.width or 4096, D=args.depth or 256, mul_percent=int(mp) if mp else None)
-        batch = args.batch_per_gpu or 1024
-        bytes_table, bool_path = BYTES_PER_OP, None
-    elif args.workload == 'structured':
-        wl = workloads.StructuredArith(N=args.width or 1408, chained=args.chained)
-        batch = args.batch_per_gpu or 1024
-        bytes_table, bool_path = BYTES_PER_OP, None
+        out = bench_c5(args, zk, workloads, ctx, args.steps, args.warmup)
     else:
-        wl = workloads.BoolLayered(W=args.width or 16384, D=args.depth or 640,
-                                   wiring=os.environ.get('ZKI_C4_WIRING', 'random'))
-        batch = args.batch_per_gpu or 4096
-        bytes_table, bool_path = BYTES_PER_OP_BOOL, args.bool_path
-    lane_offset = rank * batch
-    ev, inst, wit, n_bad, msgs, host = build_session(zk, wl, batch, lane_offset, args.lane_group, bool_path,
-                                                     args.streams)
-    kinds, _, _ = ev.tape()
-    # structured: the unit of work is one backend call of the reference's evaluator (every value-returning call it
-    # makes for one witness, ladders and scope copies included) -- what the CPU baseline executes call by call
-    gates = wl.n_gates if hasattr(wl, 'n_gates') else int((kinds != 9).sum())
-    algo_bytes_per_lane = float(sum(bytes_table.get(int(k), 0) * int(c) for k, c in zip(*np.unique(kinds, return_counts=True))))
-    info = ev.schedule_info()
-    if args.workload == 'structured':
-        # the bytes of the program that runs (one entry = one gate's reads and write; 13 = the `x != 0` entry a ladder
-        # became): the backend calls the rewrite removed -- scope copies, ladder products -- move no bytes at all
-        pk = ev.schedule_dump()[0][:, 1] & 0xFF
-        algo_bytes_per_lane = float(sum({**BYTES_PER_OP, 13: 64}.get(int(k), 0) * int(c) for k, c in zip(*np.unique(pk, return_counts=True))))
-    lds = args.workload == 'c4' and ev.uses_lds_path()
-    wide_launches = 1 if lds else info['launches'] - info['sequential_launches']
-
-    counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if dist_on else None
-    reduced = torch.zeros(2, dtype=torch.int64, device=red_dev) if dist_on else None
-
-    def step():
-        ev.replay()
-        ev.synchronize()                # verdict words and counts are final on the engine's stream
-        if dist_on:
-            reduced.copy_(counts_t)     # 16 bytes out of the engine's counter words
-            dist.all_reduce(reduced)    # RCCL over xGMI: {satisfied, failed}
-            # the collective runs on RCCL's stream: finish it before the next replay resets the counters
-            torch.cuda.current_stream().synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ev.synchronize()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    t0 = time.perf_counter()
-    ev_ms = []
-    for _ in range(args.steps):
-        step()
-        ev_ms.append(ev.last_replay_ms)
-    ev.synchronize()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    if dist_on:
-        total = reduced.cpu().tolist()
-        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    else:
-        total = list(ev.counts())
-    # PCIe-inclusive figure (never `value`): the boundary hands over host buffers every step
-    pcie_ms = None
-    if world == 1 and args.workload != 'structured':
-        # page-locked host buffers (what a streaming caller would use): the DMA engine reads them directly
-        pin_i = torch.from_numpy(np.ascontiguousarray(inst).reshape(-1)).pin_memory()
-        pin_w = torch.from_numpy(np.ascontiguousarray(wit).reshape(-1)).pin_memory()
-        ib, wb = pin_i.data_ptr(), pin_w.data_ptr()
-        ev.set_inputs(ib, wb, batch)
-        ev.replay()
-        ev.synchronize()
-        tp = time.perf_counter()
-        for _ in range(6):   # batch k+1 is handed over while batch k replays (two input sets, copy stream)
-            ev.set_inputs(ib, wb, batch)
-            ev.replay()
-        ev.synchronize()
-        pcie_ms = (time.perf_counter() - tp) * 1e3 / 6
-        assert list(ev.counts()) == total, (ev.counts(), total)   # the handed-over batches give the resident answer
-    exp_sat = workloads.expected_satisfied(batch * world)
-    assert total[0] == exp_sat and total[0] + total[1] == batch * world, (total, exp_sat)
-    first_verdict = None
-    if world == 1 and args.workload == 'c2' and not args.no_first_verdict:
-        first_verdict = {}
-        for name, stream, pinned in (('at_finalize', 0, False), ('streamed', 1, False), ('streamed_pinned_inputs', 1, True)):
-            runs = [first_verdict_seconds(zk, wl, msgs, inst, wit, batch, stream, pinned) for _ in range(3)]
-            best = min(runs, key=lambda r: r['total_s'])
-            assert best['satisfied'] == exp_sat
-            first_verdict[name] = best
-
-    hbm_variant = None
-    if world == 1 and args.workload == 'c2' and not args.no_hbm_variant and not args.width and not args.batch_per_gpu:
-        # the same relation with 4096 witnesses replayed at once: a 1.05 GB wire table cannot sit in the 256 MiB
-        # Infinity Cache, so here the algorithmic-bytes roofline is an HBM figure (the headline batch of 1024 keeps its
-        # 263 MB table on-die)
-        hb = 4096
-        hev, _, _, hbad, _, _ = build_session(zk, wl, hb, 0, hb, None, args.streams)
-        for _ in range(2):
-            hev.replay()
-        hev.synchronize()
-        t0h = time.perf_counter()
-        hms = []
-        for _ in range(8):
-            hev.replay()
-            hev.synchronize()
-            hms.append(hev.last_replay_ms)
-        helapsed = (time.perf_counter() - t0h) / 8
-        assert list(hev.counts()) == [workloads.expected_satisfied(hb), hbad]
-        hach = algo_bytes_per_lane * hb / (float(np.mean(hms)) * 1e-3) / 1e9
-        hbm_variant = {'batch': hb, 'lane_group': hb, 'wire_table_MB': round(hev.table_bytes / 1e6, 1),
-                       'ms_per_step': helapsed * 1e3, 'value': gates * hb / helapsed, 'achieved': hach,
-                       'frac': hach / HBM_PEAK_GBS, 'what': 'same program, all 4096 witnesses in flight: working set 4x the '
-                                                            'Infinity Cache, so achieved / frac are against HBM'}
-        hev.close()
-
+        out = bench_tape(args.workload, args, zk, workloads, ctx, args.steps, args.warmup, True)
+    default_c2 = args.workload == 'c2' and not (args.width or args.depth or args.batch_per_gpu or args.lane_group)
+    if rank == 0 and world == 1 and not dist_on and default_c2 and not args.no_secondary:
+        # the other workloads, measured in this same invocation with bounded CPU samples (a few seconds each)
+        t0 = time.time()
+        sec = {}
+        sec['c4'] = bench_tape('c4', args, zk, workloads, ctx, 20, 3, False, cpu_budget_s=4.0)
+        sec['c5'] = bench_c5(args, zk, workloads, ctx, 5, 1, cpu_budget_s=4.0)
+        sec['structured'] = bench_tape('structured', args, zk, workloads, ctx, 20, 3, False, cpu_budget_s=4.0)
+        out['secondary'] = sec
+        out['secondary_wall_s'] = round(time.time() - t0, 1)
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = gates * batch * world / (elapsed / args.steps)
-        # roofline of the dominant kernel (replay_kernel<8,false>, one launch per circuit level):
-        # HIP-event time of the replays on the engine's stream / wide launches
-        kernel_ms = float(np.mean(ev_ms)) / max(wide_launches, 1)
-        bytes_per_launch = algo_bytes_per_lane * batch / max(wide_launches, 1)
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        structured = args.workload == 'structured'
-        traffic, traffic_src = (None, None) if structured else pmc_traffic(wl.W, batch, wl.width, args.workload)
-        fused = info['device_ops'] < len(kinds)
-        if args.workload == 'c2':
-            metric = 'gate-ops/sec (whole node), 256-bit field, 1M-gate relation, batched witnesses'
-            dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
-            wl_name = ('BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
-                       'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
-            kernel = 'replay_fused_kernel<8, 0>' if fused else 'replay_kernel<8, false, false>'
-        elif structured:
-            metric = ('backend-ops/sec (whole node), 256-bit field, For/Call/Switch relation of ~1M backend calls, batched '
-                      'witnesses (one unit = one value-returning ZKBackend call of the reference evaluator)')
-            dtype = 'u64x4 (GF(p) Montgomery limbs, exact integer)'
-            wl_name = ('structured%s: For over a named function with a nested call and a 2-case Switch, %d iterations, '
-                       'BN254 (shape of producers/examples.rs:72-212), witness batch=%d per GPU, %d GPU(s)'
-                       % (' (chained: each iteration reads the previous result)' if wl.chained else '', wl.N, batch, world))
-            kernel = 'replay_fused_kernel<8, 0> + <8, 1>' if fused else 'replay_kernel<8, false, false>'
-        else:
-            metric = 'gate-ops/sec (whole node), GF(2), 10M-gate And/Xor/Not relation, bit-packed batched witnesses'
-            dtype = 'u1 (GF(2), %d witnesses per word)' % (32 if lds else 64)
-            wl_name = ('BASELINE configs[3]: GF(2), %d-gate And/Xor/Not relation (W=%d x D=%d), witness batch=%d '
-                       'per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
-            kernel = 'bool_lds_kernel (wire table resident in LDS)' if lds else 'bool_replay_kernel'
-        step_kernel_ms = float(np.mean(ev_ms))
-        roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                    'kernel': kernel, 'launches_per_step': wide_launches,
-                    'concurrent_streams': 1 if lds else args.streams,
-                    'note': 'achieved / frac = algorithmic bytes (SURVEY.md 8d: 96 B per Add/Mul gate and witness ...) of the '
-                            'timed replay / its HIP-event time on the engine stream / the HBM spec peak.  The program moves '
-                            'fewer bytes than that accounting (gates evaluated inside their reader never touch memory, shared '
-                            'operands hit in L2): frac_traffic = measured L2<->fabric bytes (traffic x launches) / the same time '
-                            '/ the same peak, and `binding` names the resource that actually limits the kernel.  A level is one '
-                            'kernel per stream (lane shares run concurrently), so rocprofv3 lists launches_per_step x '
-                            'concurrent_streams kernels whose durations overlap',
-                    'avg_launch_ms': kernel_ms, 'algorithmic_bytes_per_launch': bytes_per_launch}
-        if traffic is not None:
-            roofline['traffic_bytes_per_step'] = traffic * max(wide_launches, 1)
-            roofline['frac_traffic'] = traffic * max(wide_launches, 1) / (step_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        be = binding_evidence(args.workload)
-        if be:
-            roofline['binding'] = be.get('binding')
-            roofline['binding_evidence'] = be.get('evidence')
-        elif structured:
-            roofline['binding'] = 'launch latency'
-            roofline['binding_evidence'] = ('%d launches of a few thousand entries per replay: the kernels are shorter than the '
-                                            'dependent-launch boundary' % info['launches'])
-        if hbm_variant is not None:
-            roofline['hbm_variant'] = hbm_variant
-        out = {
-            'metric': metric,
-            'value': value, 'unit': 'backend-ops/s' if structured else 'gate-ops/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': dtype, 'data': 'synthetic',
-            'config': {'workload': wl_name,
-                       'relation_messages': host['messages'], 'relation_bytes': host['relation_bytes'],
-                       'backend_ops_per_witness': int(len(kinds)), 'levels': info['levels'],
-                       'launches_per_step': info['launches'], 'sequential_launches': info['sequential_launches'],
-                       'wire_table_slots': info['slots'],
-                       'program_entries': info['device_ops'],
-                       'backend_ops_without_an_entry_of_their_own': int(len(kinds)) - info['device_ops'],
-                       'wire_table_MB': round(ev.table_bytes / 1e6, 1), 'lane_group': args.lane_group,
-                       'parallelism': 'witness lanes sharded over %d rank(s) on %d device(s); one all-reduce of 2 x u64 (%s)'
-                                      % (world, min(world, n_dev), 'none' if world == 1 else 'RCCL' if backend == 'nccl' else backend + ' rehearsal'),
-                       'pcie_inclusive_ms_per_step': None if pcie_ms is None else round(pcie_ms, 3),
-                       'satisfied': total[0], 'failed': total[1], 'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')},
-                       'flatten_backend_ops_per_s': round(len(kinds) / max(host['ingest_and_record_s'], 1e-9)),
-                       'relation_in_to_first_verdict': first_verdict, 'tape_windows': ev.stream_info()['windows']},
-            'roofline': roofline,
-        }
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
-            out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates, ev)
         emit_json_line(out)
     if dist_on:
         dist.barrier()

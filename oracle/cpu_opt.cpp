@@ -72,10 +72,27 @@ extern "C" {
 // first_fail[lane] = sequence number of the first failing assert or 0xFFFFFFFF.
 // out_values (may be NULL): canonical value of every op for lane `dump_lane` ([n_ops][32] bytes).
 // Returns wall-clock seconds of the evaluation.
+double zko_opt_eval_dump(const uint8_t* kinds, const uint32_t* a, const uint32_t* b, uint64_t n_ops, const uint8_t* consts,
+                         uint32_t const_width, uint32_t n_consts, const uint8_t* mod_le, uint32_t mod_len,
+                         const uint8_t* inst, uint32_t n_inst, const uint8_t* wit, uint32_t n_wit, uint32_t width,
+                         uint32_t batch, uint32_t threads, uint32_t* first_fail, uint8_t* out_values, uint32_t dump_lane,
+                         const uint64_t* dump_ops, uint32_t n_dump, uint8_t* out_dump);
+
 double zko_opt_eval(const uint8_t* kinds, const uint32_t* a, const uint32_t* b, uint64_t n_ops, const uint8_t* consts,
                     uint32_t const_width, uint32_t n_consts, const uint8_t* mod_le, uint32_t mod_len,
                     const uint8_t* inst, uint32_t n_inst, const uint8_t* wit, uint32_t n_wit, uint32_t width,
                     uint32_t batch, uint32_t threads, uint32_t* first_fail, uint8_t* out_values, uint32_t dump_lane) {
+  return zko_opt_eval_dump(kinds, a, b, n_ops, consts, const_width, n_consts, mod_le, mod_len, inst, n_inst, wit, n_wit, width,
+                           batch, threads, first_fail, out_values, dump_lane, nullptr, 0, nullptr);
+}
+
+// The same, and for EVERY lane the canonical values of the n_dump listed tape ops: out_dump[lane][k][32] (the output
+// wires of a full-size workload: what tests/golden/make_c2_digests.py hashes and the GPU tier compares against).
+double zko_opt_eval_dump(const uint8_t* kinds, const uint32_t* a, const uint32_t* b, uint64_t n_ops, const uint8_t* consts,
+                    uint32_t const_width, uint32_t n_consts, const uint8_t* mod_le, uint32_t mod_len,
+                    const uint8_t* inst, uint32_t n_inst, const uint8_t* wit, uint32_t n_wit, uint32_t width,
+                    uint32_t batch, uint32_t threads, uint32_t* first_fail, uint8_t* out_values, uint32_t dump_lane,
+                    const uint64_t* dump_ops, uint32_t n_dump, uint8_t* out_dump) {
   Field f;
   f.init(mod_le, mod_len);
   std::vector<F4> cm(n_consts);
@@ -104,6 +121,10 @@ double zko_opt_eval(const uint8_t* kinds, const uint32_t* a, const uint32_t* b, 
         }
       }
       first_fail[lane] = ff;
+      for (uint32_t k = 0; k < n_dump && out_dump; ++k) {
+        const F4 c = f.mul(v[dump_ops[k]], lit1);
+        memcpy(out_dump + ((size_t)lane * n_dump + k) * 32, c.l, 32);
+      }
       if (out_values && lane == dump_lane)
         for (uint64_t i = 0; i < n_ops; ++i) {
           F4 c = kinds[i] == 9 ? F4{{0, 0, 0, 0}} : f.mul(v[i], lit1);

@@ -61,3 +61,45 @@ def r1cs_sample_vars(wl, n=257):
 
 def r1cs_digest(values, width):
     return hashlib.sha256(b''.join(int(v).to_bytes(width, 'little') for v in values)).hexdigest()
+
+
+# ---- every lane of the full-size workloads (tests/golden/c2_all_lanes.json, c4_all_lanes.json) -----------------------
+def lane_hash(outputs_row):
+    """16 hex digits for one lane: the first 8 bytes of the SHA-256 of its output values as little-endian bytes
+    ([n_out][width] uint8 for GF(p); [n_out] bits, one byte each, for GF(2))"""
+    return hashlib.sha256(np.ascontiguousarray(outputs_row, dtype=np.uint8).tobytes()).hexdigest()[:16]
+
+
+def arith_layered_outputs(wl, inst, wit, threads=None):
+    """ArithLayered (C2) for a whole batch: the n_out output wires of every lane, uint8 [batch][n_out][width], by
+    `cpu_opt` (oracle/cpu_opt.cpp: flat array + 4x64 Montgomery, a different arithmetic from both the literal oracle's
+    long division and the GPU's 32-bit product scanning) on the tape the host records for the relation WITHOUT its
+    epilogue.  Every directive of that relation is one value-returning backend call, so tape index == wire id."""
+    import os
+    import oracle_lib
+    import zkinterface_ir_amd as zk
+    assert wl.width == 32
+    ev = zk.Evaluator()
+    ev.declare_inputs(wl.n_instance0, wl.n_witness)
+    for m in wl.relation_messages(with_epilogue=False, free_last=False):
+        ev.ingest_message(m)
+    assert ev.host_violations() == []
+    kinds, a, b = ev.tape()
+    ids = wl.output_wire_ids()
+    assert len(kinds) == wl.W * (wl.D + 1) and all(kinds[i] in (1, 2) for i in ids)
+    batch = inst.shape[0]
+    i0 = np.ascontiguousarray(inst[:, :wl.n_instance0])
+    _, _, out = oracle_lib.opt_eval_outputs(kinds, a, b, ev.constants(), wl.mod_le, i0.tobytes(), wl.n_instance0,
+                                            np.ascontiguousarray(wit).tobytes(), wl.n_witness, wl.width, batch,
+                                            threads or min(os.cpu_count() or 1, 64), ids)
+    ev.close()
+    return out
+
+
+def check_against_all_lanes_fixture(fx, outputs, lane_offset=0):
+    """outputs[lane] (as lane_hash takes them) against the committed per-lane hashes; lanes beyond the fixture fail"""
+    hashes = fx['hashes']
+    for lane in range(len(outputs)):
+        g = lane + lane_offset
+        assert g < len(hashes), 'lane %d is beyond the %d lanes of the fixture' % (g, len(hashes))
+        assert lane_hash(outputs[lane]) == hashes[g], 'lane %d: outputs differ from the committed oracle-chain hash' % g

@@ -54,6 +54,8 @@ def load():
                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p,
                                  ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                  ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    lib.zko_opt_eval_dump.restype = ctypes.c_double
+    lib.zko_opt_eval_dump.argtypes = lib.zko_opt_eval.argtypes + [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
     lib.zko_r1cs_check.restype = ctypes.c_double
     lib.zko_r1cs_check.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p,
                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p,
@@ -98,6 +100,26 @@ def opt_eval(kinds, a, b, constants, modulus_le, inst, n_inst, wit, n_wit, width
     out = None
     if vals is not None:
         out = [int.from_bytes(vals[i].tobytes(), 'little') for i in range(len(kinds)) if kinds[i] != 9]
+    return ff, secs, out
+
+
+def opt_eval_outputs(kinds, a, b, constants, modulus_le, inst, n_inst, wit, n_wit, width, batch, threads, dump_ops):
+    """`cpu_opt` over a whole batch, returning for every lane the canonical values of the listed tape ops:
+    (first_fail uint32[batch], seconds, uint8 [batch][len(dump_ops)][32] little-endian)."""
+    import numpy as np
+    lib = load()
+    kinds = np.ascontiguousarray(kinds, dtype=np.uint8)
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    cw = max([len(c) for c in constants] + [1])
+    cbytes = b''.join(bytes(c) + bytes(cw - len(c)) for c in constants) or b'\x00'
+    ff = np.zeros(batch, dtype=np.uint32)
+    dump_ops = np.ascontiguousarray(dump_ops, dtype=np.uint64)
+    assert len(dump_ops) and int(dump_ops.max()) < len(kinds)
+    out = np.zeros((batch, len(dump_ops), 32), dtype=np.uint8)
+    secs = lib.zko_opt_eval_dump(kinds.ctypes.data, a.ctypes.data, b.ctypes.data, len(kinds), cbytes, cw, len(constants),
+                                 modulus_le, len(modulus_le), inst, n_inst, wit, n_wit, width, batch, threads,
+                                 ff.ctypes.data, None, 0, dump_ops.ctypes.data, len(dump_ops), out.ctypes.data)
     return ff, secs, out
 
 

@@ -46,6 +46,8 @@ def c4_reference():
     for lane, want in fx['lanes'].items():
         assert cpu_checkers.bool_digest(outs[int(lane)]) == want['sha256'], lane
         assert ''.join(str(int(b)) for b in outs[int(lane)]) == want['bits']
+    # every lane against the committed per-lane hashes (tests/golden/make_all_lanes.py)
+    cpu_checkers.check_against_all_lanes_fixture(_fixture('c4_all_lanes.json'), outs)
     return wl, inst, wit, outs
 
 

@@ -214,23 +214,18 @@ def test_unreduced_inputs_get_the_reference_verdict_or_a_refusal():
 
 
 def _layered_session(wl, batch, lane_group=0):
-    """probe pass (outputs) + full relation; returns (evaluator, inst, wit, n_bad)."""
-    probe = zk.Evaluator()
-    probe.declare_inputs(wl.n_instance0, wl.n_witness)
-    for m in wl.relation_messages(with_epilogue=False, free_last=False):
-        probe.ingest_message(m)
-    assert probe.host_violations() == []
-    probe.finalize()
+    """The full relation with its epilogue over a batch whose expected outputs come from the CPU (`cpu_opt` on the tape of
+    the relation without its epilogue, tests/cpu_checkers.py) -- never from the GPU.  At the BASELINE sizes every lane of
+    them is also checked against the committed oracle-chain hashes (tests/golden/c2_all_lanes.json).
+    Returns (evaluator, inst, wit, n_bad)."""
+    import json
+    import os
+    import cpu_checkers
+    from helpers import ROOT
     inst, wit = wl.inputs(batch)
-    probe.set_inputs(np.ascontiguousarray(inst[:, :wl.n_instance0]).tobytes(), wit.tobytes(), batch)
-    probe.replay()
-    probe.synchronize()
-    outs = np.zeros((batch, wl.n_out, wl.width), dtype=np.uint8)
-    for t, wid in enumerate(wl.output_wire_ids()):
-        vals = probe.get(wid, batch)
-        for lane in range(batch):
-            outs[lane, t] = np.frombuffer(vals[lane].to_bytes(wl.width, 'little'), dtype=np.uint8)
-    probe.close()
+    outs = cpu_checkers.arith_layered_outputs(wl, inst, wit)
+    if (wl.W, wl.D, wl.n_out, wl.seed) == (4096, 256, 64, 0x5EED0001):
+        cpu_checkers.check_against_all_lanes_fixture(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'c2_all_lanes.json'))), outs)
     n_bad = wl.set_expected_outputs(inst, outs)
     ev = zk.Evaluator()
     ev.declare_inputs(wl.n_instance, wl.n_witness)
@@ -327,6 +322,13 @@ def test_full_size_c2_outputs_match_the_committed_oracle_digests():
         vals = [col[int(lane)] for col in cols]
         assert hashlib.sha256('\n'.join(str(v) for v in vals).encode()).hexdigest() == want['sha256'], lane
         assert str(vals[0]) == want['first_output']
+    # ... and ALL 1024 lanes against the per-lane hashes of tests/golden/c2_all_lanes.json (cpu_opt, pinned to the oracle
+    # on the six lanes above by tests/test_oracle_golden.py)
+    import cpu_checkers
+    outs = np.zeros((batch, wl.n_out, wl.width), dtype=np.uint8)
+    for t, col in enumerate(cols):
+        outs[:, t] = np.frombuffer(b''.join(v.to_bytes(wl.width, 'little') for v in col), dtype=np.uint8).reshape(batch, wl.width)
+    cpu_checkers.check_against_all_lanes_fixture(json.load(open(os.path.join(ROOT, 'tests', 'golden', 'c2_all_lanes.json'))), outs)
 
 
 @pytest.mark.parametrize('batch', [1100, 2560])

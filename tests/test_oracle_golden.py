@@ -112,3 +112,34 @@ def test_c2_full_size_digest_fixture_matches_the_oracle():
     vals = [run.get(w) for w in wl.output_wire_ids()]
     assert hashlib.sha256('\n'.join(str(v) for v in vals).encode()).hexdigest() == fx['lanes'][str(lane)]['sha256']
     assert str(vals[0]) == fx['lanes'][str(lane)]['first_output']
+
+
+def test_all_lanes_fixtures_are_what_their_generator_says():
+    """tests/golden/c2_all_lanes.json / c4_all_lanes.json hold one 64-bit hash of the 64 output wires for EVERY lane
+    (8192 of C2 = configs[2]'s 8 ranks x 1024; 4096 of C4), made by the fast CPU checkers.  Regenerated here for a
+    sample: lanes 0..127 of rank 0 -- among them four of the six lanes the literal oracle's digests pin (0, 1, 96, 97), so
+    the chain oracle -> cpu_opt -> all lanes is checked end to end -- and a few lanes of another rank's share."""
+    import hashlib
+    import json
+    import os
+    import cpu_checkers
+    from helpers import ROOT
+    from zkinterface_ir_amd import workloads
+    fx = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'c2_all_lanes.json')))
+    six = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'c2_digests.json')))
+    assert len(fx['hashes']) == 8192 and len(set(fx['hashes'])) == 8192
+    wl = workloads.ArithLayered()
+    inst, wit = wl.inputs(128)
+    out = cpu_checkers.arith_layered_outputs(wl, inst, wit, threads=8)
+    cpu_checkers.check_against_all_lanes_fixture(fx, out)
+    for lane in (0, 1, 96, 97):
+        vals = [int.from_bytes(out[lane, t].tobytes(), 'little') for t in range(wl.n_out)]
+        assert hashlib.sha256('\n'.join(str(v) for v in vals).encode()).hexdigest() == six['lanes'][str(lane)]['sha256'], lane
+    inst, wit = wl.inputs(8, 3 * 1024)           # rank 3 of configs[2]
+    cpu_checkers.check_against_all_lanes_fixture(fx, cpu_checkers.arith_layered_outputs(wl, inst, wit, threads=8), 3 * 1024)
+    # a damaged output does not pass
+    bad = out.copy()
+    bad[5, 0, 0] ^= 1
+    import pytest
+    with pytest.raises(AssertionError, match='lane 5'):
+        cpu_checkers.check_against_all_lanes_fixture(fx, bad)

@@ -7,7 +7,7 @@
 # tools/pmc_traffic.py applies the gfx950 corrections of MI355X_MICROARCH.md, tools/binding_evidence.py writes
 # profiles/binding_<workload>.json from the summaries.  Copy gpurun_out/<tag>/* into profiles/ afterwards.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 WHAT=${2:-bench}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -26,21 +26,32 @@ pmc() {  # pmc <name> <counters...> -- <bench args...>
   cp $(find /tmp/pmc_$name -name '*counter_collection.csv' | head -1) /tmp/pmc_$name.csv
 }
 if [ $WHAT = bench ]; then
-  for wl in c2 c4 c5 structured; do
+  # the driver's command: the C2 headline line with the c4 / c5 / structured lines under `secondary`
+  echo "[collect] bench (default invocation)"
+  timeout -k 10 600 $B --steps 20 --warmup 3 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+  python3 - $OUT $TAG <<'PY'
+import json, sys
+out, tag = sys.argv[1], sys.argv[2]
+d = json.load(open('%s/%s_bench_default.json' % (out, tag)))
+sec = d.pop('secondary', {})
+json.dump(d, open('%s/%s_bench_c2.json' % (out, tag), 'w'))
+for k, v in sec.items():
+    json.dump(v, open('%s/%s_bench_%s.json' % (out, tag, k), 'w'))
+PY
+  # kernel stats of the TIMED REGION only: --timed-steps-only runs nothing but the probe (another kernel: the unfused
+  # replay_kernel / the HBM-table GF(2) kernel), the warm-up steps and the timed steps
+  for wl in c2 c4 c5; do
     extra=""; [ $wl != c2 ] && extra="--workload $wl"
-    echo "[collect] bench $wl"
-    timeout -k 10 500 $B --steps 20 --warmup 3 $extra > $OUT/${TAG}_bench_$wl.json 2> $OUT/bench_$wl.err
-    [ $wl = structured ] && continue
     rm -rf /tmp/prof_$wl
     echo "[collect] rocprofv3 stats $wl"
-    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- $B --steps 5 --warmup 1 --no-cpu-baseline --no-hbm-variant $extra > $OUT/prof_$wl.log 2>&1
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -- $B --steps 20 --warmup 3 --timed-steps-only $extra > $OUT/${TAG}_bench_${wl}_under_trace.json 2> $OUT/prof_$wl.log
     cp $(find /tmp/prof_$wl -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_${wl}_kernel_stats.csv
   done
   tail -c 400 $OUT/${TAG}_bench_c2.json
 elif [ $WHAT = pmc_c2 ]; then
   # one stream: a level is ONE launch over all 1024 witnesses (grid > 2M threads); the probe session of bench.py replays
   # its lane halves on two streams (1.3M threads per launch) and is left out by the grid filter
-  C2="--steps 3 --warmup 1 --no-cpu-baseline --no-hbm-variant --no-first-verdict --streams 1"
+  C2="--steps 3 --warmup 1 --timed-steps-only --streams 1"
   K='replay_fused_kernel<8, 0>'
   pmc c2_f FETCH_SIZE -- $C2
   pmc c2_w WRITE_SIZE -- $C2
@@ -52,12 +63,12 @@ elif [ $WHAT = pmc_c2 ]; then
   pmc c2_tcc TCC_HIT_sum TCC_MISS_sum -- $C2
   python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c2_tcc.csv "$K" 2000000 > $OUT/${TAG}_pmc_c2_tcc_counters.json
   # the same program with 4096 witnesses in flight (1.05 GB wire table: cannot sit in the Infinity Cache)
-  H="--steps 2 --warmup 1 --no-cpu-baseline --no-hbm-variant --no-first-verdict --streams 1 --batch-per-gpu 4096 --lane-group 4096"
+  H="--steps 2 --warmup 1 --timed-steps-only --streams 1 --batch-per-gpu 4096 --lane-group 4096"
   pmc c2h_f FETCH_SIZE -- $H
   pmc c2h_w WRITE_SIZE -- $H
   python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c2h_f.csv /tmp/pmc_c2h_w.csv $OUT/pmc_traffic_c2_hbm_variant.json 4000000 "$K" c2_hbm_variant > /dev/null
 elif [ $WHAT = pmc_c45 ]; then
-  C4="--workload c4 --steps 2 --warmup 1 --no-cpu-baseline"
+  C4="--workload c4 --steps 2 --warmup 1 --timed-steps-only"
   pmc c4_f FETCH_SIZE -- $C4
   pmc c4_w WRITE_SIZE -- $C4
   python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c4_f.csv /tmp/pmc_c4_w.csv $OUT/pmc_traffic_c4.json 1000 bool_lds_kernel c4 > /dev/null
@@ -73,7 +84,7 @@ elif [ $WHAT = pmc_c45 ]; then
   # the same relation shape with gate j reading wires j and j+1 of the previous layer: conflict-free by construction,
   # same program size -- what is left is the program stream and the barriers
   ZKI_C4_WIRING=identity $B --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_c4_identity_wiring.json 2> $OUT/bench_c4_identity.err || true
-  C5="--workload c5 --steps 2 --warmup 1 --no-cpu-baseline"
+  C5="--workload c5 --steps 2 --warmup 1 --timed-steps-only"
   K5='r1cs_row_kernel<8, false>'
   pmc c5_f FETCH_SIZE -- $C5
   pmc c5_w WRITE_SIZE -- $C5
