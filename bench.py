@@ -207,7 +207,10 @@ def cpu_baseline(wl, msgs, inst, wit, gates, ev=None, budget_s=15.0, with_opt=Tr
                                 wl.width, 1, 1)
     per_lane = max(one[1], 1e-3)
     threads = min(cores, 64)
-    lanes = int(min(inst.shape[0], max(threads, min(4 * threads, (budget_s / per_lane) * threads))))
+    # whole rounds of one witness per thread: as many as the budget allows at the single-thread time, at most four (with
+    # every thread busy a witness takes several times its single-thread time: hash maps and heap integers share the caches)
+    rounds = max(1, min(4, int(budget_s / (4.0 * per_lane))))
+    lanes = int(min(inst.shape[0], rounds * threads))
     ok, secs, ops = oracle_lib.eval_batch(rel, wl.mod_le, inst[:lanes].tobytes(), wl.n_instance,
                                           wit[:lanes].tobytes(), wl.n_witness, wl.width, lanes, threads)
     extra = {}
@@ -401,7 +404,10 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
                                    wiring=os.environ.get('ZKI_C4_WIRING', 'random'))
         batch = bpg or 4096
         bytes_table, bool_path = BYTES_PER_OP_BOOL, args.bool_path
-    lane_offset = rank * batch
+    # ZKI_RANK_BASE (rehearsals only): this launch holds ranks base .. base + world - 1 of a larger job -- a one-GPU box may
+    # run at most 6 processes on its card, so the 8 lane shares of BASELINE configs[2] are rehearsed as two launches of 4
+    rank_base = int(os.environ.get('ZKI_RANK_BASE', '0'))
+    lane_offset = (rank_base + rank) * batch
     ev, inst, wit, n_bad, msgs, host = build_session(zk, name, wl, batch, lane_offset, lane_group, bool_path, args.streams)
     kinds, _, _ = ev.tape()
     # structured: the unit of work is one backend call of the reference's evaluator (every value-returning call it
@@ -462,7 +468,7 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
         ranks_seen = sorted(gathered, key=lambda r: r['rank'])
     else:
         total = list(ev.counts())
-    exp_sat = workloads.expected_satisfied(batch * world)
+    exp_sat = workloads.expected_satisfied(batch * world, rank_base * batch)
     assert total[0] == exp_sat and total[0] + total[1] == batch * world, (total, exp_sat)
     if ranks_seen is not None:
         assert [r['rank'] for r in ranks_seen] == list(range(world)), ranks_seen
@@ -545,7 +551,7 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
                        'wire_table_MB': round(ev.table_bytes / 1e6, 1), 'lane_group': lane_group,
                        'parallelism': 'witness lanes sharded over %d rank(s) on %d device(s); one all-reduce of 2 x u64 (%s)'
                                       % (world, min(world, n_dev), 'none' if world == 1 else 'RCCL' if ctx['backend'] == 'nccl' else ctx['backend'] + ' rehearsal'),
-                       'ranks_seen': ranks_seen,
+                       'ranks_seen': ranks_seen, 'rank_base': rank_base,
                        'pcie_inclusive_ms_per_step': None if pcie_ms is None else round(pcie_ms, 3),
                        'satisfied': total[0], 'failed': total[1],
                        'expected_outputs': ('closed form in Python integers' if structured else

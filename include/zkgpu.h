@@ -141,6 +141,21 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s);
  * wire table stays in the 256 MiB Infinity Cache (whole XCD rounds per stream), or the whole batch when it fits */
 int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 
+/* Values >= the field characteristic.  The reference's PlaintextBackend keeps constants, instance and witness values
+ * unreduced (rust/src/consumers/evaluator.rs:862-864,896-898,940-946): arithmetic gates reduce their result, but copy
+ * clones the integer, assert_zero / not test it for zero, and / xor over an odd field work on its bits and
+ * Evaluator::get returns it.  After zkgpu_finalize, zkgpu_input_modes gives per input position (witness = 0: instance
+ * stream, 1: witness stream; returns the number of positions, writes at most cap bytes) how a value >= p is treated:
+ *   0x00  reduced on load: every use is arithmetic (over GF(2): and / xor, whose low bit only depends on low bits);
+ *   0x01  read by assert_zero / not alone, through copies: those see "non-zero", as the reference does (a value >= p
+ *         is never the integer 0) -- GF(p): the kernels test the raw input beside the wire; GF(2): packed as v != 0;
+ *   0x02  GF(p): both of the above (the sinks still get the reference's answer);
+ *   0xFF  it reaches and / xor over an odd field, Evaluator::get (a wire alive at the end) or, over GF(2), both a zero
+ *         test and a gate: a lane holding a value >= p there is flagged ZKGPU_LANE_NONCANONICAL and counted as failed,
+ *         with a violation text that says so.  Constants >= p in those places are refused by zkgpu_finalize.
+ * The modes depend on the tape alone, not on options ("stream" windows included). */
+size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size_t cap);
+
 /* options: "max_tape_ops" = N (default 2^30: loops are unrolled, this bounds a corrupt loop bound),
  * "streams" = 1..4 (lane shares replayed concurrently, default 2),
  * "sort_by_operand" = 0|1|2|3 (order of the ops inside a level: tape order, by first operand, that followed by a
@@ -161,10 +176,14 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  * a replay is hundreds of kernel launches; the program is replicated, no data-path collective.  zkgpu_counts combines
  * the per-device {satisfied, failed} counters with one RCCL all-reduce (ncclCommInitAll; loaded with dlopen on first
  * use) when the listed devices are distinct, and by a host sum when a device is listed more than once -- the
- * rehearsal of the lane split on a one-GPU box.  Per-lane results, violations and wire dumps are gathered in lane
+ * rehearsal of the lane split on a one-GPU box -- or when RCCL cannot be loaded or initialised (zkgpu_rccl_note then
+ * says why; the counts are exact either way).  The all-reduce over MORE THAN ONE device has not run on hardware yet:
+ * no multi-GPU node was available to any round so far; what has run is the one-rank communicator of "force_rccl".  Per-lane results, violations and wire dumps are gathered in lane
  * order.  Not available with several devices: zkgpu_set_inputs_device, zkgpu_counts_device, zkgpu_stream,
  * zkgpu_replay_timed and the R1CS entry points.  Set before the first zkgpu_set_inputs* call.  Default: one engine on
  * the thread's current device),
+ * "force_rccl" = 0|1 (zkgpu_counts always goes through ncclCommInitAll + ncclAllReduce, also for a single engine -- a
+ * communicator of one rank -- and an RCCL failure is an error instead of falling back to the host sum; default 0),
  * "stream" = 0 | 1 | N (streaming ingest, rust/src/consumers/evaluator.rs:286-301: the reference consumes a relation
  * as a stream of <= 100k-gate messages; with N > 0 the tape is cut into windows of about N recorded calls ("1" = 131072),
  * and a worker thread schedules each window -- and sends its program entries to the GPU -- as soon as it is complete,
@@ -222,6 +241,8 @@ void* zkgpu_counts_device(zkgpu_session* s);                  /* device uint64[2
 void* zkgpu_stream(zkgpu_session* s);                         /* hipStream_t the replay runs on */
 int zkgpu_device_count(void);                                 /* GPUs the HIP runtime sees (-1: none / no runtime) */
 int zkgpu_n_engines(const zkgpu_session* s);                  /* engines the batch is split over (option "devices") */
+uint64_t zkgpu_rccl_reductions(const zkgpu_session* s);       /* zkgpu_counts calls answered by an RCCL all-reduce */
+size_t zkgpu_rccl_note(const zkgpu_session* s, char* buf, size_t cap); /* why RCCL was not used ("" = it was, or was not needed) */
 int zkgpu_lane_results(zkgpu_session* s, uint32_t* first_fail, uint32_t* flags); /* [batch] each */
 /* Evaluator::get_violations() of lane `lane`, '\n'-separated; returns the length needed */
 size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t cap);

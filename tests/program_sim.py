@@ -9,8 +9,10 @@ OP = {'nop': 0, 'add': 1, 'mul': 2, 'addc': 3, 'mulc': 4, 'copy': 5, 'const': 6,
       'assert': 9, 'and': 10, 'xor': 11, 'not': 12, 'nz': 13}
 
 
-def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None):
+def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None, modes=None):
     """Run one lane.  instances / witnesses: python ints.  Returns (slots, first_fail_seq, noncanonical).
+    modes = (instance modes, witness modes) as zkgpu_input_modes gives them (how a value >= p is treated per position:
+    0xFF flags the lane; GF(2): 0x01 packs `v != 0`); None = every position 0.
     Within a non-sequential launch the ops are executed in a shuffled order when shuffle_seed is given
     (they must be independent), mimicking the arbitrary order of waves on the GPU."""
     import random
@@ -25,6 +27,19 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
         for k in range(words_per_const):
             v |= int(const_words[i * words_per_const + k]) << (32 * k)
         consts.append(v)
+    inst_modes, wit_modes = modes if modes is not None else ([], [])
+
+    def mode_of(is_witness, position):
+        m = wit_modes if is_witness else inst_modes
+        return m[position] if position < len(m) else 0
+
+    def source_is_nonzero(code):
+        """the unreduced source an assert_zero / not entry names (device/replay_kernels.hpp unreduced_source_is_nonzero)"""
+        if code < 2:
+            return code == 1
+        q = code - 2
+        v = (witnesses if q & 1 else instances)[q >> 1]
+        return v >= p
     slots = [None] * n_slots
     first_fail = None
     noncanon = False
@@ -87,18 +102,21 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
             elif kind == OP['not']:
                 assert slots[a] is not None
                 reads.add(a)
-                r = 1 - slots[a] if boolean else (R % p if slots[a] == 0 else 0)
+                code = 0 if boolean else (a1 | b)    # fused entry: a1; unfused: b (the other is 0)
+                r = 1 - slots[a] if boolean else (R % p if slots[a] == 0 and not source_is_nonzero(code) else 0)
             elif kind == OP['const']:
                 r = consts[a]
             elif kind in (OP['instance'], OP['witness']):
                 v = instances[a] if kind == OP['instance'] else witnesses[a]
-                if v >= p and b:     # b: a strict input (an unreduced value would reach copy / assert_zero / not / a bit op)
+                mode = mode_of(kind == OP['witness'], a)
+                if v >= p and mode == 0xFF:     # the unreduced value would reach an integer bit operation / Evaluator::get
                     noncanon = True
-                r = (v & 1) if boolean else (v * R % p)
+                r = ((1 if v else 0) if mode == 0x01 else (v & 1)) if boolean else (v * R % p)
             elif kind == OP['assert']:
                 assert slots[a] is not None
                 reads.add(a)
-                if slots[a] != 0 and (first_fail is None or b < first_fail):
+                code = 0 if boolean else (dst | a1)   # fused entry: a1; unfused: dst (the other is 0)
+                if (slots[a] != 0 or source_is_nonzero(code)) and (first_fail is None or b < first_fail):
                     first_fail = b
                 continue
             else:

@@ -101,3 +101,44 @@ def test_c_example_splits_a_batch_over_the_listed_devices(tmp_path):
     assert 'lane 0: TRUE' in r.stdout and 'lane 1: FALSE: Wire_' in r.stdout
     r = subprocess.run([exe, '--batch', '64'] + REF_EXAMPLES, capture_output=True, text=True)   # every visible GPU
     assert r.returncode == 0 and '63 TRUE, 1 FALSE' in r.stdout
+
+
+@pytest.mark.gpu
+def test_counts_through_rccl_with_a_one_device_communicator():
+    """option "force_rccl": zkgpu_counts runs the in-library RCCL reduction -- dlopen of librccl, ncclCommInitAll,
+    ncclGroupStart / ncclAllReduce(2 x u64, sum) on the engine's stream / ncclGroupEnd -- with a communicator of one rank,
+    so that the code path of a multi-GPU `devices` list has run against the real RCCL on a one-GPU box.  The counts must
+    be the plain ones, batch after batch, and the session says that RCCL answered."""
+    wl = workloads.StructuredArith(N=24)
+    batch = 500
+    inst, wit, bad = wl.inputs(batch, corrupt_every=7)
+    plain = _session(wl, batch, None, inst, wit)
+    assert plain.counts() == (batch - bad, bad) and plain.rccl_reductions == 0
+    ev = zk.Evaluator()
+    ev.set_option('force_rccl', '1')
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in wl.relation_messages():
+        ev.ingest_message(m)
+    ev.finalize()
+    for k, b in enumerate((batch, 130, batch)):
+        ev.set_inputs(inst[:b].tobytes(), wit[:b].tobytes(), b)
+        ev.replay()
+        ev.synchronize()
+        nb = sum(1 for i in range(b) if i % 7 == 0)
+        assert ev.counts() == (b - nb, nb)
+        assert ev.rccl_reductions == k + 1 and ev.rccl_note() == ''
+    # per-lane results are untouched by the way the counts were combined
+    assert np.array_equal(ev.lane_results(batch)[0], plain.lane_results(batch)[0])
+    # a device listed twice cannot be an RCCL communicator: with force_rccl that is an error, not a silent host sum
+    two = zk.Evaluator()
+    two.set_option('devices', '0,0')
+    two.set_option('force_rccl', '1')
+    two.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in wl.relation_messages():
+        two.ingest_message(m)
+    two.finalize()
+    two.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    two.replay()
+    two.synchronize()
+    with pytest.raises(zk.ZkGpuError, match='force_rccl'):
+        two.counts()

@@ -50,7 +50,7 @@ def test_random_relation_against_oracle(seed):
             ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32)
             slots, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'],
                                                        info['slots'], p, rows_i[lane], rows_w[lane],
-                                                       shuffle_seed=seed)
+                                                       shuffle_seed=seed, modes=(ev2.input_modes(False), ev2.input_modes(True)))
             assert not noncanon
             assert expected_product_violations(ev2, ff) == ref.violations, (seed, lane)
             if retain:

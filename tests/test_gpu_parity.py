@@ -175,7 +175,8 @@ def test_switch_weights_in_the_production_schedule(modulus):
 def test_unreduced_inputs_get_the_reference_verdict_or_a_refusal():
     """The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  Where a value >= p first meets an
     arithmetic gate its residue is what the reference computes with too: the kernels reduce it on load and the lane
-    gets the oracle's verdict.  Where it could reach copy / assert_zero / not / a bit operation as it is, the lane is
+    gets the oracle's verdict.  Where it reaches assert_zero / not through copies alone it is "not zero", as it is for the
+    reference's integer test: the oracle's verdict again.  Where its BITS matter (and / xor over an odd field) the lane is
     refused with a text that says so (tests/test_unreduced.py has the cases one by one)."""
     _, _, rel = circuits.arith_example(101)
     ev = zk.Evaluator()
@@ -195,22 +196,69 @@ def test_unreduced_inputs_get_the_reference_verdict_or_a_refusal():
         assert ev.get_violations(lane) == ref.violations, lane      # every use in this relation is arithmetic
         n_ok += ref.violations == []
     assert n_ok == 4 and ev.counts() == (4, 1)
-    # assert_zero(copy(w)): strict -- w = p is not zero for the reference's integer test; refused, not guessed
+    # assert_zero(copy(w)): w = p is not zero for the reference's integer test, and the assert's entry tests the raw input
+    # beside the wire -- the reference's verdict, lane by lane
     from zkinterface_ir_amd import sieve_writer as sw
-    rel2 = sw.write_relation(bytes([101]), 'arithmetic', 'simple', [], [('witness', 0), ('copy', 1, 0), ('assert_zero', 1), ('free', 0, 1)])
+    for retain in (False, True):
+        rel2 = sw.write_relation(bytes([101]), 'arithmetic,boolean', 'simple', [],
+                                 [('witness', 0), ('copy', 1, 0), ('assert_zero', 1), ('witness', 2), ('not', 3, 2), ('mulc', 4, 3, bytes([5])),
+                                  ('addc', 5, 4, bytes([96])), ('assert_zero', 5), ('free', 0, 5)])
+        ev = zk.Evaluator()
+        ev.declare_inputs(0, 2)
+        ev.ingest_message(rel2)
+        ev.finalize(retain_all=retain)
+        assert ev.input_modes(True) == [0x01, 0x01]
+        rows_w = [[0, 0], [101, 0], [5, 0], [0, 101], [0, 7], [202, 0], [0, 2 ** 32 - 1], [101, 101]]
+        _, wit = batch_arrays([[]] * len(rows_w), rows_w, ev.elem_bytes)
+        ev.set_inputs(None, wit, len(rows_w))
+        ev.replay()
+        ev.synchronize()
+        n_true = 0
+        for lane, row in enumerate(rows_w):
+            ref = oracle_lane(bytes([101]), [], row, [rel2], 4, trace=False)
+            assert ev.get_violations(lane) == ref.violations, (retain, lane)
+            n_true += ref.violations == []
+        assert ev.get_violations(1) == ['Wire_1 (may be weighted) should be 0, while it is not']     # w = p
+        assert ev.get_violations(3) == ['Wire_5 (may be weighted) should be 0, while it is not']     # not(p) = 0
+        assert ev.counts() == (n_true, len(rows_w) - n_true) and n_true == 1
+        assert not ev.lane_results(len(rows_w))[1].any()                                              # nobody flagged
+    # what stays refused: the bits of an unreduced integer in `and` over an odd field
+    rel3 = sw.write_relation(bytes([101]), 'arithmetic,boolean', 'simple', [],
+                             [('witness', 0), ('constant', 1, bytes([3])), ('and', 2, 0, 1), ('addc', 3, 2, bytes([100])), ('assert_zero', 3),
+                              ('free', 0, 3)])
     ev = zk.Evaluator()
     ev.declare_inputs(0, 1)
-    ev.ingest_message(rel2)
+    ev.ingest_message(rel3)
     ev.finalize()
-    _, wit = batch_arrays([[], [], []], [[0], [101], [5]], ev.elem_bytes)
-    ev.set_inputs(None, wit, 3)
+    assert ev.input_modes(True) == [0xFF]
+    _, wit = batch_arrays([[], []], [[5], [106]], ev.elem_bytes)
+    ev.set_inputs(None, wit, 2)
     ev.replay()
     ev.synchronize()
-    assert ev.get_violations(0) == []
-    v = ev.get_violations(1)
+    assert ev.get_violations(0) == []                                    # 5 & 3 = 1
+    v = ev.get_violations(1)                                             # the reference: 106 & 3 = 2 -> Wire_3 fails
     assert len(v) == 1 and 'not canonical' in v[0] and 'evaluator.rs:896-946' in v[0]
-    assert ev.get_violations(2) == ['Wire_1 (may be weighted) should be 0, while it is not']
-    assert ev.counts() == (1, 2)
+    assert ev.counts() == (1, 1)
+    # GF(2): a position only zero tests read is packed as `v != 0` (both kernels)
+    rel4 = sw.write_relation(bytes([2]), 'boolean', 'simple', [],
+                             [('witness', 0), ('not', 1, 0), ('assert_zero', 1), ('witness', 2), ('copy', 3, 2), ('assert_zero', 3)]
+                             + [('witness', 4 + k) for k in range(20)] + [('free', 0, 23)])
+    rows_w = [[1, 0] + [0] * 20, [2, 0] + [1] * 20, [0, 0] + [0] * 20, [254, 2] + [1] * 20, [3, 0] + [3] * 20]
+    for path in ('hbm', 'lds'):
+        ev = zk.Evaluator()
+        ev.set_option('bool_path', path)
+        ev.declare_inputs(0, 22)
+        ev.ingest_message(rel4)
+        ev.finalize()
+        assert ev.input_modes(True)[:2] == [0x01, 0x01]
+        _, wit = batch_arrays([[]] * len(rows_w), rows_w, 1)
+        ev.set_inputs(None, wit, len(rows_w))
+        ev.replay()
+        ev.synchronize()
+        for lane, row in enumerate(rows_w):
+            ref = oracle_lane(bytes([2]), [], row, [rel4], 1, trace=False)
+            assert ev.get_violations(lane) == ref.violations, (path, lane)
+        assert ev.counts() == (3, 2)
 
 
 def _layered_session(wl, batch, lane_group=0):

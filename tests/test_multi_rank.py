@@ -78,3 +78,31 @@ def test_rccl_path_with_one_rank():
         assert out.returncode == 0, out.stderr[-3000:]
         r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
         assert r['n_gpus'] == 1 and r['config']['satisfied'] == workloads.expected_satisfied(128) == 126
+
+
+@pytest.mark.gpu
+def test_configs2_lane_shares_at_full_size_in_two_launches_of_four_ranks():
+    """BASELINE configs[2]: the full 2^20-gate BN254 relation, 8 ranks x 1024 witnesses.  The pool allows at most 6
+    processes on one card, so the 8 lane shares are rehearsed as two launches of 4 ranks (ZKI_RANK_BASE = 0 and 4), each
+    rank with its own engine, 263 MB wire table and 1024-lane share at its global lane offset; every rank's probe outputs
+    are checked against tests/golden/c2_all_lanes.json (all 8192 lanes) inside bench.py, the counts are reduced over the
+    process group, and `ranks_seen` comes from an all_gather over it.  Together: 8192 - 85 satisfied."""
+    sat = 0
+    for base in (0, 4):
+        os.environ['ZKI_RANK_BASE'] = str(base)
+        try:
+            r = run_bench('--gpus', 4, '--steps', 2, '--warmup', 1, '--no-cpu-baseline', timeout=900)
+        finally:
+            del os.environ['ZKI_RANK_BASE']
+        assert r['n_gpus'] == 4 and r['config']['rank_base'] == base and r['config']['batch_per_gpu'] == 1024
+        assert 'BASELINE configs[1]' in r['config']['workload'] and '1048576-gate' in r['config']['workload']
+        seen = r['config']['ranks_seen']
+        assert [s['rank'] for s in seen] == [0, 1, 2, 3]
+        assert [s['lane_offset'] for s in seen] == [(base + k) * 1024 for k in range(4)]
+        for s in seen:
+            assert s['lanes'] == 1024 and s['satisfied'] == workloads.expected_satisfied(1024, s['lane_offset'])
+            assert s['satisfied'] + s['failed'] == 1024
+        assert r['config']['satisfied'] == sum(s['satisfied'] for s in seen) == workloads.expected_satisfied(4096, base * 1024)
+        assert '1024 of 1024 lanes checked' in r['config']['expected_outputs']
+        sat += r['config']['satisfied']
+    assert sat == 8192 - 85

@@ -1,10 +1,14 @@
 """Values >= the field characteristic.  PlaintextBackend keeps constants, instance and witness
 values unreduced (rust/src/consumers/evaluator.rs:862-864,896-898,940-946): add / mul / add_constant / mul_constant
 reduce their result, but `copy` clones the integer as it is, `assert_zero` and `not` test it for zero, `and` / `xor`
-work on its bits and `Evaluator::get` returns it.  The product reduces such a value exactly where the reference's own
-arithmetic would (anything that first meets an arithmetic gate; over GF(2) also and / xor, whose low bit only depends
-on the low bits), so those statements get the reference's verdict; a value that could reach one of the other consumers
-through copies alone is refused -- per lane for inputs, at finalize for constants -- and the refusal says so."""
+work on its bits and `Evaluator::get` returns it.  The product gives such a value the reference's verdict wherever that
+is decidable without the integer itself: it reduces it exactly where the reference's own arithmetic would (anything
+that first meets an arithmetic gate; over GF(2) also and / xor, whose low bit only depends on the low bits), and an
+assert_zero / not reached through copies alone sees "not zero" -- a value >= p is never the integer 0 -- by testing the
+raw input beside the wire (GF(p)) or by packing the position as `v != 0` (GF(2)).  What is left is refused, and the
+refusal says so: the bits of an unreduced integer in and / xor over an odd field, Evaluator::get of a wire alive at
+the end, and a GF(2) position one bit cannot serve (zero test and gate at once) -- per lane for inputs, at finalize for
+constants.  Every case below is held against the oracle's run of the same statement."""
 import pytest
 
 import circuits
@@ -29,8 +33,10 @@ def _run(p, gates, inst, wit, gateset='arithmetic', width=None):
     ev.finalize()
     ops, launches, consts, _ = ev.schedule_dump()
     info = ev.schedule_info()
-    _, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, inst, wit)
+    modes = (ev.input_modes(False), ev.input_modes(True))
+    _, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, inst, wit, modes=modes)
     ref = oracle_lane(mod_le, inst, wit, [rel], max(width, 32), trace=False)
+    _run.modes = modes
     return expected_product_violations(ev, ff), ref.violations, noncanon
 
 
@@ -48,21 +54,48 @@ def test_inputs_that_first_meet_arithmetic_are_reduced_like_the_reference_does(p
         assert mine == ref and (ref == []) == true, (w, e)
 
 
-def test_an_unreduced_input_that_reaches_assert_zero_through_copies_is_refused_per_lane():
-    # assert_zero(copy(copy(w))): the reference tests the unreduced integer: w = p is NOT zero for it
-    gates = [('witness', 0), ('copy', 1, 0), ('copy', 2, 1), ('assert_zero', 2)]
-    mine, ref, noncanon = _run(P, gates, [], [0])
-    assert mine == ref == [] and not noncanon
-    mine, ref, noncanon = _run(P, gates, [], [P])
-    assert ref == ['Wire_2 (may be weighted) should be 0, while it is not']      # p != 0 as an integer
-    assert noncanon                                                              # the product flags the lane instead of guessing
+def test_an_unreduced_input_that_reaches_assert_zero_through_copies_is_not_zero():
+    # assert_zero(copy(copy(w))): the reference tests the unreduced integer: w = p, 2p are NOT zero for it
+    gates = [('witness', 0), ('copy', 1, 0), ('copy', 2, 1), ('assert_zero', 2), ('free', 0, 2)]
+    for w, true in ((0, True), (P, False), (2 * P, False), (5, False), (P + 5, False)):
+        mine, ref, noncanon = _run(P, gates, [], [w])
+        assert not noncanon and mine == ref, w
+        assert ref == ([] if true else ['Wire_2 (may be weighted) should be 0, while it is not'])
+        assert _run.modes == ([], [0x01])                           # read by zero tests alone
     # the same input through an arithmetic gate first: p + 0 = 0, both say TRUE
     gates = [('witness', 0), ('addc', 1, 0, bytes([0])), ('assert_zero', 1), ('free', 0, 1)]
     mine, ref, noncanon = _run(P, gates, [], [P])
-    assert mine == ref == [] and not noncanon
+    assert mine == ref == [] and not noncanon and _run.modes == ([], [0x00])
+    # zero test AND arithmetic on one witness: the sink sees the integer, the product sees the residue
+    gates = [('witness', 0), ('instance', 1), ('copy', 2, 0), ('assert_zero', 2), ('mul', 3, 0, 0), ('mulc', 4, 1, sw.int_to_le(P - 1)),
+             ('add', 5, 3, 4), ('assert_zero', 5), ('free', 0, 5)]
+    for w, e in ((0, 0), (P, 0), (P, 1), (P + 3, 9), (3, 9)):
+        mine, ref, noncanon = _run(P, gates, [e], [w])
+        assert not noncanon and mine == ref, (w, e)
+        assert _run.modes == ([0x00], [0x02])
+    assert _run(P, gates, [0], [P])[1] == ['Wire_2 (may be weighted) should be 0, while it is not']
+    # over BN254: the raw value is compared with a 254-bit p word by word
+    gates = [('instance', 0), ('copy', 1, 0), ('assert_zero', 1), ('free', 0, 1)]
+    for v in (0, BIG, BIG + 1, 2 ** 256 - 1, 1):
+        mine, ref, noncanon = _run(BIG, gates, [v], [])
+        assert not noncanon and mine == ref and (ref == []) == (v == 0), v
 
 
-def test_bit_operations_and_not_are_strict_over_an_odd_field_but_and_xor_are_not_over_gf2():
+def test_not_sees_the_unreduced_integer():
+    # not = is_zero ? 1 : 0 on the integer (evaluator.rs:935-938): not(p) = 0, not(0) = 1
+    gates = [('witness', 0), ('not', 1, 0), ('assert_zero', 1), ('free', 0, 1)]
+    for w in (0, 1, P, 2 * P, P + 1):
+        mine, ref, noncanon = _run(P, gates, [], [w], gateset='arithmetic,boolean')
+        assert not noncanon and mine == ref and (ref == []) == (w != 0), w
+    # through a copy, and the result used by arithmetic
+    gates = [('witness', 0), ('copy', 1, 0), ('not', 2, 1), ('mulc', 3, 2, bytes([7])), ('addc', 4, 3, sw.int_to_le(P - 7)), ('assert_zero', 4),
+             ('free', 0, 4)]
+    for w in (0, P, 3):
+        mine, ref, noncanon = _run(P, gates, [], [w], gateset='arithmetic,boolean')
+        assert not noncanon and mine == ref and (ref == []) == (w == 0), w
+
+
+def test_bit_operations_are_strict_over_an_odd_field_but_not_over_gf2():
     # odd p: (w & 3) on the unreduced integer
     gates = [('witness', 0), ('constant', 1, bytes([3])), ('and', 2, 0, 1), ('addc', 3, 2, sw.int_to_le(P - 1)), ('assert_zero', 3)]
     mine, ref, noncanon = _run(P, gates, [], [5], gateset='arithmetic,boolean')      # 5 & 3 = 1
@@ -75,12 +108,25 @@ def test_bit_operations_and_not_are_strict_over_an_odd_field_but_and_xor_are_not
     for w0, w1, e in ((2, 1, 1), (3, 1, 0), (2, 3, 1), (0, 1, 1)):
         mine, ref, noncanon = _run(2, gates, [e], [w0, w1], gateset='boolean', width=1)
         assert not noncanon and mine == ref == [], (w0, w1, e)
-    # ... but `not` is `is_zero ? 1 : 0` on the integer: not(2) = 0 for the reference, not(0) = 1
-    gates = [('witness', 0), ('not', 1, 0), ('assert_zero', 1)]
-    mine, ref, noncanon = _run(2, gates, [], [1], gateset='boolean', width=1)
-    assert mine == ref == [] and not noncanon
-    mine, ref, noncanon = _run(2, gates, [], [2], gateset='boolean', width=1)
-    assert ref == [] and noncanon            # reference: not(2) = 0, TRUE; the residue would give not(0) = 1: refused
+    # ... but `not` is `is_zero ? 1 : 0` on the integer: not(2) = 0 for the reference, not(0) = 1.  A position read by
+    # zero tests alone is packed as `v != 0`
+    gates = [('witness', 0), ('not', 1, 0), ('assert_zero', 1), ('free', 0, 1)]
+    for w in (0, 1, 2, 3, 254):
+        mine, ref, noncanon = _run(2, gates, [], [w], gateset='boolean', width=1)
+        assert not noncanon and mine == ref and (ref == []) == (w != 0), w
+        assert _run.modes == ([], [0x01])
+    gates = [('witness', 0), ('copy', 1, 0), ('assert_zero', 1), ('free', 0, 1)]
+    for w in (0, 1, 2):
+        mine, ref, noncanon = _run(2, gates, [], [w], gateset='boolean', width=1)
+        assert not noncanon and mine == ref and (ref == []) == (w == 0), w
+    # one bit cannot be `v & 1` for a gate and `v != 0` for a zero test: such a position is strict, a value > 1 refused
+    gates = [('witness', 0), ('witness', 1), ('not', 2, 0), ('xor', 3, 0, 1), ('xor', 4, 2, 3), ('assert_zero', 4), ('free', 0, 4)]
+    for w0, w1 in ((0, 1), (1, 0), (1, 1), (0, 0)):
+        mine, ref, noncanon = _run(2, gates, [], [w0, w1], gateset='boolean', width=1)
+        assert not noncanon and mine == ref, (w0, w1)
+        assert _run.modes == ([], [0xFF, 0x00])
+    _, ref, noncanon = _run(2, gates, [], [2, 1], gateset='boolean', width=1)
+    assert noncanon
 
 
 def test_constants_beyond_the_characteristic():
@@ -90,13 +136,40 @@ def test_constants_beyond_the_characteristic():
              ('free', 0, 3)]
     mine, ref, noncanon = _run(P, gates, [], [3])          # 3 * 7 - 21
     assert mine == ref == [] and not noncanon
-    # copied into an assert: the reference sees the integer 101, not 0 -- refused at finalize, with the reason
-    rel = sw.write_relation(mod_le, 'arithmetic', 'simple', [], [('constant', 0, sw.int_to_le(P)), ('copy', 1, 0), ('assert_zero', 1)])
+    # copied into an assert: the reference sees the integer 101, not 0 -- and so does the assert's entry
+    gates = [('constant', 0, sw.int_to_le(P)), ('copy', 1, 0), ('assert_zero', 1), ('free', 0, 1)]
+    mine, ref, noncanon = _run(P, gates, [], [])
+    assert mine == ref == ['Wire_1 (may be weighted) should be 0, while it is not'] and not noncanon
+    gates = [('constant', 0, sw.int_to_le(2 * P)), ('not', 1, 0), ('assert_zero', 1), ('free', 0, 1)]     # not(2p) = 0
+    mine, ref, noncanon = _run(P, gates, [], [], gateset='arithmetic,boolean')
+    assert mine == ref == [] and not noncanon
+    # the same constant in arithmetic AND in front of a zero test
+    gates = [('witness', 0), ('constant', 1, sw.int_to_le(P + 7)), ('mul', 2, 0, 1), ('addc', 3, 2, sw.int_to_le(P - 21)), ('assert_zero', 3),
+             ('not', 4, 1), ('assert_zero', 4), ('free', 0, 4)]
+    mine, ref, noncanon = _run(P, gates, [], [3])
+    assert mine == ref == [] and not noncanon
+    # GF(2): a constant 2 in front of zero tests alone is `non-zero`; feeding a gate as well it is refused at finalize
+    gates = [('constant', 0, bytes([2])), ('copy', 1, 0), ('assert_zero', 1), ('free', 0, 1)]
+    mine, ref, noncanon = _run(2, gates, [], [], gateset='boolean', width=1)
+    assert mine == ref == ['Wire_1 (may be weighted) should be 0, while it is not']
+    gates = [('constant', 0, bytes([2])), ('not', 1, 0), ('assert_zero', 1), ('free', 0, 1)]
+    mine, ref, noncanon = _run(2, gates, [], [], gateset='boolean', width=1)
+    assert mine == ref == []
+    rel = sw.write_relation(bytes([2]), 'boolean', 'simple', [], [('constant', 0, bytes([2])), ('witness', 1), ('not', 2, 0), ('xor', 3, 0, 1),
+                                                                 ('free', 0, 3)])
     ev = zk.Evaluator()
+    ev.declare_inputs(0, 1)
     ev.ingest_message(rel)
-    with pytest.raises(zk.ZkGpuError, match='constant >= the field characteristic reaches copy / assert_zero'):
+    with pytest.raises(zk.ZkGpuError, match='constant >= the field characteristic reaches assert_zero / not and, as its low bit, a gate'):
         ev.finalize()
-    assert oracle_lane(mod_le, [], [], [rel], 32, trace=False).violations == ['Wire_1 (may be weighted) should be 0, while it is not']
+    # a constant in an integer bit operation over an odd field: refused at finalize
+    rel = sw.write_relation(mod_le, 'arithmetic,boolean', 'simple', [], [('constant', 0, sw.int_to_le(P + 6)), ('witness', 1), ('and', 2, 0, 1),
+                                                                        ('free', 0, 2)])
+    ev = zk.Evaluator()
+    ev.declare_inputs(0, 1)
+    ev.ingest_message(rel)
+    with pytest.raises(zk.ZkGpuError, match='reaches and / xor'):
+        ev.finalize()
     # a wire left alive at the end can be asked for with Evaluator::get: its constant must be canonical too
     rel = sw.write_relation(mod_le, 'arithmetic', 'simple', [], [('constant', 0, sw.int_to_le(P + 1))])
     ev = zk.Evaluator()
@@ -105,18 +178,43 @@ def test_constants_beyond_the_characteristic():
         ev.finalize()
 
 
-def test_streamed_windows_are_cautious_about_values_that_stay_open():
-    """a window cannot know the later readers of a value its owner still holds: such an input stays strict"""
-    gates = [('witness', 0)] + [('addc', k, k - 1, bytes([1])) for k in range(1, 40)] + [('mulc', 40, 0, bytes([2])), ('free', 0, 40)]
-    rel = sw.write_relation(sw.int_to_le(P), 'arithmetic', 'simple', [], gates)
-    flags = {}
-    for stream in ('0', '16'):
-        ev = zk.Evaluator()
-        ev.set_option('stream', stream)
-        ev.declare_inputs(0, 1)
-        ev.ingest_message(rel)
-        ev.finalize()
-        ops, launches, consts, _ = ev.schedule_dump()
-        info = ev.schedule_info()
-        _, _, flags[stream] = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], P, [], [P + 1])
-    assert flags == {'0': False, '16': True}      # one window sees every reader (all arithmetic); the first of three does not
+def test_a_wire_alive_at_the_end_keeps_its_input_strict():
+    # Evaluator::get returns the unreduced integer: an input behind a wire nobody freed must be canonical
+    gates = [('witness', 0), ('copy', 1, 0), ('mul', 2, 0, 0)]
+    mine, ref, noncanon = _run(P, gates, [], [5])
+    assert mine == ref == [] and not noncanon and _run.modes == ([], [0xFF])
+    _, _, noncanon = _run(P, gates, [], [P + 5])
+    assert noncanon
+
+
+def test_the_verdict_does_not_depend_on_how_the_tape_was_cut_into_windows():
+    """a window cannot know the later readers of a value its owner still holds, so what a value >= p means for a position
+    is decided when the tape has ended (Schedule::strict_*), not in the entries a streamed window uploaded long before"""
+    chain = [('witness', 0)] + [('addc', k, k - 1, bytes([1])) for k in range(1, 40)] + [('mulc', 40, 0, bytes([2]))]
+    cases = {
+        'arithmetic only': (chain + [('free', 0, 40)], [P + 1], 0x00),
+        'zero test in a later window': (chain + [('copy', 41, 0), ('assert_zero', 41), ('free', 0, 41)], [P], 0x02),
+        'alive at the end': (chain + [('free', 1, 40)], [P + 1], 0xFF),
+    }
+    for name, (gates, wit, mode) in cases.items():
+        rel = sw.write_relation(sw.int_to_le(P), 'arithmetic', 'simple', [], gates)
+        ref = oracle_lane(sw.int_to_le(P), [], wit, [rel], 32, trace=False)
+        seen = {}
+        for stream in ('0', '16'):
+            ev = zk.Evaluator()
+            ev.set_option('stream', stream)
+            ev.declare_inputs(0, 1)
+            ev.ingest_message(rel)
+            ev.finalize()
+            assert (ev.stream_info()['windows'] > 1) == (stream == '16')
+            ops, launches, consts, _ = ev.schedule_dump()
+            info = ev.schedule_info()
+            modes = (ev.input_modes(False), ev.input_modes(True))
+            assert modes == ([], [mode]), (name, stream)
+            _, ff, flagged = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], P, [], wit, modes=modes)
+            seen[stream] = (expected_product_violations(ev, ff), flagged)
+        assert seen['0'] == seen['16'], name
+        if mode != 0xFF:
+            assert seen['0'] == (ref.violations, False), name
+        else:
+            assert seen['0'][1]

@@ -87,6 +87,7 @@ def lib():
         'zkgpu_set_inputs_device': (ci, [vp, vp, vp, u32]),
         'zkgpu_set_inputs_from_messages': (ci, [vp]),
         'zkgpu_set_lane_group': (ci, [vp, u32]),
+        'zkgpu_input_modes': (sz, [vp, ci, vp, sz]),
         'zkgpu_set_option': (ci, [vp, ctypes.c_char_p, ctypes.c_char_p]),
         'zkgpu_modulus': (sz, [vp, ctypes.c_char_p, sz]),
         'zkgpu_message_values': (u32, [vp, ci]),
@@ -107,6 +108,8 @@ def lib():
         'zkgpu_stream': (vp, [vp]),
         'zkgpu_n_engines': (ci, [vp]),
         'zkgpu_device_count': (ci, []),
+        'zkgpu_rccl_reductions': (u64, [vp]),
+        'zkgpu_rccl_note': (sz, [vp, ctypes.c_char_p, sz]),
         'zkgpu_lane_results': (ci, [vp, vp, vp]),
         'zkgpu_lane_violations': (sz, [vp, u32, ctypes.c_char_p, sz]),
         'zkgpu_dump_trace_values': (ci, [vp, u64, u64, vp]),
@@ -402,6 +405,13 @@ class Evaluator:
     def set_inputs_from_messages(self):
         self._ck(self.L.zkgpu_set_inputs_from_messages(self.h))
 
+    def input_modes(self, witness=False):
+        """per input position how a value >= p is treated (include/zkgpu.h zkgpu_input_modes): list of 0x00 / 0x01 / 0x02 / 0xFF"""
+        n = self.L.zkgpu_input_modes(self.h, int(witness), None, 0)
+        buf = (ctypes.c_uint8 * max(n, 1))()
+        self.L.zkgpu_input_modes(self.h, int(witness), buf, n)
+        return list(buf[:n])
+
     def set_lane_group(self, lanes):
         self._ck(self.L.zkgpu_set_lane_group(self.h, lanes))
 
@@ -444,6 +454,14 @@ class Evaluator:
     @property
     def n_engines(self):
         return int(self.L.zkgpu_n_engines(self.h))
+
+    @property
+    def rccl_reductions(self):
+        """counts() calls answered by an RCCL all-reduce (several devices, or option force_rccl)"""
+        return int(self.L.zkgpu_rccl_reductions(self.h))
+
+    def rccl_note(self):
+        return self._text(self.L.zkgpu_rccl_note)
 
     def stream_ptr(self):
         return self.L.zkgpu_stream(self.h)

@@ -63,6 +63,9 @@ struct zkgpu_session {
   std::vector<std::unique_ptr<Engine>> peers;
   std::vector<uint32_t> lane_first;
   std::unique_ptr<CountReducer> reducer;   // RCCL, when the devices are distinct
+  bool force_rccl = false;                 // option "force_rccl": zkgpu_counts always goes through RCCL, failures are errors
+  uint64_t rccl_reductions = 0;            // zkgpu_counts calls answered by an RCCL all-reduce
+  std::string rccl_note;                   // why the host sum was used instead (RCCL could not be loaded / initialised)
   uint32_t batch = 0;
   Schedule sched;
   bool finalized = false;
@@ -361,7 +364,7 @@ void split_lanes(zkgpu_session* s, uint32_t batch) {
 void total_counts(zkgpu_session* s, uint64_t out[2]) {
   const std::vector<size_t> act = active_engines(s);
   std::vector<Engine*> eng = all_engines(s);
-  if (s->peers.empty() || act.size() <= 1) {
+  auto host_sum = [&] {
     out[0] = out[1] = 0;
     for (size_t k : act.empty() ? std::vector<size_t>{0} : act) {
       uint64_t c[2] = {0, 0};
@@ -369,23 +372,30 @@ void total_counts(zkgpu_session* s, uint64_t out[2]) {
       out[0] += c[0];
       out[1] += c[1];
     }
-    return;
-  }
+  };
   bool distinct = act.size() == eng.size();
   for (size_t i = 0; i < eng.size() && distinct; ++i)
     for (size_t j = 0; j < i; ++j)
       if (eng[i]->device() == eng[j]->device()) distinct = false;
-  if (distinct) {
-    if (!s->reducer) s->reducer.reset(new CountReducer(eng));
-    s->reducer->all_reduce(out);
+  // RCCL: several engines on distinct devices, or -- option "force_rccl" -- also the one-engine session (a communicator of
+  // one rank: the same ncclCommInitAll + ncclAllReduce calls, on a box with one GPU)
+  const bool want_rccl = distinct && (act.size() > 1 || s->force_rccl);
+  if (s->force_rccl && !distinct)
+    throw std::runtime_error("force_rccl: RCCL needs every engine on a device of its own and lanes on each of them");
+  if (!want_rccl) {
+    host_sum();
     return;
   }
-  out[0] = out[1] = 0;
-  for (size_t k : act) {
-    uint64_t c[2] = {0, 0};
-    eng[k]->download(nullptr, nullptr, c);
-    out[0] += c[0];
-    out[1] += c[1];
+  try {
+    if (!s->reducer) s->reducer.reset(new CountReducer(eng));
+    s->reducer->all_reduce(out);
+    ++s->rccl_reductions;
+  } catch (const std::exception& e) {
+    if (s->force_rccl) throw;
+    // the counts themselves are exact either way: without a usable RCCL they are summed on the host, and the reason is kept
+    s->reducer.reset();
+    s->rccl_note = e.what();
+    host_sum();
   }
 }
 
@@ -786,6 +796,14 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
   });
 }
 
+size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size_t cap) {
+  if (!s || !s->finalized) return 0;
+  const std::vector<uint8_t>& m = witness ? s->sched.strict_witness : s->sched.strict_instance;
+  const size_t n = witness ? lane_inputs(s, false) : lane_inputs(s, true);
+  for (size_t k = 0; k < n && k < cap && out; ++k) out[k] = k < m.size() ? m[k] : 0;
+  return n;
+}
+
 int zkgpu_stream_info(const zkgpu_session* s, double out[3]) {
   if (!s || !s->finalized) return 1;
   out[0] = (double)(s->sched.window_first_op.empty() ? 0 : s->sched.window_first_op.size() - 1);
@@ -900,13 +918,21 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
     if (s->backend.tape().n_instance > li.size() || s->backend.tape().n_witness > lw.size())
       throw std::runtime_error("the tape consumes more instance/witness values than the ingested messages hold");
     const FieldHost& f = s->backend.field();
-    // a value too wide for the buffer is >= p: at a position where only the residue matters the residue goes in; at a
-    // strict one (Schedule::strict_*) all-ones does, which the device flags like any other non-canonical strict input
-    auto fill = [&](const std::vector<Value>& vals, std::vector<uint8_t>& buf, const std::vector<uint8_t>& strict) {
+    // a value too wide for the buffer is >= p.  Where only the residue matters (mode 0) the residue goes in; at a strict
+    // position (0xFF) all-ones does, which the device flags like any other non-canonical strict input; at a position only
+    // zero tests read (0x01) all-ones too -- it is >= p and non-zero, which is all those look at.  A position read both by
+    // zero tests and by arithmetic (0x02) would need the residue AND the fact that the integer is not zero: refused.
+    auto fill = [&](const std::vector<Value>& vals, std::vector<uint8_t>& buf, const std::vector<uint8_t>& modes) {
       for (size_t k = 0; k < vals.size(); ++k) {
         bool big = false;
         put_value(vals[k], &buf[k * w], w, f, &big);
-        if (big && k < strict.size() && strict[k]) memset(&buf[k * w], 0xff, w);
+        const uint8_t mode = k < modes.size() ? modes[k] : 0;
+        if (big && (mode == 0xFF || mode == 0x01)) memset(&buf[k * w], 0xff, w);
+        if (big && mode == 0x02)
+          throw std::runtime_error("GPU backend: input value " + std::to_string(k) + " is wider than the field's limbs and is read both by "
+                                   "arithmetic gates (which need its residue) and, through copies, by assert_zero / not (which "
+                                   "test the unreduced integer, evaluator.rs:900-906,935-938): hand the batch over with "
+                                   "zkgpu_set_inputs in full-width values instead");
       }
     };
     fill(li, inst, s->sched.strict_instance);
@@ -957,6 +983,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       }
       if (devs.size() > 64) throw std::runtime_error("devices: at most 64 engines");
       s->devices = devs;
+    } else if (k == "force_rccl") {
+      s->force_rccl = v != "0";
     } else if (k == "stream") {
       // tape entries per window; "1" = the default window of 131072 entries; before the first Relation message
       if (s->backend.tape().size() || s->finalized) throw std::runtime_error("stream must be set before the first Relation message");
@@ -1102,10 +1130,12 @@ size_t zkgpu_launch_timings(const zkgpu_session* s, float* ms, uint32_t* ops, si
 int zkgpu_counts(zkgpu_session* s, uint64_t out[2]) {
   return guarded(s, [&] {
     need_engine(s);
-    if (s->peers.empty()) s->engine->download(nullptr, nullptr, out);
+    if (s->peers.empty() && !s->force_rccl) s->engine->download(nullptr, nullptr, out);
     else total_counts(s, out);
   });
 }
+uint64_t zkgpu_rccl_reductions(const zkgpu_session* s) { return s ? s->rccl_reductions : 0; }
+size_t zkgpu_rccl_note(const zkgpu_session* s, char* buf, size_t cap) { return s ? copy_out(s->rccl_note, buf, cap) : 0; }
 void* zkgpu_counts_device(zkgpu_session* s) { return (s && s->engine && s->peers.empty()) ? s->engine->counts_device() : nullptr; }
 void* zkgpu_stream(zkgpu_session* s) { return (s && s->engine && s->peers.empty()) ? s->engine->stream() : nullptr; }
 int zkgpu_device_count(void) { return visible_devices(); }
@@ -1131,9 +1161,10 @@ size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t 
         if (!s->ev.has_error() || m != s->ev.error()) v.push_back(m);  // "Did not receive any gate to verify."
     const uint32_t ff = s->first_fail[lane];
     if (s->flags[lane] & ZKGPU_LANE_NONCANONICAL) {
-      v.push_back("GPU backend: an instance or witness value is not canonical (>= field characteristic) and reaches copy / "
-                  "assert_zero / not / and / xor / Evaluator::get without passing through an arithmetic gate; the reference "
-                  "evaluates those on the unreduced integer (evaluator.rs:896-946) and this path does not");
+      v.push_back("GPU backend: an instance or witness value is not canonical (>= field characteristic) and reaches and / xor "
+                  "over an odd field, Evaluator::get (a wire alive at the end) or, over GF(2), both a zero test and a gate "
+                  "without passing through an arithmetic gate; the reference evaluates those on the unreduced integer "
+                  "(evaluator.rs:896-946) and this path does not");
     } else if (ff != ZKGPU_NO_FAIL) {
       v.push_back("Wire_" + std::to_string(s->backend.tape().assert_wire[ff]) +
                   " (may be weighted) should be 0, while it is not");

@@ -80,6 +80,8 @@ struct ReplayArgs {
   u32* first_fail;        // [lane] min assert sequence number that failed
   u32* lane_flags;        // [lane] sticky flags (non-canonical input ...)
   u32 xcd_chunks;         // != 0: XCD-aware 1-D grid, see block_coords()
+  const uint8_t* strict_inst;   // per input position: 0xFF = a value >= p flags the lane (Schedule::strict_instance)
+  const uint8_t* strict_wit;
 };
 
 struct ReplayArgs2 {
@@ -99,6 +101,8 @@ struct ReplayArgs2 {
   u32* lane_flags;
   u32 xcd_chunks;
   u32 op_stride;          // 1 or 4, see the kernel
+  const uint8_t* strict_inst;   // as in ReplayArgs
+  const uint8_t* strict_wit;
 };
 
 // instantiations of replay_fused_kernel (replay_kernels.hpp)

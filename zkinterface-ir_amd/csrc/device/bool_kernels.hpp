@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void verdict_kernel(const u32* __restrict__ fi
 // One wave = 64 witnesses x 256 positions.  Each lane reads 16 of its bytes per load (rows are
 // 16-byte aligned when n_vals % 16 == 0), every byte position is turned into a 64-bit word by a
 // wave ballot, and lane b keeps / stores the word of position k + b: one store per 16 positions.
-// strict[k] != 0: a value > 1 at position k flags the lane (it would reach assert_zero / not unreduced, see
-// schedule.cpp mark_strict_sources); elsewhere the low bit is the residue and that is all and / xor ever look at.
+// strict[k] = the mode of position k (schedule.cpp track_unreduced_values): 0xFF = a value > 1 flags the lane (it reaches
+// Evaluator::get unreduced, or both a zero test and a gate); 0x01 = read by assert_zero / not alone, through copies: for the
+// reference those test the unreduced INTEGER for zero (evaluator.rs:900-906,935-938), so the position is packed as
+// `v != 0`; elsewhere the low bit is the residue and that is all and / xor ever look at.
 // One launch packs both streams: blockIdx.z = 0 the instances, 1 the witnesses (grid.y covers the longer of the two).
 struct PackArgs {
   const uint8_t* raw[2];
@@ -68,9 +70,20 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const PackArgs pa, u32
   u32 k = k0;
   if ((n_vals & 15) == 0 && ((size_t)raw & 15) == 0) {
     auto pack16 = [&](const uint4 v, u32 kk) {
-      const u32 w[4] = {v.x, v.y, v.z, v.w};
-      const uint4 sm = *reinterpret_cast<const uint4*>(strict + kk);   // 0x00 / 0xFF per position (padded to 16)
-      bad |= (((v.x & sm.x) | (v.y & sm.y) | (v.z & sm.z) | (v.w & sm.w)) & 0xFEFEFEFEu) != 0;
+      u32 w[4] = {v.x, v.y, v.z, v.w};
+      const uint4 sm = *reinterpret_cast<const uint4*>(strict + kk);   // 0x00 / 0x01 / 0xFF per position (padded to 16)
+      bad |= (((v.x & sm.x) | (v.y & sm.y) | (v.z & sm.z) | (v.w & sm.w)) & 0xFEFEFEFEu) != 0;   // (mode 0x01 never flags)
+      const u32 m[4] = {sm.x, sm.y, sm.z, sm.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u32 zm = m[q] & ~(m[q] >> 1) & 0x01010101u;   // bytes of mode 0x01 (wave-uniform: the branch is scalar)
+        if (zm) {   // bit 0 of such a byte := OR of all its bits (`v != 0`)
+          u32 t = w[q] | ((w[q] >> 4) & 0x0F0F0F0Fu);
+          t |= (t >> 2) & 0x3F3F3F3Fu;
+          t |= (t >> 1) & 0x7F7F7F7Fu;
+          w[q] ^= (w[q] ^ t) & zm;
+        }
+      }
       u64 mine = 0;
 #pragma unroll
       for (int b = 0; b < 16; ++b) {
@@ -92,8 +105,8 @@ __global__ __launch_bounds__(256) void pack_inputs_kernel(const PackArgs pa, u32
   }
   for (; k < k1; ++k) {
     const uint8_t v = valid ? row[k] : 0;
-    bad |= v > 1 && strict[k];
-    const u64 m = __ballot(v & 1);
+    bad |= v > 1 && strict[k] == 0xFF;
+    const u64 m = __ballot(strict[k] == 0x01 ? v != 0 : (v & 1) != 0);
     if (lane == 0) packed[(size_t)k * total_words + word] = m;
   }
   if (bad) atomicOr(&lane_flags[lane_g], kLaneFlagNonCanonical);

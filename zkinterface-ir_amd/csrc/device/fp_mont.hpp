@@ -73,14 +73,17 @@ __device__ __forceinline__ Fp<N> fp_bit_xor(const Fp<N>& a, const Fp<N>& b, cons
   }
   return fp_to_mont<N>(r, fp);
 }
-// `not` of PlaintextBackend (evaluator.rs:935-938): 1 if the value is zero, else 0.
+// 1 (Montgomery form) or 0: `not` of PlaintextBackend (evaluator.rs:935-938) is fp_indicator(the integer is zero)
 template <int N>
-__device__ __forceinline__ Fp<N> fp_is_zero_indicator(const Fp<N>& a, const FieldParams& fp) {
-  const bool z = fp_is_zero<N>(a);
+__device__ __forceinline__ Fp<N> fp_indicator(bool set, const FieldParams& fp) {
   Fp<N> r;
 #pragma unroll
-  for (int i = 0; i < N; ++i) r.w[i] = z ? fp.one[i] : 0u;
+  for (int i = 0; i < N; ++i) r.w[i] = set ? fp.one[i] : 0u;
   return r;
+}
+template <int N>
+__device__ __forceinline__ Fp<N> fp_is_zero_indicator(const Fp<N>& a, const FieldParams& fp) {
+  return fp_indicator<N>(fp_is_zero<N>(a), fp);
 }
 
 // a >= p ?

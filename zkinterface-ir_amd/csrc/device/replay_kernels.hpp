@@ -101,6 +101,26 @@ __device__ __forceinline__ Fp<N> input_load(const uint8_t* __restrict__ base, u3
   return r;
 }
 
+// The operand of an assert_zero / not that a constant, instance or witness value reaches through copies alone is, for the
+// reference, the UNREDUCED integer (evaluator.rs:862-864,896-906,932-946): a value >= p is not zero whatever its residue.
+// `code` (schedule.cpp track_unreduced_values): 0 = no such source, 1 = a constant >= p, 2 + 2 * position + is_witness =
+// an input, whose raw value is tested here beside the wire.
+template <int N, class Args>
+__device__ __forceinline__ bool unreduced_source_is_nonzero(u32 code, const Args& args, u32 lane_g, bool lane_valid,
+                                                            const FieldParams& fp) {
+  if (code < 2) return code == 1;
+  const u32 q = code - 2;
+  const bool is_wit = (q & 1) != 0;
+  const Fp<N> raw = input_load<N>(is_wit ? args.wit : args.inst, lane_g, is_wit ? args.n_wit : args.n_inst, q >> 1, lane_valid);
+  return lane_valid && fp_geq_p<N>(raw, fp);
+}
+
+// Input positions whose value must be canonical (mode 0xFF in Schedule::strict_instance / strict_witness: it reaches an
+// integer bit operation or Evaluator::get unreduced): a value >= p there flags the lane.
+__device__ __forceinline__ bool position_is_strict(const uint8_t* __restrict__ modes, u32 position) {
+  return modes[position] == 0xFF;
+}
+
 // One wave = 64 witnesses x `ops_per_wave` consecutive tape ops.
 // PIPE: operands of op i+1 are requested before op i is computed; legal only
 // when the ops of one wave are mutually independent (a level of the schedule).
@@ -155,16 +175,18 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       case OP_XOR:
         if constexpr (BITOPS) r = fp_bit_xor<N>(a, b, fp); else has_out = false;
         break;
-      case OP_NOT: r = fp_is_zero_indicator<N>(a, fp); break;
+      case OP_NOT:   // op.b: the unreduced source behind the operand, if any
+        r = fp_indicator<N>(fp_is_zero<N>(a) && !unreduced_source_is_nonzero<N>(op.b, args, lane_g, lane_valid, fp), fp);
+        break;
       case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a * N); break;
       case OP_INSTANCE:
       case OP_WITNESS: {
         const bool is_inst = op.kind == OP_INSTANCE;
         Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit,
                                   op.a, lane_valid);
-        if (op.b && fp_geq_p<N>(raw, fp)) {
-          // The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  op.b: this one can reach copy /
-          // assert_zero / not / a bit operation as it is, where the residue would not do: flag the lane.
+        if (position_is_strict(is_inst ? args.strict_inst : args.strict_wit, op.a) && lane_valid && fp_geq_p<N>(raw, fp)) {
+          // The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  This one can reach an integer bit
+          // operation or Evaluator::get as it is, where the residue would not do: flag the lane.
           atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
         }
         r = fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       }
       case OP_ASSERT: {
         has_out = false;
-        const bool nz = !fp_is_zero<N>(a);
+        const bool nz = !fp_is_zero<N>(a) || unreduced_source_is_nonzero<N>(op.dst, args, lane_g, lane_valid, fp);
         if (__ballot(nz && lane_valid) != 0ull) {
           if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b);
         }
@@ -274,19 +296,24 @@ __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict
       if constexpr (CLS == kFusedAll) r = fp_bit_xor<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
       else has_out = false;
       break;
-    case OP_NOT: r = fp_is_zero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
+    case OP_NOT:   // op.a1: the unreduced source behind the operand, if any
+      r = fp_indicator<N>(fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC)) &&
+                              !unreduced_source_is_nonzero<N>(op.a1, args, lane_g, lane_valid, fp), fp);
+      break;
     case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
     case OP_INSTANCE:
     case OP_WITNESS: {
       const bool is_inst = kind == OP_INSTANCE;
       Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0, lane_valid);
-      if (op.b0 && fp_geq_p<N>(raw, fp)) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);   // strict inputs only
+      if (position_is_strict(is_inst ? args.strict_inst : args.strict_wit, op.a0) && lane_valid && fp_geq_p<N>(raw, fp))
+        atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);   // strict positions only
       r = fp_to_mont<N>(raw, fp);
       break;
     }
     case OP_ASSERT: {
       has_out = false;
-      const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC));
+      const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC)) ||
+                      unreduced_source_is_nonzero<N>(op.a1, args, lane_g, lane_valid, fp);
       if (__ballot(nz && lane_valid) != 0ull) {
         if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b0);
       }

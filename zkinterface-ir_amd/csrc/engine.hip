@@ -189,8 +189,14 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
   auto slot = [&](size_t i, uint32_t v) {
     if (v >= s.n_slots) fail(i, ("a wire-table slot (" + std::to_string(v) + " of " + std::to_string(s.n_slots) + ")").c_str());
   };
+  // the unreduced source an assert_zero / not entry names (0 none, 1 a constant, 2 + 2 * position + is_witness)
+  auto source = [&](size_t i, uint32_t code) {
+    if (code < 2) return;
+    const uint32_t q = code - 2;
+    if ((q >> 1) >= ((q & 1) ? n_witness : n_instance)) fail(i, "the input position of its unreduced source");
+  };
   auto check = [&](size_t i, uint32_t kind, uint32_t dst, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t ea,
-                   uint32_t eb, uint32_t second, uint32_t dst2, uint32_t c0) {
+                   uint32_t eb, uint32_t second, uint32_t dst2, uint32_t c0, uint32_t src) {
     switch (kind) {
       case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR:
         slot(i, dst); slot(i, a0); slot(i, b0);
@@ -202,14 +208,15 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
         slot(i, dst); slot(i, a0);
         if (b0 >= n_consts) fail(i, "a constant");
         break;
-      case TK_COPY: case TK_NOT: case TK_NZ: slot(i, dst); slot(i, a0); break;
+      case TK_COPY: case TK_NZ: slot(i, dst); slot(i, a0); break;
+      case TK_NOT: slot(i, dst); slot(i, a0); source(i, src); break;
       case TK_CONST:
         slot(i, dst);
         if (a0 >= n_consts) fail(i, "a constant");
         break;
       case TK_INSTANCE: slot(i, dst); if (a0 >= n_instance) fail(i, "an instance position"); break;
       case TK_WITNESS: slot(i, dst); if (a0 >= n_witness) fail(i, "a witness position"); break;
-      case TK_ASSERT: slot(i, a0); break;
+      case TK_ASSERT: slot(i, a0); source(i, src); break;
       case TK_NOP: break;
       default: fail(i, "an unknown kind");
     }
@@ -227,10 +234,12 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
           const DevOp2& d = s.ops2[i];
           const uint32_t kind = d.kind & 0xFF, ea = (d.kind >> 8) & 3, eb = (d.kind >> 10) & 3, second = (d.kind >> 12) & 3;
           if ((d.kind >> 14) != 0 || ((ea || eb || second) && kind != TK_ADD && kind != TK_MUL)) fail(i, "its kind word");
-          check(i, kind, d.dst, d.a0, d.a1, d.b0, d.b1, ea, eb, second, d.pad0, d.pad1);
+          check(i, kind, d.dst, d.a0, d.a1, d.b0, d.b1, ea, eb, second, d.pad0, d.pad1, d.a1);
         } else {
           const DevOp& d = s.ops[i];
-          check(i, d.kind, d.dst, d.a, 0, d.b, 0, 0, 0, 0, 0, 0);
+          // (the unfused entry keeps the source code in the field its kind leaves unused: assert_zero dst, not b)
+          const uint32_t src = s.boolean_path ? 0 : d.kind == TK_ASSERT ? d.dst : d.kind == TK_NOT ? d.b : 0;
+          check(i, d.kind, d.kind == TK_ASSERT ? 0 : d.dst, d.a, 0, d.b, 0, 0, 0, 0, 0, 0, src);
         }
       }
     } catch (const std::exception& e) {
@@ -333,12 +342,13 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   HIP_OK(hipMemset(d_consts_, 0, cbytes));
   if (!s.const_words.empty())
     HIP_OK(hipMemcpy(d_consts_, s.const_words.data(), s.const_words.size() * 4, hipMemcpyHostToDevice));
-  if (boolean_) {
-    // per input position: 0xFF = a value > 1 flags the lane (padded to whole 16-byte rows of the packing kernel)
-    auto upload_mask = [&](void*& d, const std::vector<uint8_t>& strict, uint32_t n) {
+  {
+    // per input position, the mode the scheduler decided (schedule.cpp track_unreduced_values): 0xFF = a value >= p flags
+    // the lane; GF(2): 0x01 = packed as `v != 0` (read by zero tests only).  Padded to whole 16-byte rows of the packing kernel.
+    auto upload_mask = [&](void*& d, const std::vector<uint8_t>& modes, uint32_t n) {
       dfree(d);
       std::vector<uint8_t> m(((size_t)n + 31) / 16 * 16, 0);
-      for (size_t k = 0; k < strict.size() && k < n; ++k) m[k] = strict[k] ? 0xFF : 0;
+      for (size_t k = 0; k < modes.size() && k < n; ++k) m[k] = modes[k];
       HIP_OK(hipMalloc(&d, m.size()));
       HIP_OK(hipMemcpy(d, m.data(), m.size(), hipMemcpyHostToDevice));
     };
@@ -565,6 +575,8 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.n_wit = n_wit_;
     a.first_fail = (zkgpu::u32*)d_first_fail_;
     a.lane_flags = (zkgpu::u32*)d_flags_;
+    a.strict_inst = (const uint8_t*)d_strict_inst_;
+    a.strict_wit = (const uint8_t*)d_strict_wit_;
     if (L.sequential) {
       // a strand: one workgroup per lane block walks the levels of the run, barrier between levels
       a.xcd_chunks = 0;
@@ -608,6 +620,8 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   a.n_wit = n_wit_;
   a.first_fail = (zkgpu::u32*)d_first_fail_;
   a.lane_flags = (zkgpu::u32*)d_flags_;
+  a.strict_inst = (const uint8_t*)d_strict_inst_;
+  a.strict_wit = (const uint8_t*)d_strict_wit_;
   a.xcd_chunks = xcd_chunks;
   launch_plain(nwords_, sched_.has_bitops, grid, st, a, fp);
 }
@@ -1075,7 +1089,17 @@ void CountReducer::all_reduce(uint64_t totals[2]) {
   auto check_nccl = [&](int rc, const char* what) {
     if (rc != 0) throw std::runtime_error(std::string("RCCL: ") + what + ": " + ((nccl_error_string_t)fn_[5])(rc));
   };
+  // whatever happens between ncclGroupStart and ncclGroupEnd, the group is closed again: an open group would swallow
+  // every later collective of this thread
+  struct GroupGuard {
+    nccl_group_t end;
+    bool open = false;
+    ~GroupGuard() {
+      if (open) (void)end();
+    }
+  } group{(nccl_group_t)fn_[3]};
   check_nccl(((nccl_group_t)fn_[2])(), "ncclGroupStart");
+  group.open = true;
   for (size_t k = 0; k < engines_.size(); ++k) {
     HIP_OK(hipSetDevice(engines_[k]->device()));
     // on the engine's stream: ordered behind the verdict kernel of its replay
@@ -1083,10 +1107,12 @@ void CountReducer::all_reduce(uint64_t totals[2]) {
                                             (hipStream_t)engines_[k]->stream()),
                "ncclAllReduce");
   }
+  group.open = false;
   check_nccl(((nccl_group_t)fn_[3])(), "ncclGroupEnd");
   for (Engine* e : engines_) e->synchronize();
   HIP_OK(hipSetDevice(engines_[0]->device()));
   HIP_OK(hipMemcpy(totals, reduced_[0], 16, hipMemcpyDeviceToHost));
+  ++n_reductions_;
 }
 
 }  // namespace zki

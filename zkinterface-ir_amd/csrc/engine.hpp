@@ -197,6 +197,7 @@ class CountReducer {
   CountReducer(const CountReducer&) = delete;
   CountReducer& operator=(const CountReducer&) = delete;
   void all_reduce(uint64_t totals[2]);   // enqueue, wait, read the totals back from the first device
+  uint64_t reductions() const { return n_reductions_; }   // all-reduces that ran to the end
 
  private:
   std::vector<Engine*> engines_;
@@ -204,6 +205,7 @@ class CountReducer {
   std::vector<void*> reduced_;    // device u64[2] per engine
   void* lib_ = nullptr;
   void* fn_[6] = {nullptr};
+  uint64_t n_reductions_ = 0;
 };
 
 }  // namespace zki

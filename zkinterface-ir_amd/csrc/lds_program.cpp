@@ -42,8 +42,10 @@ bool lds_program_fits(const Schedule& s) {
   constexpr uint64_t kLdsBytes = 160 * 1024;
   return ((uint64_t)s.n_slots + zkgpu::kLdsExtraSlots) * 4 + 64 <= kLdsBytes &&
          s.n_slots + zkgpu::kLdsExtraSlots < 0xFFFF &&   // + scratch and constant slots, 16-bit slot numbers
-         // block headers carry 32-bit byte offsets into the row stream
-         (uint64_t)s.ops.size() * 6 + s.launches.size() * 24576ull + (1u << 22) < (1ull << 32);
+         // block headers carry 32-bit byte offsets into the row stream: 6 bytes per op + the padding of every kind-run of a
+         // level to whole rows (copy, and, xor, not: up to four runs per launch, each less than one row of 12288 bytes) +
+         // the slack rows behind the last block.  build_lds_program checks the real offsets again as it writes them.
+         (uint64_t)s.ops.size() * 6 + s.launches.size() * (4ull * zkgpu::kLdsRowOps * 6) + (1u << 22) < (1ull << 32);
 }
 
 LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& block_sizes, uint32_t forced_block_rows) {
@@ -113,7 +115,10 @@ LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& blo
       }
       const uint32_t id = (uint32_t)(blocks.size() / 2);
       blocks.push_back(desc);
-      blocks.push_back((open_first + (uint32_t)r * 1024u) * 12u);   // byte offset (lds_program_fits: below 4 GiB)
+      const uint64_t byte_offset = ((uint64_t)open_first + (uint64_t)r * 1024u) * 12u;
+      if (byte_offset + (uint64_t)block_rows * zkgpu::kLdsRowOps * 6 >= (1ull << 32))   // (lds_program_fits bounds it; never wrap silently)
+        throw std::runtime_error("Engine: the row stream of the LDS-resident GF(2) program exceeds 32-bit byte offsets");
+      blocks.push_back((uint32_t)byte_offset);
       // consecutive blocks form one run (one chunk)
       if (ln.size() >= 4 && (ln[ln.size() - 2] & zkgpu::kLdsChunkBlocks) && ln[ln.size() - 4] + ln[ln.size() - 1] == id)
         ++ln[ln.size() - 1];
@@ -138,7 +143,10 @@ LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& blo
       const bool last_kind = e >= L.count;
       const int rk = row_kind(kind);
       if (rk >= 0) {
-        if (open_kinds.empty()) open_first = (uint32_t)(lo6.size() / 6);   // in 12-byte thread records
+        if (open_kinds.empty()) {
+          if (lo6.size() / 6 > 0xFFFFFFFFull) throw std::runtime_error("Engine: the row stream of the LDS-resident GF(2) program is too long");
+          open_first = (uint32_t)(lo6.size() / 6);   // in 12-byte thread records
+        }
         size_t n = 0;
         auto put6 = [&](unsigned short dst, unsigned short a, unsigned short b) {
           lo6.push_back(dst);

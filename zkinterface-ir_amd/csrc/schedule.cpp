@@ -24,6 +24,7 @@ inline int n_inputs(uint8_t k) {
 }
 
 constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr uint32_t kSyntheticOne = 0xFFFFFFFEu;   // GF(2) CONST entry: the pool's synthetic 1 (resolved in finish())
 
 // Depth-first walk of the "reads the same wire" graph of one level: ops become neighbours of an op they
 // share an operand with, so the second reader of a wire runs while the first reader's fetch is still in
@@ -146,9 +147,19 @@ struct StreamScheduler::Impl {
   uint8_t st(uint32_t h) const { return state[h - lo]; }
   bool inner(uint32_t h) const { return h >= lo && (state[h - lo] == ST_FUSED || state[h - lo] == ST_PAIR_SHARED); }
 
-  std::vector<uint8_t> strict;           // sources: the value must not be reduced silently (see mark_strict_sources)
+  // Unreduced inputs (see track_unreduced_values): per handle over the whole tape, the source (constant / instance /
+  // witness op) whose integer value the handle carries unchanged -- itself for a source, the source of its operand for a
+  // copy, kInf for everything an arithmetic gate has produced -- and what the source is
+  std::vector<uint32_t> src_root;
+  std::vector<uint8_t> src_kind;         // per handle: TK_CONST / TK_INSTANCE / TK_WITNESS for sources, 0 otherwise
+  std::vector<uint32_t> src_pos;         // per source handle: input position, or 1 for a constant >= p (0: canonical)
+  std::vector<uint8_t> src_zero_test, src_other;   // per source handle: read by assert_zero / not through copies; by anything else
+  std::vector<uint32_t> sink_code;       // window: per op, for assert_zero / not reached from a source through copies alone:
+                                         // 1 = the source is a constant >= p, 2 + 2 * position + is_witness = an input
   void grow(uint32_t n);
-  void mark_strict_sources(const TapeWindow& w);
+  void track_unreduced_values(const TapeWindow& w);
+  void refuse_unreduced(uint32_t source, const char* consumer);
+  void finish_input_modes();
   void rewrite_ladders(const TapeWindow& w);
   void propagate_copies();
   void levelise();
@@ -170,46 +181,99 @@ void StreamScheduler::Impl::grow(uint32_t n) {
   flags.resize(n, 0);
   s.slot_of.resize(n, kNoWire);
   s.level_of.resize(n, 0);
+  src_root.resize(n, kInf);
+  src_kind.resize(n, 0);
+  src_pos.resize(n, 0);
+  src_zero_test.resize(n, 0);
+  src_other.resize(n, 0);
 }
 
 // PlaintextBackend keeps constants, instance and witness values UNREDUCED (evaluator.rs:862-864,896-898,940-946):
 // `copy` clones them as they are, `assert_zero` / `not` test the unreduced integer for zero, `and` / `xor` work on its
 // bits, `Evaluator::get` returns it -- while add / mul / add_constant / mul_constant reduce their result (`% m`), and
 // over GF(2) the low bit of `a & b` and `a ^ b` only depends on the low bits of a and b.  So a value >= p behaves like
-// its residue unless it reaches one of the former through copies alone.  This pass marks the sources of the window for
-// which that can happen ("strict"): the device reduces every other input on the fly (to_mont of a value < R is the
-// Montgomery form of its residue) and flags a lane only where a strict input is >= p.  A source that later windows may
-// still read (not closed) is strict by caution.
-void StreamScheduler::Impl::mark_strict_sources(const TapeWindow& w) {
-  const uint32_t n = hi - lo;
-  strict.assign(n, 0);
-  std::vector<uint8_t> sens(n, 0);
-  auto mark = [&](uint32_t h) {
-    if (h >= lo) sens[h - lo] = 1;
-  };
-  for (uint32_t i = hi; i-- > lo;) {
-    const uint8_t k = w.kind[i - lo];
-    const bool bit_op = (k == TK_AND || k == TK_XOR) && !field.is_two;
-    if (k == TK_ASSERT || k == TK_NOT || bit_op) {
-      mark(w.a[i - lo]);
-      if (bit_op) mark(w.b[i - lo]);
-    } else if (k == TK_COPY && (sens[i - lo] || !closed(i))) {
-      mark(w.a[i - lo]);
-    }
+// its residue unless it reaches one of the former through copies alone, and this pass follows every source through its
+// copies (forward, over the whole tape: `src_root` outlives the window):
+//   * assert_zero / not: a value >= p is NOT zero as an integer, whatever its residue -- decidable, so the sink gets the
+//     reference's answer.  GF(p): the sink's entry names the source (`sink_code`) and the kernel tests the raw input
+//     beside the wire (fused_entry / replay_kernel).  GF(2): a position read by such sinks alone is packed as `v != 0`
+//     instead of `v & 1` (pack_inputs_kernel, mode 0x01); a constant >= p read by such sinks alone becomes the constant 1.
+//   * and / xor over an odd field, `Evaluator::get` (a wire alive at the end): the bits of the unreduced integer matter.
+//     Refused: per lane for an input >= p at such a position (mode 0xFF, the lane is flagged), at finalize for a
+//     constant >= p.  Also refused: the GF(2) position (or constant) that feeds BOTH a zero test and a gate -- one bit
+//     cannot be `v & 1` and `v != 0` at once.
+// Everything else is reduced on load (to_mont of any value below R is the Montgomery form of its residue).
+// The modes are final when the tape has ended (finish_input_modes) and travel in Schedule::strict_instance /
+// strict_witness, not in the program entries: a streamed window has been uploaded long before its sources' last readers
+// are known, and the verdict must not depend on how the tape was cut.
+void StreamScheduler::Impl::refuse_unreduced(uint32_t r, const char* consumer) {
+  if (src_kind[r] == TK_CONST) {
+    if (src_pos[r])
+      throw Error(std::string("GPU backend: a constant >= the field characteristic reaches ") + consumer +
+                  " without passing through an arithmetic gate; the reference evaluates that on the unreduced integer "
+                  "(evaluator.rs:896-938) and this path does not");
+    return;
   }
+  std::vector<uint8_t>& pos = src_kind[r] == TK_INSTANCE ? s.strict_instance : s.strict_witness;
+  if (pos.size() <= src_pos[r]) pos.resize((size_t)src_pos[r] + 1, 0);
+  pos[src_pos[r]] = 0xFF;
+}
+
+void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
+  const uint32_t n = hi - lo;
+  sink_code.assign(n, 0);
   for (uint32_t i = lo; i < hi; ++i) {
     const uint8_t k = w.kind[i - lo];
-    if (k != TK_CONST && k != TK_INSTANCE && k != TK_WITNESS) continue;
-    strict[i - lo] = sens[i - lo] || !closed(i);
-    if (k == TK_CONST && w.b[i - lo] != 0 && strict[i - lo])
-      throw Error("GPU backend: a constant >= the field characteristic reaches copy / assert_zero / not / and / xor / "
-                  "Evaluator::get without passing through an arithmetic gate; the reference evaluates those on the unreduced "
-                  "integer (evaluator.rs:896-938) and this path does not");
-    if (k != TK_CONST && strict[i - lo]) {
-      std::vector<uint8_t>& pos = k == TK_INSTANCE ? s.strict_instance : s.strict_witness;
-      if (pos.size() <= w.a[i - lo]) pos.resize((size_t)w.a[i - lo] + 1, 0);
-      pos[w.a[i - lo]] = 1;
+    const uint32_t a = w.a[i - lo], b = w.b[i - lo];
+    if (k == TK_CONST || k == TK_INSTANCE || k == TK_WITNESS) {
+      src_root[i] = i;
+      src_kind[i] = k;
+      src_pos[i] = k == TK_CONST ? (b != 0 ? 1u : 0u) : a;   // tape: b != 0 marks a constant that is not canonical
+      continue;
     }
+    if (k == TK_COPY) {
+      src_root[i] = src_root[a];
+      continue;
+    }
+    const int ni = n_inputs(k);
+    const bool bit_op = (k == TK_AND || k == TK_XOR) && !field.is_two;
+    for (int q = 0; q < ni; ++q) {
+      const uint32_t r = src_root[q == 0 ? a : b];
+      if (r == kInf) continue;
+      if (k == TK_ASSERT || k == TK_NOT) {
+        src_zero_test[r] = 1;
+        sink_code[i - lo] = src_kind[r] == TK_CONST ? (src_pos[r] ? 1u : 0u) : 2u + 2u * src_pos[r] + (src_kind[r] == TK_WITNESS ? 1u : 0u);
+      } else {
+        src_other[r] = 1;
+        if (bit_op) refuse_unreduced(r, "and / xor");
+      }
+    }
+  }
+  if (final && w.pinned)   // wires alive at the end can be asked for with Evaluator::get, which returns the integer as it is
+    for (uint32_t h : *w.pinned)
+      if (h < hi && src_root[h] != kInf) {
+        src_other[src_root[h]] = 1;
+        refuse_unreduced(src_root[h], "Evaluator::get (a wire alive at the end)");
+      }
+}
+
+// after the last window: the input modes of the positions no refusal has claimed, and -- GF(2) -- the sources one bit
+// cannot serve
+void StreamScheduler::Impl::finish_input_modes() {
+  for (uint32_t h = 0; h < (uint32_t)src_kind.size(); ++h) {
+    if (!src_kind[h] || !src_zero_test[h]) continue;
+    if (src_kind[h] == TK_CONST) {
+      if (src_pos[h] && field.is_two && src_other[h])
+        refuse_unreduced(h, "assert_zero / not and, as its low bit, a gate");
+      continue;
+    }
+    std::vector<uint8_t>& pos = src_kind[h] == TK_INSTANCE ? s.strict_instance : s.strict_witness;
+    if (pos.size() <= src_pos[h]) pos.resize((size_t)src_pos[h] + 1, 0);
+    uint8_t& mode = pos[src_pos[h]];
+    if (mode == 0xFF) continue;
+    // 0x01: zero tests only.  0x02 (GF(p)): zero tests and arithmetic -- the kernels treat it like 0 (the sinks test the
+    // raw input themselves); the one caller that cares is zkgpu_set_inputs_from_messages with a value wider than the limbs
+    mode = !src_other[h] ? 0x01 : (field.is_two ? 0xFF : 0x02);
   }
 }
 
@@ -720,11 +784,6 @@ void StreamScheduler::Impl::assign_slots() {
         out[pos_of(g, lane)] = i;
       }
     }
-    if (getenv("ZKI_BANK_DEBUG")) {
-      size_t holes = 0;
-      for (size_t q = 0; q < cnt; ++q) holes += out[q] == kInf;
-      fprintf(stderr, "[bank] run of %zu: %zu holes after matching\n", cnt, holes);
-    }
     // what no matching could take (the last few ops of the run): into the holes as they come
     size_t r = 0;
     for (size_t q = 0; q < cnt; ++q) {
@@ -856,12 +915,14 @@ void StreamScheduler::Impl::emit_entries() {
           d.a0 = s.slot_of[x];
           d.b0 = y;
           break;
-        case TK_COPY: case TK_NOT: case TK_NZ: d.a0 = s.slot_of[x]; break;
+        case TK_COPY: case TK_NZ: d.a0 = s.slot_of[x]; break;
+        case TK_NOT: d.a0 = s.slot_of[x]; d.a1 = sink_code[i - lo]; break;   // a1: the unreduced source behind the operand
         case TK_CONST: d.a0 = x; break;
-        case TK_INSTANCE: case TK_WITNESS: d.a0 = x; d.b0 = strict[i - lo]; break;   // b0: flag the lane if the value is >= p
+        case TK_INSTANCE: case TK_WITNESS: d.a0 = x; break;
         case TK_ASSERT:
           d.a0 = s.slot_of[x];
           d.b0 = y;
+          d.a1 = sink_code[i - lo];
           break;
         default: break;
       }
@@ -886,12 +947,17 @@ void StreamScheduler::Impl::emit_entries() {
         d.a = s.slot_of[x];
         d.b = y;
         break;
-      case TK_COPY: case TK_NOT: case TK_NZ: d.a = s.slot_of[x]; break;
-      case TK_CONST: d.a = x; break;
-      case TK_INSTANCE: case TK_WITNESS: d.a = x; d.b = strict[i - lo]; break;
+      case TK_COPY: case TK_NZ: d.a = s.slot_of[x]; break;
+      case TK_NOT: d.a = s.slot_of[x]; d.b = field.is_two ? 0 : sink_code[i - lo]; break;   // b: the unreduced source behind the operand
+      case TK_CONST:
+        // GF(2): a constant >= 2 that only zero tests read (through copies) is `non-zero` to them: the constant 1
+        d.a = (field.is_two && src_pos[i] && src_zero_test[i] && !src_other[i]) ? kSyntheticOne : x;
+        break;
+      case TK_INSTANCE: case TK_WITNESS: d.a = x; break;
       case TK_ASSERT:
         d.a = s.slot_of[x];
         d.b = y;
+        d.dst = field.is_two ? 0 : sink_code[i - lo];
         break;
       default: break;
     }
@@ -975,6 +1041,7 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     for (uint32_t h : *w.pinned)
       if (h < w.hi) m.flags[h] = (uint8_t)((m.flags[h] | FL_PINNED) & ~FL_DROPPED);
   const uint32_t n = w.hi - w.lo;
+  m.track_unreduced_values(w);   // (also for an empty final window: the wires alive at the end are known only now)
   m.n_wlevels = 0;
   m.order.clear();
   static const bool profile = getenv("ZKI_SCHED_PROFILE") != nullptr;
@@ -988,7 +1055,6 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     m.state.assign(n, ST_ENTRY);
     m.ra.assign(w.a, w.a + n);
     m.rb.assign(w.b, w.b + n);
-    m.mark_strict_sources(w);
     m.rewrite_ladders(w);
     m.propagate_copies();
     lap();
@@ -1029,13 +1095,17 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
 Schedule StreamScheduler::finish(const std::vector<Value>& consts) {
   Impl& m = *impl_;
   Schedule& s = m.s;
+  m.finish_input_modes();
   // ---- constant pool in device form -------------------------------------
   const uint32_t n_consts = (uint32_t)consts.size();
   if (s.boolean_path) {
     s.words_per_const = 1;
-    s.const_words.resize(n_consts + 1);
+    s.const_words.resize(n_consts + 2);
     for (uint32_t i = 0; i < n_consts; ++i) s.const_words[i] = !consts[i].empty() && (consts[i][0] & 1);  // value mod 2
     s.const_words[n_consts] = 0;  // synthetic 0 for mul_constant by an even constant
+    s.const_words[n_consts + 1] = 1;  // synthetic 1: a constant >= 2 in front of zero tests (track_unreduced_values)
+    for (DevOp& d : s.ops)
+      if (d.kind == TK_CONST && d.a == kSyntheticOne) d.a = n_consts + 1;
     // arithmetic mod 2 on {0,1}: (a+b)%2 = xor, (a*b)%2 = and
     for (DevOp& d : s.ops) {
       if (d.kind == TK_ADD) d.kind = TK_XOR;
