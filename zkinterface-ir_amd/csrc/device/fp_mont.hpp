@@ -45,6 +45,8 @@ template <int N>
 __device__ __forceinline__ Fp<N> fp_to_mont(const Fp<N>& a, const FieldParams& fp);
 template <int N>
 __device__ __forceinline__ bool fp_geq_p(const Fp<N>& a, const FieldParams& fp);
+template <int N>
+__device__ __forceinline__ Fp<N> fp_cond_sub(const u32* t, u64 force, const FieldParams& fp, u64* borrow_out, const u32* pv = nullptr);
 
 // `and` / `xor` of PlaintextBackend over an odd field (evaluator.rs:924-933): the bit operation on the canonical
 // integers, then `% p`.  a & b <= min(a, b) < p needs no reduction; a ^ b < 2^bits(p) < 2p needs one subtraction.
@@ -62,15 +64,7 @@ __device__ __forceinline__ Fp<N> fp_bit_xor(const Fp<N>& a, const Fp<N>& b, cons
   Fp<N> r;
 #pragma unroll
   for (int i = 0; i < N; ++i) r.w[i] = x.w[i] ^ y.w[i];
-  if (fp_geq_p<N>(r, fp)) {
-    u64 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const u64 d = (u64)r.w[i] - fp.p[i] - borrow;
-      r.w[i] = (u32)d;
-      borrow = (d >> 63) & 1;
-    }
-  }
+  r = fp_cond_sub<N>(r.w, 0ull, fp, nullptr);   // a ^ b < 2^bits(p) < 2p
   return fp_to_mont<N>(r, fp);
 }
 // 1 (Montgomery form) or 0: `not` of PlaintextBackend (evaluator.rs:935-938) is fp_indicator(the integer is zero)
@@ -86,42 +80,145 @@ __device__ __forceinline__ Fp<N> fp_is_zero_indicator(const Fp<N>& a, const Fiel
   return fp_indicator<N>(fp_is_zero<N>(a), fp);
 }
 
+// a >= p ?  (defined behind the carry chains below)
+// ---- carry chains ----------------------------------------------------------------------------------------------------
+// hipcc lowers `c += (u64)a + b; s = (u32)c; c >>= 32` and its subtracting twin to 64-bit arithmetic: five VALU
+// instructions per word (a 32-bit add, a zero-extension move, two 64-bit adds, a shift) where the hardware has one --
+// v_addc_co_u32 / v_subb_co_u32 with the carry in an SGPR pair.  A modular add came out as ~105 VALU instructions, the
+// conditional subtraction that ends every Montgomery product as ~45.  Here a chain is a few asm statements of up to four
+// words each, the carry travelling between them in a 64-bit lane mask (an SGPR pair: "s" operands of VOP3b).
+// One SGPR (or VCC) is all the constant bus of gfx9 lets an instruction read, and the carry-in is one: the OTHER operands
+// of a chain have to be VGPRs -- the words of p are copied into registers for it (v_mov from the kernarg SGPRs; the
+// compiler rematerialises them where it is short of registers).
+template <int K, bool FIRST, bool SUB>
+__device__ __forceinline__ void carry_chunk(u32* r, const u32* a, const u32* b, u64& c) {
+  static_assert(K == 2 || K == 4, "");
+  if constexpr (K == 4) {
+    if constexpr (FIRST) {
+      if constexpr (SUB)
+        asm("v_sub_co_u32_e64 %0, %4, %5, %9\n\tv_subb_co_u32_e64 %1, %4, %6, %10, %4\n\tv_subb_co_u32_e64 %2, %4, %7, %11, %4\n\t"
+            "v_subb_co_u32_e64 %3, %4, %8, %12, %4"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&s"(c)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+      else
+        asm("v_add_co_u32_e64 %0, %4, %5, %9\n\tv_addc_co_u32_e64 %1, %4, %6, %10, %4\n\tv_addc_co_u32_e64 %2, %4, %7, %11, %4\n\t"
+            "v_addc_co_u32_e64 %3, %4, %8, %12, %4"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&s"(c)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    } else {
+      if constexpr (SUB)
+        asm("v_subb_co_u32_e64 %0, %4, %5, %9, %4\n\tv_subb_co_u32_e64 %1, %4, %6, %10, %4\n\tv_subb_co_u32_e64 %2, %4, %7, %11, %4\n\t"
+            "v_subb_co_u32_e64 %3, %4, %8, %12, %4"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "+s"(c)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+      else
+        asm("v_addc_co_u32_e64 %0, %4, %5, %9, %4\n\tv_addc_co_u32_e64 %1, %4, %6, %10, %4\n\tv_addc_co_u32_e64 %2, %4, %7, %11, %4\n\t"
+            "v_addc_co_u32_e64 %3, %4, %8, %12, %4"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "+s"(c)
+            : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    }
+  } else {
+    if constexpr (FIRST) {
+      if constexpr (SUB)
+        asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\tv_subb_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&s"(c) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+      else
+        asm("v_add_co_u32_e64 %0, %2, %3, %5\n\tv_addc_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(r[0]), "=&v"(r[1]), "=&s"(c) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+    } else {
+      if constexpr (SUB)
+        asm("v_subb_co_u32_e64 %0, %2, %3, %5, %2\n\tv_subb_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(r[0]), "=&v"(r[1]), "+s"(c) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+      else
+        asm("v_addc_co_u32_e64 %0, %2, %3, %5, %2\n\tv_addc_co_u32_e64 %1, %2, %4, %6, %2"
+            : "=&v"(r[0]), "=&v"(r[1]), "+s"(c) : "v"(a[0]), "v"(a[1]), "v"(b[0]), "v"(b[1]));
+    }
+  }
+}
+
+template <int N, bool SUB, int I = 0>
+__device__ __forceinline__ void carry_chain(u32* r, const u32* a, const u32* b, u64& c) {
+  static_assert(N % 2 == 0, "field widths are whole 64-bit limbs");
+  if constexpr (I < N) {
+    constexpr int K = (N - I >= 4) ? 4 : 2;
+    carry_chunk<K, I == 0, SUB>(r + I, a + I, b + I, c);
+    carry_chain<N, SUB, I + K>(r, a, b, c);
+  }
+}
+
+// r[i] = lanes of `mask` ? d[i] : s[i] (the mask is a 64-bit lane mask in an SGPR pair)
+template <int N, int I = 0>
+__device__ __forceinline__ void select_words(u32* r, const u32* s, const u32* d, u64 mask) {
+  if constexpr (I < N) {
+    if constexpr (N - I >= 4) {
+      asm("v_cndmask_b32_e64 %0, %4, %8, %12\n\tv_cndmask_b32_e64 %1, %5, %9, %12\n\tv_cndmask_b32_e64 %2, %6, %10, %12\n\t"
+          "v_cndmask_b32_e64 %3, %7, %11, %12"
+          : "=&v"(r[I]), "=&v"(r[I + 1]), "=&v"(r[I + 2]), "=&v"(r[I + 3])
+          : "v"(s[I]), "v"(s[I + 1]), "v"(s[I + 2]), "v"(s[I + 3]), "v"(d[I]), "v"(d[I + 1]), "v"(d[I + 2]), "v"(d[I + 3]), "s"(mask));
+      select_words<N, I + 4>(r, s, d, mask);
+    } else {
+      asm("v_cndmask_b32_e64 %0, %2, %4, %6\n\tv_cndmask_b32_e64 %1, %3, %5, %6"
+          : "=&v"(r[I]), "=&v"(r[I + 1]) : "v"(s[I]), "v"(s[I + 1]), "v"(d[I]), "v"(d[I + 1]), "s"(mask));
+      select_words<N, I + 2>(r, s, d, mask);
+    }
+  }
+}
+
+// the words of p in VGPRs (see above: a carry chain cannot read them from SGPRs)
+template <int N>
+__device__ __forceinline__ void p_words(u32 (&pv)[N], const FieldParams& fp) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) pv[i] = fp.p[i];
+}
+
+// the same, opaque to hipcc: it copies the words once and keeps them (left to itself it sinks the eight v_mov into every
+// branch that subtracts p -- cheap to recompute, so it recomputes them: 19 instead of 8 moves per program entry)
+template <int N>
+__device__ __forceinline__ void p_words_resident(u32 (&pv)[N], const FieldParams& fp) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(pv[i]) : "s"(fp.p[i]));
+}
+
+// t - p where that is not negative, else t; `force`: lanes whose value has a set bit above the N words (t >= 2^(32N) > p).
+// For t < 2p the result is canonical.  borrow_out (optional): lanes where t < p as N-word integers.  pv_in (optional): the
+// words of p already in VGPRs (p_words) -- a kernel that runs several operations per wave copies them once.
+template <int N>
+__device__ __forceinline__ Fp<N> fp_cond_sub(const u32* t, u64 force, const FieldParams& fp, u64* borrow_out, const u32* pv_in) {
+  u32 pv[N], d[N];
+  if (pv_in) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) pv[i] = pv_in[i];
+  } else {
+    p_words<N>(pv, fp);
+  }
+  u64 bw;
+  carry_chain<N, true>(d, t, pv, bw);
+  if (borrow_out) *borrow_out = bw;
+  Fp<N> r;
+  select_words<N>(r.w, t, d, force | ~bw);
+  return r;
+}
+
 // a >= p ?
 template <int N>
 __device__ __forceinline__ bool fp_geq_p(const Fp<N>& a, const FieldParams& fp) {
-  u64 borrow = 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    u64 d = (u64)a.w[i] - fp.p[i] - borrow;
-    borrow = (d >> 63) & 1;  // high bits set on underflow
-  }
-  return borrow == 0;
+  u32 pv[N], d[N];
+  p_words<N>(pv, fp);
+  u64 bw;
+  carry_chain<N, true>(d, a.w, pv, bw);
+  u32 ge;
+  asm("v_cndmask_b32_e64 %0, 1, 0, %1" : "=v"(ge) : "s"(bw));   // no borrow: a >= p
+  return ge != 0;
 }
 
 // r = (a + b) mod p for canonical a, b.
 template <int N>
-__device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
-  Fp<N> s, d;
-  u64 c = 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    c += (u64)a.w[i] + b.w[i];
-    s.w[i] = (u32)c;
-    c >>= 32;
-  }
-  u64 borrow = 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    u64 t = (u64)s.w[i] - fp.p[i] - borrow;
-    d.w[i] = (u32)t;
-    borrow = (t >> 63) & 1;
-  }
+__device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp, const u32* pv = nullptr) {
+  u32 s[N];
+  u64 carry;
+  carry_chain<N, false>(s, a.w, b.w, carry);
   // s >= p  <=>  carry-out of the add, or no borrow in the subtract
-  const bool use_d = (c != 0) | (borrow == 0);
-  Fp<N> r;
-#pragma unroll
-  for (int i = 0; i < N; ++i) r.w[i] = use_d ? d.w[i] : s.w[i];
-  return r;
+  return fp_cond_sub<N>(s, carry, fp, nullptr, pv);
 }
 
 // (acc_hi : acc_lo) += x * y with a 96-bit accumulator: one v_mad_u64_u32 whose carry-out (VCC) is
@@ -210,26 +307,14 @@ __device__ __forceinline__ void fp_mul_columns(u64& lo, u32& hi, const Fp<N>& a,
 }
 
 template <int N>
-__device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
+__device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp, const u32* pv = nullptr) {
   u64 lo = 0;
   u32 hi = 0;
   u32 m[N], t[N + 1];
   fp_mul_columns<N, 0>(lo, hi, a, b, m, t, fp);
   t[N] = (u32)lo;
   // t < 2p here; one conditional subtraction.
-  Fp<N> d;
-  u64 borrow = 0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-    u64 x = (u64)t[i] - fp.p[i] - borrow;
-    d.w[i] = (u32)x;
-    borrow = (x >> 63) & 1;
-  }
-  const bool use_d = (t[N] != 0) | (borrow == 0);
-  Fp<N> r;
-#pragma unroll
-  for (int i = 0; i < N; ++i) r.w[i] = use_d ? d.w[i] : t[i];
-  return r;
+  return fp_cond_sub<N>(t, __ballot(t[N] != 0), fp, nullptr, pv);
 }
 
 // N wave-uniform words (a coefficient in Montgomery form) read on the scalar path into SGPRs
@@ -276,18 +361,14 @@ __device__ __forceinline__ Fp<N> fp_dot(const Fp<N> (&v)[K], const FpS<N> (&c)[K
   fp_dot_columns<N, K, 0>(lo, hi, v, c, m, t, fp);
   t[N] = (u32)lo;
   for (u32 round = 0; round < rounds; ++round) {
-    u32 d[N];
-    u64 borrow = 0;
+    u64 bw;
+    const u64 top = __ballot(t[N] != 0);
+    const Fp<N> x = fp_cond_sub<N>(t, top, fp, &bw);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      u64 x = (u64)t[i] - fp.p[i] - borrow;
-      d[i] = (u32)x;
-      borrow = (x >> 63) & 1;
-    }
-    const bool ge = (t[N] != 0) | (borrow == 0);  // t >= p
-#pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = ge ? d[i] : t[i];
-    t[N] = ge ? t[N] - (u32)borrow : t[N];
+    for (int i = 0; i < N; ++i) t[i] = x.w[i];
+    // where p was subtracted (top | ~bw) and the N-word subtraction borrowed, the borrow comes out of the top word
+    u64 dec = top & bw;
+    asm("v_subbrev_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(t[N]), "+s"(dec));
   }
   Fp<N> r;
 #pragma unroll

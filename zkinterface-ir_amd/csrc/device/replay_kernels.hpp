@@ -257,9 +257,11 @@ __device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restric
   Fp<N> x0 = wire_load<N>(T + (size_t)op.a0 * REC), x1, y0 = wire_load<N>(T + (size_t)op.b0 * REC), y1;
   if (ea) x1 = wire_load<N>(T + (size_t)op.a1 * REC);
   if (eb) y1 = wire_load<N>(T + (size_t)op.b1 * REC);
-  if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp) : fp_mul<N>(x0, x1, fp);
-  if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp) : fp_mul<N>(y0, y1, fp);
-  Fp<N> r = kind == OP_ADD ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
+  u32 pv[N];   // the words of p in VGPRs, once per entry: every carry chain below subtracts them (fp_mont.hpp)
+  p_words_resident<N>(pv, fp);
+  if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp, pv) : fp_mul<N>(x0, x1, fp, pv);
+  if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp, pv) : fp_mul<N>(y0, y1, fp, pv);
+  Fp<N> r = kind == OP_ADD ? fp_add<N>(x0, y0, fp, pv) : fp_mul<N>(x0, y0, fp, pv);
   u32 dst_slot = op.dst;
   const u32 pair = (op.kind >> 12) & 3;
   if (pair) {
@@ -267,7 +269,7 @@ __device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restric
     // gate's other operand into registers the first no longer needs, and let the common store write it
     wire_store<N>(T + (size_t)dst_slot * REC, r);
     y0 = wire_load<N>(T + (size_t)op.pad1 * REC);
-    r = pair == 1 ? fp_add<N>(x0, y0, fp) : fp_mul<N>(x0, y0, fp);
+    r = pair == 1 ? fp_add<N>(x0, y0, fp, pv) : fp_mul<N>(x0, y0, fp, pv);
     dst_slot = op.pad0;
   }
   wire_store<N>(T + (size_t)dst_slot * REC, r);
