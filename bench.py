@@ -82,12 +82,13 @@ def check_probe_outputs(name, wl, outs, lane_offset):
     oracle-chain hashes, so a wrong but self-consistent device result cannot pass.  Returns how many lanes were checked."""
     hashes = golden_hashes(name)
     default = (name == 'c2' and (wl.W, wl.D) == (4096, 256)) or (name == 'c4' and (wl.W, wl.D) == (16384, 640))
-    if hashes is None or not default or lane_offset + len(outs) > len(hashes):
+    if hashes is None or not default:
         return 0
-    for lane in range(len(outs)):
+    covered = max(0, min(len(outs), len(hashes) - lane_offset))     # (the fixtures hold 8192 lanes of C2, 4096 of C4)
+    for lane in range(covered):
         h = hashlib.sha256(np.ascontiguousarray(outs[lane], dtype=np.uint8).tobytes()).hexdigest()[:16]
         assert h == hashes[lane + lane_offset], 'lane %d: probe outputs differ from tests/golden/%s_all_lanes.json' % (lane + lane_offset, name)
-    return len(outs)
+    return covered
 
 
 class _DevU64x2:
@@ -565,6 +566,27 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(wl, msgs, inst, wit, gates, ev, cpu_budget_s, with_opt=headline)
     ev.close()
+
+    if rank == 0 and world == 1 and name == 'c4' and lds and not width and not bpg and not args.timed_steps_only:
+        # the LDS-resident kernel gives every 32-witness slice a workgroup of its own that walks the whole program: the
+        # BASELINE batch of 4096 fills 128 of the 256 CUs.  The same program over 8192 witnesses fills the chip.
+        vb = 8192
+        vev, _, _, vbad, _, vhost = build_session(zk, name, wl, vb, 0, 0, bool_path, args.streams)
+        for _ in range(2):
+            vev.replay()
+        vev.synchronize()
+        vms = []
+        for _ in range(10):
+            vev.replay()
+            vev.synchronize()
+            vms.append(vev.last_replay_ms)
+        assert list(vev.counts()) == [workloads.expected_satisfied(vb), vbad]
+        vk = float(np.mean(vms))
+        out['batch_8192'] = {'batch': vb, 'workgroups': vb // 32, 'ms_per_step': vk, 'value': gates * vb / (vk * 1e-3), 'unit': 'gate-ops/s',
+                             'lanes_checked_against_golden_hashes': vhost['lanes_checked_against_golden_hashes'],
+                             'what': 'same relation, 8192 witnesses = 256 workgroups, one per CU; ms_per_step is the HIP-event time of '
+                                     'the replay (input packing + the LDS-resident kernel + the verdict reduction)'}
+        vev.close()
 
     if rank == 0 and world == 1 and name == 'c2' and headline and not args.no_hbm_variant and not width and not bpg:
         # the same relation with 4096 witnesses replayed at once: a 1.05 GB wire table cannot sit in the 256 MiB

@@ -11,6 +11,8 @@ from zkinterface_ir_amd.sieve_writer import int_to_le, write_instance, write_rel
 BN254_R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 BLS12_381_Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab  # 381 bits
 P320 = 2 ** 320 - 197  # a 320-bit prime (five 64-bit limbs)
+P448 = 2 ** 448 - 2 ** 224 - 1  # the Ed448 'Goldilocks' prime (seven limbs)
+P512 = 2 ** 512 - 569  # the largest prime below 2^512 (eight limbs: the widest field the kernels are built for)
 
 
 def lit32(v):

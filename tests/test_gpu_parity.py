@@ -101,7 +101,7 @@ def _batched_example(modulus, lanes):
 
 
 @pytest.mark.parametrize('modulus', [101, circuits.BN254_R, 2 ** 61 - 1, 2 ** 127 - 1, circuits.P320,
-                                     circuits.BLS12_381_Q])
+                                     circuits.BLS12_381_Q, circuits.P448, circuits.P512])
 def test_batched_example_matches_oracle_per_lane(modulus):
     """One relation, many (instance, witness) pairs: lane i == i-th reference run."""
     lanes = 70  # spans two 64-lane blocks, ragged tail
@@ -131,7 +131,7 @@ def test_batched_example_matches_oracle_per_lane(modulus):
     assert w == 8 * ((modulus.bit_length() + 63) // 64)
 
 
-@pytest.mark.parametrize('modulus', [101, circuits.BN254_R, 2 ** 61 - 1, circuits.P320])
+@pytest.mark.parametrize('modulus', [101, circuits.BN254_R, 2 ** 61 - 1, circuits.P320, circuits.P512])
 def test_switch_weights_in_the_production_schedule(modulus):
     """The compact schedule (exponent ladder of every Switch weight replaced by one `x != 0` entry, copies
     propagated, gates fused) against one oracle run per lane; the lanes take the first branch, the second branch

@@ -76,12 +76,12 @@ def test_scheduled_program_matches_oracle(name, retain):
         assert info['slots'] < ev.n_value_ops  # liveness actually reuses slots
 
 
-@pytest.mark.parametrize('p', [circuits.P320, circuits.BLS12_381_Q])
+@pytest.mark.parametrize('p', [circuits.P320, circuits.BLS12_381_Q, circuits.P448, circuits.P512])
 def test_fields_wider_than_256_bits(p):
-    """five- and six-limb fields (up to 384 bits) through recording, scheduling and the interpreter"""
+    """five- to eight-limb fields (up to 512 bits) through recording, scheduling and the interpreter"""
     inst, wit, rel = circuits.arith_example(p)
     bufs = [inst, wit, rel]
-    ref = OracleRun(buffers=bufs, width=48)
+    ref = OracleRun(buffers=bufs, width=64)
     assert ref.violations == []
     for retain in (True, False):
         ev = zk.Evaluator.from_messages(bufs)
@@ -94,8 +94,8 @@ def test_fields_wider_than_256_bits(p):
             vals = [program_sim.from_device_form(slots[slot_of[i]], p, info['words_per_const'])
                     for i in range(len(kinds)) if kinds[i] != 9]
             assert vals == ref.trace_values()
-    too_wide = circuits.arith_example(2 ** 400 + 1)[2]
-    assert any('wider than 384 bits' in m for m in zk.Evaluator.from_messages([too_wide]).host_violations())
+    too_wide = circuits.arith_example(2 ** 520 + 1)[2]
+    assert any('wider than 512 bits' in m for m in zk.Evaluator.from_messages([too_wide]).host_violations())
 
 
 def test_reader_file_ordering_and_framing(tmp_path):

@@ -13,7 +13,7 @@ namespace zkgpu {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-constexpr int kMaxWords = 12;  // fields up to 384 bits
+constexpr int kMaxWords = 16;  // fields up to 512 bits
 
 // Per-field constants, passed by value in the kernarg segment (wave-uniform:
 // the compiler keeps them in SGPRs).
@@ -22,7 +22,7 @@ struct FieldParams {
   u32 r2[kMaxWords];   // R^2 mod p   (to_mont multiplier)
   u32 one[kMaxWords];  // R mod p     (Montgomery form of 1)
   u32 n0inv;           // -p^{-1} mod 2^32
-  u32 nwords;          // N actually used (2, 4, ..., 12)
+  u32 nwords;          // N actually used (2, 4, ..., 16)
   // conditional subtractions that make the lazily reduced sum of K Montgomery products canonical: the sum is below
   // (K * p / R + 1) * p, so ceil(K * p / R) of them (host: Engine::load_program); index K - 1, K = 1..4
   u32 dot_rounds[4];
@@ -200,6 +200,8 @@ ZKGPU_DECLARE_WIDTH(6)
 ZKGPU_DECLARE_WIDTH(8)
 ZKGPU_DECLARE_WIDTH(10)
 ZKGPU_DECLARE_WIDTH(12)
+ZKGPU_DECLARE_WIDTH(14)
+ZKGPU_DECLARE_WIDTH(16)
 #undef ZKGPU_DECLARE_WIDTH
 
 void launch_verdict(dim3 grid, hipStream_t st, const u32* first_fail, const u32* lane_flags, u32 batch,

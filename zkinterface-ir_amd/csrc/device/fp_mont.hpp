@@ -8,7 +8,7 @@
 // 32x32 (v_mad_u64_u32).  All results are canonical (< p), which is what makes
 // from_mont(x) bit-identical to the reference's reduced BigUint.
 //
-// Requirements: p odd, p < 2^(32*N), N <= 12 (384 bits).  p = 2 is handled by the Boolean path.
+// Requirements: p odd, p < 2^(32*N), N <= 16 (512 bits).  p = 2 is handled by the Boolean path.
 #pragma once
 #include "args.hpp"
 
@@ -249,7 +249,7 @@ __device__ __forceinline__ Fp<N> fp_add(const Fp<N>& a, const Fp<N>& b, const Fi
 #define ZKGPU_MT0(i, j) "v_mad_u64_u32 %0, vcc, %" #i ", %" #j ", %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc\n\t"
 template <int K, bool SC, bool FIRST = false>
 __device__ __forceinline__ void madc_run(u64& lo, u32& hi, const u32* x, const u32* y) {
-  static_assert(K >= 1 && K <= 12, "");
+  static_assert(K >= 1 && K <= 16, "");
 #define ZKGPU_IN(j) "v"(x[j]), "v"(y[-(j)])
 #define ZKGPU_IS(j) "v"(x[j]), "s"(y[-(j)])
   if constexpr (K == 1) { if constexpr (FIRST) { if constexpr (SC) asm(ZKGPU_MT0(2, 3) : "+v"(lo), "=&v"(hi) : ZKGPU_IS(0) : "vcc"); else asm(ZKGPU_MT0(2, 3) : "+v"(lo), "=&v"(hi) : ZKGPU_IN(0) : "vcc"); } else { if constexpr (SC) asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IS(0) : "vcc"); else asm(ZKGPU_MT(2, 3) : "+v"(lo), "+v"(hi) : ZKGPU_IN(0) : "vcc"); } }

@@ -258,7 +258,8 @@ __device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restric
   if (ea) x1 = wire_load<N>(T + (size_t)op.a1 * REC);
   if (eb) y1 = wire_load<N>(T + (size_t)op.b1 * REC);
   u32 pv[N];   // the words of p in VGPRs, once per entry: every carry chain below subtracts them (fp_mont.hpp)
-  p_words_resident<N>(pv, fp);
+  if constexpr (N <= 12) p_words_resident<N>(pv, fp);
+  else p_words<N>(pv, fp);   // (beyond 384 bits the kernel is short of registers: let hipcc rematerialise them)
   if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp, pv) : fp_mul<N>(x0, x1, fp, pv);
   if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp, pv) : fp_mul<N>(y0, y1, fp, pv);
   Fp<N> r = kind == OP_ADD ? fp_add<N>(x0, y0, fp, pv) : fp_mul<N>(x0, y0, fp, pv);

@@ -27,7 +27,7 @@ static_assert(sizeof(DevOp) == sizeof(zkgpu::TapeOp), "DevOp must match the devi
 static_assert(sizeof(DevOp2) == sizeof(zkgpu::TapeOp2), "DevOp2 must match the device TapeOp2");
 static_assert(sizeof(R1csRowDev) == sizeof(zkgpu::R1csRow) && sizeof(R1csTermDev) == sizeof(zkgpu::R1csTerm),
               "host and device R1CS records must match");
-static_assert(sizeof(zkgpu::FieldParams) <= 192, "FieldParams must fit Engine::field_params_");
+static_assert(sizeof(zkgpu::FieldParams) <= 256, "FieldParams must fit Engine::field_params_");
 
 template <typename T>
 void dfree(T*& p) {
@@ -38,7 +38,7 @@ void dfree(T*& p) {
 }
 
 // one launcher set per field width (kernels_arith.hip)
-#define ZK_WIDTHS(X) X(2) X(4) X(6) X(8) X(10) X(12)
+#define ZK_WIDTHS(X) X(2) X(4) X(6) X(8) X(10) X(12) X(14) X(16)
 void launch_fused(uint32_t nwords, int cls, dim3 grid, size_t lds_pad, hipStream_t st, const zkgpu::ReplayArgs2& a,
                   const zkgpu::FieldParams& fp) {
   switch (nwords) {

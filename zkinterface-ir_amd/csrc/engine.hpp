@@ -180,7 +180,7 @@ class Engine {
   // pinned wires (Evaluator::get) need the LDS-resident values written back to HBM
   void set_writeback(bool on) { force_writeback_ = on; graph_dirty_ = true; }
  private:
-  unsigned char field_params_[192];  // zkgpu::FieldParams, opaque here
+  unsigned char field_params_[256];  // zkgpu::FieldParams, opaque here
 };
 
 // One process driving several GPUs: the {satisfied, failed} counters of engines on DISTINCT devices are combined by an

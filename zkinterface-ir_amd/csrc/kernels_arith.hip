@@ -1,4 +1,4 @@
-// GF(p) kernels for ONE field width: compiled once per width with -DZKGPU_W=<32-bit words> (2, 4, ..., 12), so
+// GF(p) kernels for ONE field width: compiled once per width with -DZKGPU_W=<32-bit words> (2, 4, ..., 16), so
 // the six widths build in parallel and the engine's host code instantiates no kernel.  Defines the launchers
 // declared in device/args.hpp.
 #include "device/r1cs_kernels.hpp"

@@ -49,7 +49,7 @@ void FieldHost::init(const Value& modulus_le) {
   *this = FieldHost();
   const size_t n = significant_bytes(modulus_le);
   if (n == 0) throw Error("Modulus cannot be zero.");  // evaluator.rs:868-869
-  if (n > 4 * (size_t)W) throw Error("GPU backend: field characteristic wider than 384 bits is not supported");
+  if (n > 4 * (size_t)W) throw Error("GPU backend: field characteristic wider than 512 bits is not supported");
   for (size_t i = 0; i < n; ++i) p[i / 4] |= (uint32_t)modulus_le[i] << (8 * (i % 4));
   for (int i = W - 1; i >= 0 && bits == 0; --i)
     if (p[i]) bits = 32 * i + (32 - __builtin_clz(p[i]));

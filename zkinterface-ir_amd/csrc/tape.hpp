@@ -23,13 +23,13 @@ const char* tape_kind_name(uint8_t k);  // names of SURVEY.md Appendix A ("copy"
 
 constexpr uint32_t kNoWire = 0xFFFFFFFFu;
 
-constexpr int kFieldWords = 12;  // 32-bit words of the widest supported field (384 bits)
+constexpr int kFieldWords = 16;  // 32-bit words of the widest supported field (512 bits)
 
-// Host-side description of GF(p), p < 2^384: limbs and Montgomery constants
+// Host-side description of GF(p), p < 2^512: limbs and Montgomery constants
 // for the device (device/fp_mont.hpp FieldParams), plus canonicalisation of
 // arbitrary-length little-endian Values.
 struct FieldHost {
-  uint32_t nwords = 0;          // 32-bit words in use: 2, 4, ..., 12 (64-bit limb granularity)
+  uint32_t nwords = 0;          // 32-bit words in use: 2, 4, ..., 16 (64-bit limb granularity)
   uint32_t bits = 0;
   bool is_two = false;          // p == 2: Boolean/bit-packed path, no Montgomery form
   uint32_t p[kFieldWords] = {0}, r2[kFieldWords] = {0}, one[kFieldWords] = {0};
