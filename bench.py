@@ -532,9 +532,10 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
         roofline = make_roofline(name, kernel, max(wide_launches, 1), step_kernel_ms, algo_bytes_per_lane * batch, program,
                                  1 if lds else args.streams)
         if structured and 'counters' not in roofline:
-            roofline['binding'] = 'launch latency'
-            roofline['reading'] = ('%d launches of a few thousand entries per replay: the kernels are shorter than the '
-                                   'dependent-launch boundary' % info['launches'])
+            roofline['binding'] = 'as C2 (the same kernels at the same rate per program entry); no counters collected for this program'
+            roofline['reading'] = ('%d launches of 1,408 - 8,448 entries; %.2f us per 1000 entry-waves (C2: 259 launches of ~2,500 '
+                                   'entries run at about 0.8 us per 1000 entry-waves)'
+                                   % (info['launches'], step_kernel_ms * 1e3 / (info['device_ops'] * ((batch + 63) // 64) / 1000.0)))
         n_dev = ctx['n_dev']
         out = {
             'metric': metric,

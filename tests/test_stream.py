@@ -12,6 +12,7 @@ from helpers import batch_arrays, oracle_lane
 from random_circuits import Gen
 from test_fuzz_host import FIELDS, expected_product_violations
 import zkinterface_ir_amd as zk
+from zkinterface_ir_amd import sieve_writer as sw
 from zkinterface_ir_amd import workloads
 
 
@@ -204,3 +205,21 @@ def test_full_size_c2_streamed_matches_the_committed_oracle_digests():
     for lane, want in fx['lanes'].items():
         vals = [col[int(lane)] for col in cols]
         assert hashlib.sha256('\n'.join(str(v) for v in vals).encode()).hexdigest() == want['sha256'], lane
+
+
+def test_scheduling_options_are_refused_once_a_streamed_schedule_has_started():
+    """the streamed scheduler takes its options at the first window cut: a later zkgpu_set_option would be ignored by the
+    windows already scheduled, so it is an error instead"""
+    gates = [('witness', 0)] + [('addc', k, k - 1, bytes([1])) for k in range(1, 60)] + [('free', 0, 59)]
+    rel = sw.write_relation(sw.int_to_le(101), 'arithmetic', 'simple', [], gates)
+    ev = zk.Evaluator()
+    ev.set_option('stream', '16')
+    ev.set_option('fuse', '0')               # before the first Relation message: fine
+    ev.declare_inputs(0, 1)
+    ev.ingest_message(rel)
+    for key in ('fuse', 'pair', 'fermat', 'propagate_copies', 'sort_by_operand', 'strand_width'):
+        with pytest.raises(zk.ZkGpuError, match='the streamed schedule has started'):
+            ev.set_option(key, '1')
+    ev.set_option('streams', '1')            # a replay option: still fine
+    ev.finalize()
+    assert ev.stream_info()['windows'] > 1

@@ -954,6 +954,11 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes) {
 int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
   return guarded(s, [&] {
     const std::string k = key ? key : "", v = value ? value : "";
+    // the scheduler of a streamed ingest took its options when the first window was cut: a later change would be ignored
+    // silently by the windows already scheduled -- refuse it instead
+    if (s->stream && (k == "fuse" || k == "pair" || k == "fermat" || k == "propagate_copies" || k == "sort_by_operand" ||
+                      k == "bank_aware" || k == "strand_width" || k == "schedule_threads"))
+      throw std::runtime_error(k + ": the streamed schedule has started (option \"stream\"); set scheduling options before the first Relation message");
     if (k == "bool_path") {
       if (v == "auto") s->bool_path = 0;
       else if (v == "hbm") s->bool_path = 1;
