@@ -182,6 +182,8 @@ size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size
  * order.  Not available with several devices: zkgpu_set_inputs_device, zkgpu_counts_device, zkgpu_stream,
  * zkgpu_replay_timed and the R1CS entry points.  Set before the first zkgpu_set_inputs* call.  Default: one engine on
  * the thread's current device),
+ * "inspect_segment" = k | "" (which field segment zkgpu_tape_dump, zkgpu_schedule_info / _dump, the constant pool,
+ * zkgpu_modulus and zkgpu_input_modes(.., 2, ..) describe; default: the last one),
  * "force_rccl" = 0|1 (zkgpu_counts always goes through ncclCommInitAll + ncclAllReduce, also for a single engine -- a
  * communicator of one rank -- and an RCCL failure is an error instead of falling back to the host sum; default 0),
  * "stream" = 0 | 1 | N (streaming ingest, rust/src/consumers/evaluator.rs:286-301: the reference consumes a relation
@@ -241,6 +243,21 @@ void* zkgpu_counts_device(zkgpu_session* s);                  /* device uint64[2
 void* zkgpu_stream(zkgpu_session* s);                         /* hipStream_t the replay runs on */
 int zkgpu_device_count(void);                                 /* GPUs the HIP runtime sees (-1: none / no runtime) */
 int zkgpu_n_engines(const zkgpu_session* s);                  /* engines the batch is split over (option "devices") */
+/* Field segments.  The reference takes the modulus afresh from every message header
+ * (rust/src/consumers/evaluator.rs:232-237, :262-268): a Relation message may continue under another field characteristic,
+ * the wires of the scope live on as the integers they are.  zkgpu_ingest_* open a new FIELD SEGMENT for that -- a
+ * backend, a schedule and an engine per field; the wires alive at the boundary become inputs of the next segment
+ * (canonical integers written out by the segment before it, subject to the same rules as any unreduced input, see
+ * zkgpu_input_modes); the segments replay one after the other on one stream and share the verdict words, assert
+ * sequence numbers run through them.  zkgpu_elem_bytes is then the width of the WIDEST field: instance / witness values
+ * are handed over in that width whichever segment consumes them (a value that does not fit the limbs of the field that
+ * consumes it flags its lane).  Not supported, with an error that says so: a change between GF(2) and another field, a
+ * change on a caller-driven backend (zkgpu_backend_set_field: the library cannot see which wires are alive), several
+ * devices, R1CS entry points, zkgpu_replay_timed; option "stream" is switched off at the first change.
+ * _info: out = {values carried in, first assert sequence number, 32-bit words per value, values carried out}. */
+int zkgpu_n_field_segments(const zkgpu_session* s);
+int zkgpu_field_segment_info(const zkgpu_session* s, uint32_t k, uint32_t out[4]);
+int zkgpu_field_segment_carried(const zkgpu_session* s, uint32_t k, uint32_t* slots, uint32_t cap);
 uint64_t zkgpu_rccl_reductions(const zkgpu_session* s);       /* zkgpu_counts calls answered by an RCCL all-reduce */
 size_t zkgpu_rccl_note(const zkgpu_session* s, char* buf, size_t cap); /* why RCCL was not used ("" = it was, or was not needed) */
 int zkgpu_lane_results(zkgpu_session* s, uint32_t* first_fail, uint32_t* flags); /* [batch] each */

@@ -6,10 +6,11 @@ levelisation, slot reuse, constant pool -- against the oracle without a GPU.
 It is not a product path and is never imported outside tests/."""
 
 OP = {'nop': 0, 'add': 1, 'mul': 2, 'addc': 3, 'mulc': 4, 'copy': 5, 'const': 6, 'instance': 7, 'witness': 8,
-      'assert': 9, 'and': 10, 'xor': 11, 'not': 12, 'nz': 13}
+      'assert': 9, 'and': 10, 'xor': 11, 'not': 12, 'nz': 13, 'carry': 14}
 
 
-def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None, modes=None):
+def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None, modes=None,
+             carries=()):
     """Run one lane.  instances / witnesses: python ints.  Returns (slots, first_fail_seq, noncanonical).
     modes = (instance modes, witness modes) as zkgpu_input_modes gives them (how a value >= p is treated per position:
     0xFF flags the lane; GF(2): 0x01 packs `v != 0`); None = every position 0.
@@ -27,10 +28,13 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
         for k in range(words_per_const):
             v |= int(const_words[i * words_per_const + k]) << (32 * k)
         consts.append(v)
-    inst_modes, wit_modes = modes if modes is not None else ([], [])
+    mode_lists = list(modes) if modes is not None else []
+    while len(mode_lists) < 3:
+        mode_lists.append([])
+    streams = (instances, witnesses, carries)
 
-    def mode_of(is_witness, position):
-        m = wit_modes if is_witness else inst_modes
+    def mode_of(stream, position):
+        m = mode_lists[stream]
         return m[position] if position < len(m) else 0
 
     def source_is_nonzero(code):
@@ -38,7 +42,7 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
         if code < 2:
             return code == 1
         q = code - 2
-        v = (witnesses if q & 1 else instances)[q >> 1]
+        v = streams[q & 3][q >> 2]
         return v >= p
     slots = [None] * n_slots
     first_fail = None
@@ -106,9 +110,12 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                 r = 1 - slots[a] if boolean else (R % p if slots[a] == 0 and not source_is_nonzero(code) else 0)
             elif kind == OP['const']:
                 r = consts[a]
-            elif kind in (OP['instance'], OP['witness']):
-                v = instances[a] if kind == OP['instance'] else witnesses[a]
-                mode = mode_of(kind == OP['witness'], a)
+            elif kind in (OP['instance'], OP['witness'], OP['carry']):
+                stream = {OP['instance']: 0, OP['witness']: 1, OP['carry']: 2}[kind]
+                v = streams[stream][a]
+                mode = mode_of(stream, a)
+                if not boolean and v >= R:      # wider than the limbs of this field: cannot be represented, the lane is flagged
+                    noncanon = True
                 if v >= p and mode == 0xFF:     # the unreduced value would reach an integer bit operation / Evaluator::get
                     noncanon = True
                 r = ((1 if v else 0) if mode == 0x01 else (v & 1)) if boolean else (v * R % p)

@@ -1,0 +1,205 @@
+"""A relation whose field characteristic changes between Relation messages.  The reference takes the modulus afresh from
+every message header (rust/src/consumers/evaluator.rs:232-237, :262-268): later messages compute under the new modulus and
+the wires alive in the scope live on as the integers they are.  The product opens a new FIELD SEGMENT (backend, schedule,
+engine per field); the wires of the scope become `carry` inputs of the next segment -- unreduced integers, with the same
+rules as any value >= p (tests/test_unreduced.py).  CPU tier: recording + scheduling of every segment, interpreted by
+program_sim segment after segment, against the oracle's run of the same messages.  GPU tier: the same through the kernels."""
+import numpy as np
+import pytest
+
+import circuits
+import program_sim
+from helpers import batch_arrays, oracle_lane
+from test_fuzz_host import expected_product_violations
+import zkinterface_ir_amd as zk
+from zkinterface_ir_amd import sieve_writer as sw
+
+P1, P2, P3 = 101, 2 ** 61 - 1, 97
+
+
+def _messages(parts):
+    """parts: [(modulus, gateset, gates), ...] -> one Relation message each"""
+    return [sw.write_relation(sw.int_to_le(p), gateset, 'simple', [], gates) for p, gateset, gates in parts]
+
+
+def _session(msgs, n_inst, n_wit, retain=False):
+    ev = zk.Evaluator()
+    ev.declare_inputs(n_inst, n_wit)
+    for m in msgs:
+        ev.ingest_message(m)
+    ev.finalize(retain_all=retain)
+    return ev
+
+
+def _simulate(ev, moduli, inst, wit):
+    """program_sim over the field segments in order; returns (first failing assert or None, flagged)"""
+    assert ev.n_field_segments == len(moduli)
+    carries, first_fail, flagged = [], None, False
+    for k, p in enumerate(moduli):
+        ev.set_option('inspect_segment', str(k))
+        ops, launches, consts, _ = ev.schedule_dump()
+        info = ev.schedule_info()
+        seg = ev.field_segment_info(k)
+        assert seg['carried_in'] == len(carries) and ev.modulus_le() == sw.int_to_le(p)
+        modes = (ev.input_modes(False), ev.input_modes(True), ev.input_modes(2))
+        slots, ff, nc = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, inst, wit,
+                                             modes=modes, carries=carries)
+        flagged = flagged or nc
+        if ff is not None and (first_fail is None or ff < first_fail):
+            first_fail = ff
+        if k + 1 < len(moduli):
+            carries = [program_sim.from_device_form(slots[sl], p, info['words_per_const']) for sl in ev.field_segment_carried(k)]
+    ev.set_option('inspect_segment', '')
+    return first_fail, flagged
+
+
+# w0 * w1 computed over GF(101), then checked against an instance value over another field, with w0 carried along too
+def _two_fields(p_second, epilogue):
+    return [(P1, 'arithmetic', [('witness', 0), ('witness', 1), ('mul', 2, 0, 1), ('free', 1, 1)]),
+            (p_second, 'arithmetic', epilogue)]
+
+
+GROW = _two_fields(P2, [('instance', 3), ('mulc', 4, 3, sw.int_to_le(P2 - 1)), ('add', 5, 2, 4), ('assert_zero', 5),
+                        ('mul', 6, 0, 0), ('instance', 7), ('mulc', 8, 7, sw.int_to_le(P2 - 1)), ('add', 9, 6, 8), ('assert_zero', 9),
+                        ('free', 0, 0), ('free', 2, 9)])
+SHRINK = _two_fields(P3, [('instance', 3), ('mulc', 4, 3, sw.int_to_le(P3 - 1)), ('add', 5, 2, 4), ('assert_zero', 5),
+                          ('copy', 6, 0), ('assert_zero', 6), ('free', 0, 0), ('free', 2, 6)])
+
+
+def _lanes_grow():
+    # (instances, witnesses): e0 = (w0 * w1 mod 101) as an integer, e1 = w0^2 mod p2
+    rows = []
+    for w0, w1, ok in ((3, 4, True), (100, 100, True), (7, 50, False), (0, 9, True)):
+        e0 = (w0 * w1) % P1 + (0 if ok else 1)
+        rows.append(([e0, (w0 * w0) % P2], [w0, w1]))
+    return rows
+
+
+def test_the_modulus_may_grow_between_relation_messages():
+    msgs = _messages(GROW)
+    ev = _session(msgs, 2, 2)
+    assert ev.n_field_segments == 2 and ev.elem_bytes == 8
+    assert ev.field_segment_info(0) == {'carried_in': 0, 'assert_base': 0, 'words': 2, 'carried_out': 2}
+    assert ev.field_segment_info(1)['carried_in'] == 2
+    assert ev.n_asserts == 2 and ev.assert_wires().tolist() == [5, 9]
+    for inst, wit in _lanes_grow():
+        ref = oracle_lane(sw.int_to_le(P1), inst, wit, msgs, 32, trace=False)
+        ff, flagged = _simulate(ev, [P1, P2], inst, wit)
+        assert not flagged and expected_product_violations(ev, ff) == ref.violations, (inst, wit)
+        assert ref.violations in ([], ['Wire_5 (may be weighted) should be 0, while it is not'])
+    assert oracle_lane(sw.int_to_le(P1), *_lanes_grow()[2], msgs, 32, trace=False).violations == ['Wire_5 (may be weighted) should be 0, while it is not']
+
+
+def test_a_smaller_modulus_sees_the_carried_integers_unreduced():
+    """values carried into GF(97) from GF(101) may be >= 97: arithmetic reduces them, assert_zero(copy(w0)) tests the integer"""
+    msgs = _messages(SHRINK)
+    ev = _session(msgs, 1, 2)
+    assert ev.n_field_segments == 2
+    ev.set_option('inspect_segment', '1')
+    assert ev.input_modes(2) == [0x01, 0x00]      # w0: read by a zero test alone; the product: arithmetic
+    ev.set_option('inspect_segment', '')
+    for w0, w1, e0 in ((0, 5, 0), (97, 1, 0), (97, 1, 97), (100, 1, 3), (100, 1, 100), (0, 0, 0), (98, 99, (98 * 99) % 101)):
+        inst, wit = [e0], [w0, w1]
+        ref = oracle_lane(sw.int_to_le(P1), inst, wit, msgs, 32, trace=False)
+        ff, flagged = _simulate(ev, [P1, P3], inst, wit)
+        assert not flagged and expected_product_violations(ev, ff) == ref.violations, (inst, wit)
+        assert all(v.startswith('Wire_') for v in ref.violations)
+
+
+def test_three_segments_and_a_wire_alive_at_the_end():
+    parts = [(P1, 'arithmetic', [('witness', 0), ('addc', 1, 0, bytes([5]))]),
+             (P2, 'arithmetic', [('mul', 2, 1, 1), ('free', 0, 1)]),
+             (P1, 'arithmetic', [('instance', 3), ('mulc', 4, 3, sw.int_to_le(P1 - 1)), ('add', 5, 2, 4), ('assert_zero', 5), ('free', 3, 5)])]
+    msgs = _messages(parts)
+    ev = _session(msgs, 1, 1)
+    assert ev.n_field_segments == 3 and [ev.field_segment_info(k)['carried_out'] for k in range(3)] == [2, 1, 0]
+    for w, good in ((3, True), (100, True), (50, False)):
+        sq = ((w + 5) % P1) ** 2 % P2           # wire 2: an integer < p2, used over GF(101) again
+        inst, wit = [(sq + (0 if good else 1)) % P1], [w]
+        ref = oracle_lane(sw.int_to_le(P1), inst, wit, msgs, 32, trace=False)
+        ff, flagged = _simulate(ev, [P1, P2, P1], inst, wit)
+        # wire 2 is alive at the end: Evaluator::get could return the unreduced integer, so a value >= 101 there is refused
+        if sq >= P1:
+            assert flagged
+        else:
+            assert not flagged and expected_product_violations(ev, ff) == ref.violations, w
+
+
+def test_what_a_field_change_still_refuses():
+    a = sw.write_relation(bytes([2]), 'boolean', 'simple', [], [('witness', 0)])
+    b = sw.write_relation(bytes([101]), 'arithmetic', 'simple', [], [('witness', 1)])
+    ev = zk.Evaluator()
+    ev.declare_inputs(0, 2)
+    ev.ingest_message(a)
+    with pytest.raises(zk.ZkGpuError, match='between GF\\(2\\) and another field'):
+        ev.ingest_message(b)
+    # a caller-driven backend owns wires the library cannot see
+    ev = zk.Evaluator()
+    ev.backend_set_field(bytes([101]))
+    ev.backend_witness(0)
+    with pytest.raises(zk.ZkGpuError, match='caller-driven backend cannot'):
+        ev.backend_set_field(bytes([97]))
+    # the gate set alone may change from message to message (it only selects the Evaluator's own arms)
+    msgs = [sw.write_relation(bytes([101]), 'arithmetic', 'simple', [], [('witness', 0)]),
+            sw.write_relation(bytes([101]), 'arithmetic,boolean', 'simple', [], [('not', 1, 0), ('assert_zero', 1), ('free', 0, 1)])]
+    ev = _session(msgs, 0, 1)
+    assert ev.n_field_segments == 1 and ev.host_violations() == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('retain', [False, True])
+def test_field_segments_on_the_gpu(retain):
+    for parts, moduli, n_inst, rows in (
+            (GROW, [P1, P2], 2, _lanes_grow()),
+            (SHRINK, [P1, P3], 1, [([e0], [w0, w1]) for w0, w1, e0 in ((0, 5, 0), (97, 1, 0), (97, 1, 97), (100, 1, 3), (100, 1, 100),
+                                                                        (98, 99, (98 * 99) % 101))])):
+        msgs = _messages(parts)
+        ev = _session(msgs, n_inst, 2, retain)
+        w = ev.elem_bytes
+        inst, wit = batch_arrays([r[0] for r in rows], [r[1] for r in rows], w)
+        ev.set_inputs(inst, wit, len(rows))
+        ev.replay()
+        ev.synchronize()
+        n_ok = 0
+        for lane, (iv, wv) in enumerate(rows):
+            ref = oracle_lane(sw.int_to_le(P1), iv, wv, msgs, 32)
+            assert ev.get_violations(lane) == ref.violations, (moduli, lane)
+            n_ok += ref.violations == []
+            if retain:      # every value-returning backend call of every segment, in call order
+                assert ev.dump_trace_values(len(rows))[lane] == ref.trace_values(), (moduli, lane)
+        assert ev.counts() == (n_ok, len(rows) - n_ok)
+        # a second batch through the same chain of engines
+        ev.set_inputs(inst, wit, len(rows))
+        ev.replay()
+        ev.synchronize()
+        assert ev.counts() == (n_ok, len(rows) - n_ok)
+
+
+@pytest.mark.gpu
+def test_a_wide_field_after_a_narrow_one_on_the_gpu():
+    """GF(101) then BN254: the instance / witness buffers have the width of the widest field (32 bytes per value)"""
+    p2 = circuits.BN254_R
+    parts = [(P1, 'arithmetic', [('witness', 0), ('witness', 1), ('mul', 2, 0, 1), ('free', 0, 1)]),
+             (p2, 'arithmetic', [('witness', 3), ('mul', 4, 2, 3), ('instance', 5), ('mulc', 6, 5, sw.int_to_le(p2 - 1)), ('add', 7, 4, 6),
+                                 ('assert_zero', 7), ('free', 2, 7)])]
+    msgs = _messages(parts)
+    ev = _session(msgs, 1, 3)
+    assert ev.elem_bytes == 32
+    big = p2 - 12345
+    rows = []
+    for k in range(70):
+        w0, w1 = (7 * k) % P1, (11 * k + 3) % P1
+        good = k % 5 != 2
+        rows.append(([((w0 * w1) % P1 * big + (0 if good else 1)) % p2], [w0, w1, big]))
+    rows.append(([0], [0, 0, 2 ** 200]))        # a witness of the GF(101) segment that does not fit its limbs: refused
+    inst, wit = batch_arrays([r[0] for r in rows], [r[1] for r in rows], 32)
+    ev.set_inputs(inst, wit, len(rows))
+    ev.replay()
+    ev.synchronize()
+    n_ok = 0
+    for lane, (iv, wv) in enumerate(rows[:-1]):
+        ref = oracle_lane(sw.int_to_le(P1), iv, wv, msgs, 32, trace=False)
+        assert ev.get_violations(lane) == ref.violations, lane
+        n_ok += ref.violations == []
+    assert ev.counts() == (n_ok, len(rows) - n_ok)
+    assert 'not canonical' in ev.get_violations(len(rows) - 1)[0]

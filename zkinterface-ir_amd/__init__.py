@@ -108,6 +108,9 @@ def lib():
         'zkgpu_stream': (vp, [vp]),
         'zkgpu_n_engines': (ci, [vp]),
         'zkgpu_device_count': (ci, []),
+        'zkgpu_n_field_segments': (ci, [vp]),
+        'zkgpu_field_segment_info': (ci, [vp, u32, u32p]),
+        'zkgpu_field_segment_carried': (ci, [vp, u32, u32p, u32]),
         'zkgpu_rccl_reductions': (u64, [vp]),
         'zkgpu_rccl_note': (sz, [vp, ctypes.c_char_p, sz]),
         'zkgpu_lane_results': (ci, [vp, vp, vp]),
@@ -405,8 +408,26 @@ class Evaluator:
     def set_inputs_from_messages(self):
         self._ck(self.L.zkgpu_set_inputs_from_messages(self.h))
 
+    @property
+    def n_field_segments(self):
+        """parts of the relation recorded under one field characteristic each (include/zkgpu.h "Field segments")"""
+        return int(self.L.zkgpu_n_field_segments(self.h))
+
+    def field_segment_info(self, k):
+        out = (ctypes.c_uint32 * 4)()
+        self._ck(self.L.zkgpu_field_segment_info(self.h, k, out))
+        return dict(zip(['carried_in', 'assert_base', 'words', 'carried_out'], [int(x) for x in out]))
+
+    def field_segment_carried(self, k):
+        """wire-table slots of the values segment k hands to segment k + 1, in carry order"""
+        n = self.field_segment_info(k)['carried_out']
+        out = (ctypes.c_uint32 * max(n, 1))()
+        self._ck(self.L.zkgpu_field_segment_carried(self.h, k, out, n))
+        return [int(x) for x in out[:n]]
+
     def input_modes(self, witness=False):
-        """per input position how a value >= p is treated (include/zkgpu.h zkgpu_input_modes): list of 0x00 / 0x01 / 0x02 / 0xFF"""
+        """per input position how a value >= p is treated (include/zkgpu.h zkgpu_input_modes): list of 0x00 / 0x01 / 0x02 / 0xFF
+        (witness = 2: the values carried into the inspected field segment)"""
         n = self.L.zkgpu_input_modes(self.h, int(witness), None, 0)
         buf = (ctypes.c_uint8 * max(n, 1))()
         self.L.zkgpu_input_modes(self.h, int(witness), buf, n)

@@ -53,8 +53,25 @@ struct StreamState {
   int device = -2;       // the engine's device: the first listed one, or the RECORDING thread's current device (-2: not asked yet)
 };
 
-struct zkgpu_session {
+// A finished FIELD SEGMENT of the session.  The reference takes the modulus afresh from every message header
+// (evaluator.rs:232-237, :262-268): a Relation message may continue under another field characteristic, and the wires
+// alive in the scope simply live on as the integers they are.  Here every field has a backend, a schedule and an engine of
+// its own (kernels, wire-table stride and Montgomery constants are per field): when the modulus changes, the part recorded
+// so far is put aside as a segment, and the wires of the scope are re-bound to TK_CARRY sources of the new backend, whose
+// values the old engine writes out as canonical integers after its replay (Engine::carry_out).  The engines of a session
+// run one after the other on one stream and share the verdict words of the first.
+struct FieldSegment {
   TapeBackend backend;
+  Schedule sched;
+  std::unique_ptr<Engine> engine;
+  std::vector<uint32_t> carried_out;   // its handles whose values the next segment reads, in carry order
+  std::vector<uint32_t> value_op_index;
+};
+
+struct zkgpu_session {
+  TapeBackend backend;                                  // the CURRENT (last) field segment: backend, sched, engine
+  std::vector<std::unique_ptr<FieldSegment>> prev;      // the segments before it, in order
+  int inspect_segment = -1;                             // option "inspect_segment": which one the introspection calls describe
   Evaluator<TapeBackend> ev;
   std::unique_ptr<Engine> engine;
   // option "devices": the lanes of a batch are split over several engines, one per listed device (engine = the first,
@@ -139,17 +156,41 @@ int guarded(zkgpu_session* s, F&& f) {
 
 uint32_t lane_inputs(const zkgpu_session* s, bool instance) {
   const Tape& t = s->backend.tape();
-  return instance ? std::max<uint32_t>(t.n_instance, std::max<uint32_t>(s->declared_inst, (uint32_t)s->backend.lane0_instances().size()))
-                  : std::max<uint32_t>(t.n_witness, std::max<uint32_t>(s->declared_wit, (uint32_t)s->backend.lane0_witnesses().size()));
+  uint32_t n = instance ? std::max<uint32_t>(t.n_instance, std::max<uint32_t>(s->declared_inst, (uint32_t)s->backend.lane0_instances().size()))
+                        : std::max<uint32_t>(t.n_witness, std::max<uint32_t>(s->declared_wit, (uint32_t)s->backend.lane0_witnesses().size()));
+  for (const auto& seg : s->prev) n = std::max(n, instance ? seg->backend.tape().n_instance : seg->backend.tape().n_witness);
+  return n;
 }
+
+// ---- field segments ----------------------------------------------------------------------------------
+size_t n_segments(const zkgpu_session* s) { return s->prev.size() + 1; }
+const TapeBackend& seg_backend(const zkgpu_session* s, size_t k) { return k < s->prev.size() ? s->prev[k]->backend : s->backend; }
+const Schedule& seg_sched(const zkgpu_session* s, size_t k) { return k < s->prev.size() ? s->prev[k]->sched : s->sched; }
+Engine* seg_engine(const zkgpu_session* s, size_t k) { return k < s->prev.size() ? s->prev[k]->engine.get() : s->engine.get(); }
+// the segment the introspection calls (tape / schedule dumps, constants, modulus) describe: the last one unless told otherwise
+size_t inspected(const zkgpu_session* s) {
+  return (s->inspect_segment >= 0 && (size_t)s->inspect_segment < n_segments(s)) ? (size_t)s->inspect_segment : s->prev.size();
+}
+// bytes per input value in the caller's buffers: the limbs of the widest field of the session
+uint32_t session_elem_bytes(const zkgpu_session* s) {
+  if (!s->backend.field_set()) return 0;
+  uint32_t w = s->backend.field().is_two ? 1 : 4 * s->backend.field().nwords;
+  for (const auto& seg : s->prev) w = std::max<uint32_t>(w, 4 * seg->backend.field().nwords);
+  return w;
+}
+// first assert sequence number of segment k (the asserts of a session are numbered through)
+uint32_t seg_assert_base(const zkgpu_session* s, size_t k) { return seg_backend(s, k).assert_base(); }
 
 // k-th value-returning backend call -> tape index (flattened wire k of IRFlattener's numbering)
 void need_value_index(zkgpu_session* s) {
-  const Tape& t = s->backend.tape();
-  if (!s->value_op_index.empty() || !t.size()) return;
-  s->value_op_index.reserve(t.n_value_ops);
-  for (size_t i = 0; i < t.size(); ++i)
-    if (t.kind[i] != TK_ASSERT) s->value_op_index.push_back((uint32_t)i);
+  auto build = [](const Tape& t, std::vector<uint32_t>& idx) {
+    if (!idx.empty() || !t.size()) return;
+    idx.reserve(t.n_value_ops);
+    for (size_t i = 0; i < t.size(); ++i)
+      if (t.kind[i] != TK_ASSERT && t.kind[i] != TK_CARRY) idx.push_back((uint32_t)i);   // (a carried value is no backend call)
+  };
+  build(s->backend.tape(), s->value_op_index);
+  for (auto& seg : s->prev) build(seg->backend.tape(), seg->value_op_index);
 }
 
 ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
@@ -328,12 +369,37 @@ void need_engine(zkgpu_session* s) {
     s->engine.reset();
     s->peers.clear();
     s->reducer.reset();
+    for (auto& seg : s->prev) seg->engine.reset();
+    const uint32_t n_inst = lane_inputs(s, true), n_wit = lane_inputs(s, false);
     auto setup = [&](Engine* x) {
       configure_engine(s, x);
       x->set_writeback(s->n_pinned != 0);
-      x->load_program(s->sched, s->backend.field(), lane_inputs(s, true), lane_inputs(s, false));
+      x->load_program(s->sched, s->backend.field(), n_inst, n_wit);
       if (s->r1cs_extra_vars) x->reserve_extra_slots(s->r1cs_extra_vars);
     };
+    if (!s->prev.empty()) {
+      // several field segments: one engine per field on ONE device, chained on the stream of the first; the caller's
+      // input buffers have the width of the widest field
+      if (s->devices.size() > 1) throw std::runtime_error("a session of several field segments runs on one device");
+      const uint32_t stride = session_elem_bytes(s);
+      const size_t n = n_segments(s);
+      std::vector<Engine*> chain;
+      for (size_t k = 0; k < n; ++k) {
+        std::unique_ptr<Engine> x = (k == n - 1) ? std::move(e) : std::unique_ptr<Engine>(new Engine(dev0));
+        configure_engine(s, x.get());
+        x->set_writeback(k == n - 1 && s->n_pinned != 0);
+        x->set_input_stride(stride);
+        const Tape& t = seg_backend(s, k).tape();
+        x->load_program(seg_sched(s, k), seg_backend(s, k).field(), n_inst, n_wit, t.n_carry, k ? seg_backend(s, k - 1).field().nwords : 0);
+        chain.push_back(x.get());
+        if (k < n - 1) s->prev[k]->engine = std::move(x);
+        else s->engine = std::move(x);
+      }
+      for (size_t k = 0; k < n; ++k) chain[k]->chain_to(chain[0], k == 0, k == n - 1);
+      s->lane_first.assign(2, 0);
+      s->engine_loaded = true;
+      return;
+    }
     setup(e.get());
     s->engine = std::move(e);
     for (size_t k = 1; k < s->devices.size(); ++k) {
@@ -343,6 +409,19 @@ void need_engine(zkgpu_session* s) {
     s->lane_first.assign(s->peers.size() + 2, 0);
     s->engine_loaded = true;
   }
+}
+
+// (several field segments) engine k of the chain
+std::vector<Engine*> chain_engines(zkgpu_session* s) {
+  std::vector<Engine*> v;
+  for (auto& seg : s->prev) v.push_back(seg->engine.get());
+  v.push_back(s->engine.get());
+  return v;
+}
+
+void single_segment_only(const zkgpu_session* s, const char* what) {
+  if (!s->prev.empty())
+    throw std::runtime_error(std::string(what) + " is not available for a relation whose field characteristic changes between messages");
 }
 
 void single_device_only(const zkgpu_session* s, const char* what) {
@@ -399,6 +478,60 @@ void total_counts(zkgpu_session* s, uint64_t out[2]) {
   }
 }
 
+void stream_cut(void* arg);
+
+// The Relation message about to be ingested names another field characteristic than the backend works in: close the
+// current field segment and open the next (FieldSegment above).  Runs between two messages, so the top-level scope is
+// the only one that exists.
+void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
+  FieldHost next;
+  next.init(header.field_characteristic);
+  if (header.field_degree != 1) return;   // (set_field reports it, with the reference's text)
+  if (s->backend.field().is_two || next.is_two)
+    throw std::runtime_error("GPU backend: a change of the field characteristic between GF(2) and another field is not supported "
+                             "(bit-packed and Montgomery wires do not mix); the reference would carry the wires over as integers "
+                             "(evaluator.rs:232-237)");
+  if (s->devices.size() > 1) throw std::runtime_error("GPU backend: a field change between Relation messages is not available with several devices (option \"devices\")");
+  if (s->r1cs_ready) throw std::runtime_error("GPU backend: a field change between Relation messages is not available for R1CS sessions");
+  if (s->stream) {   // a streamed schedule of the old segment: dropped, the segment is scheduled at finalize like the others
+    stream_wait(s);
+    {
+      std::lock_guard<std::mutex> g(s->stream->mu);
+      s->stream->quit = true;
+    }
+    s->stream->cv.notify_all();
+    s->stream->worker.join();
+    s->stream.reset();
+    s->engine.reset();
+  }
+  s->backend.set_window(0, nullptr, nullptr);
+  // the wires of the scope live on: detach them from the old backend (no drop record: the old segment keeps them readable) ...
+  std::unique_ptr<FieldSegment> seg(new FieldSegment());
+  std::vector<WireId> ids;
+  s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
+    ids.push_back(id);
+    seg->carried_out.push_back(w.h);
+    w.h = kNoWire;
+    w.owner = nullptr;
+  });
+  const uint32_t assert_base = s->backend.assert_base() + (uint32_t)s->backend.tape().assert_op.size();
+  TapeBackend fresh;
+  fresh.adopt_streams(s->backend);
+  seg->backend = std::move(s->backend);
+  s->backend = std::move(fresh);
+  s->backend.set_assert_base(assert_base);
+  s->backend.set_field(header.field_characteristic, header.field_degree, is_boolean);
+  // ... and re-bind them, in the same order, to the carry stream of the new one
+  size_t k = 0;
+  s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
+    if (k >= ids.size() || ids[k] != id) throw std::runtime_error("GPU backend: the scope changed while a field segment was opened");
+    w = TapeWire(s->backend.h_carry((uint32_t)k), &s->backend);
+    ++k;
+  });
+  s->value_op_index.clear();
+  s->prev.push_back(std::move(seg));
+}
+
 void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
   const bool side_consumers = s->validator || s->stats;
   for (const auto& m : split_messages(data, len)) {
@@ -424,6 +557,18 @@ void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
       s->ev.set_modulus(msg.witness.header.field_characteristic);
       for (const Value& v : msg.witness.short_witness) s->ev.push_witness(s->backend.import_witness(v));
     } else {
+      if (msg.kind == Message::IsRelation && s->backend.field_set() && !s->ev.has_error()) {
+        // a new modulus opens a new field segment (evaluator.rs:232-237, :262-268); what FieldHost cannot take
+        // (an even modulus, more than 512 bits, zero) is left to set_field, which reports it with the reference's text
+        bool differs = false;
+        try {
+          FieldHost f;
+          f.init(msg.relation.header.field_characteristic);
+          differs = memcmp(f.p, s->backend.field().p, sizeof f.p) != 0;
+        } catch (const std::exception&) {
+        }
+        if (differs) switch_field(s, msg.relation.header, mask::contains_feature(msg.relation.gate_mask, mask::BOOL));
+      }
       s->ev.ingest_message(msg, s->backend);
     }
   }
@@ -718,12 +863,31 @@ size_t zkgpu_host_violations(zkgpu_session* s, char* buf, size_t cap) {
   return copy_out(join_lines(s->ev.get_violations()), buf, cap);
 }
 
-uint64_t zkgpu_tape_len(const zkgpu_session* s) { return s ? s->backend.tape().size() : 0; }
-uint64_t zkgpu_tape_value_ops(const zkgpu_session* s) { return s ? s->backend.tape().n_value_ops : 0; }
-uint64_t zkgpu_tape_asserts(const zkgpu_session* s) { return s ? s->backend.tape().assert_op.size() : 0; }
+// Tape introspection.  A session whose relation changed its field characteristic holds one tape per field segment: the
+// counts are totals over the segments, the assert wires run through them in order, and the per-entry dumps (and the
+// constant pool, the schedule, the modulus) describe ONE segment: the last, or the one option "inspect_segment" names.
+uint64_t zkgpu_tape_len(const zkgpu_session* s) {
+  if (!s) return 0;
+  if (s->inspect_segment >= 0) return seg_backend(s, inspected(s)).tape().size();
+  uint64_t n = 0;
+  for (size_t k = 0; k < n_segments(s); ++k) n += seg_backend(s, k).tape().size() - seg_backend(s, k).tape().n_carry;
+  return n;
+}
+uint64_t zkgpu_tape_value_ops(const zkgpu_session* s) {
+  if (!s) return 0;
+  uint64_t n = 0;
+  for (size_t k = 0; k < n_segments(s); ++k) n += seg_backend(s, k).tape().n_value_ops;
+  return n;
+}
+uint64_t zkgpu_tape_asserts(const zkgpu_session* s) {
+  if (!s) return 0;
+  uint64_t n = 0;
+  for (size_t k = 0; k < n_segments(s); ++k) n += seg_backend(s, k).tape().assert_op.size();
+  return n;
+}
 int zkgpu_tape_dump(const zkgpu_session* s, uint8_t* kinds, uint32_t* a, uint32_t* b, uint64_t cap) {
   if (!s) return -1;
-  const Tape& t = s->backend.tape();
+  const Tape& t = seg_backend(s, inspected(s)).tape();
   if (cap < t.size()) return 1;
   if (t.size()) {
     memcpy(kinds, t.kind.data(), t.size());
@@ -734,17 +898,36 @@ int zkgpu_tape_dump(const zkgpu_session* s, uint8_t* kinds, uint32_t* a, uint32_
 }
 int zkgpu_tape_assert_wires(const zkgpu_session* s, uint64_t* local_wire_ids, uint64_t cap) {
   if (!s) return -1;
-  const Tape& t = s->backend.tape();
-  if (cap < t.assert_wire.size()) return 1;
-  if (!t.assert_wire.empty()) memcpy(local_wire_ids, t.assert_wire.data(), t.assert_wire.size() * 8);
+  if (cap < zkgpu_tape_asserts(s)) return 1;
+  for (size_t k = 0; k < n_segments(s); ++k) {
+    const Tape& t = seg_backend(s, k).tape();
+    if (!t.assert_wire.empty()) memcpy(local_wire_ids, t.assert_wire.data(), t.assert_wire.size() * 8);
+    local_wire_ids += t.assert_wire.size();
+  }
   return 0;
 }
-uint32_t zkgpu_n_constants(const zkgpu_session* s) { return s ? (uint32_t)s->backend.tape().consts.size() : 0; }
+uint32_t zkgpu_n_constants(const zkgpu_session* s) { return s ? (uint32_t)seg_backend(s, inspected(s)).tape().consts.size() : 0; }
 size_t zkgpu_constant_bytes(const zkgpu_session* s, uint32_t index, uint8_t* out, size_t cap) {
-  if (!s || index >= s->backend.tape().consts.size()) return 0;
-  const Value& v = s->backend.tape().consts[index];
+  if (!s || index >= seg_backend(s, inspected(s)).tape().consts.size()) return 0;
+  const Value& v = seg_backend(s, inspected(s)).tape().consts[index];
   if (out && cap >= v.size() && !v.empty()) memcpy(out, v.data(), v.size());
   return v.size();
+}
+int zkgpu_n_field_segments(const zkgpu_session* s) { return s ? (int)n_segments(s) : 0; }
+// {carried in, first assert sequence number, 32-bit words per value, carried out} of segment k
+int zkgpu_field_segment_info(const zkgpu_session* s, uint32_t k, uint32_t out[4]) {
+  if (!s || k >= n_segments(s)) return 1;
+  out[0] = seg_backend(s, k).tape().n_carry;
+  out[1] = seg_assert_base(s, k);
+  out[2] = seg_backend(s, k).field().is_two ? 0 : seg_backend(s, k).field().nwords;
+  out[3] = k < s->prev.size() ? (uint32_t)s->prev[k]->carried_out.size() : 0;
+  return 0;
+}
+// wire-table slots of the values segment k hands to segment k + 1, in carry order (after zkgpu_finalize)
+int zkgpu_field_segment_carried(const zkgpu_session* s, uint32_t k, uint32_t* slots, uint32_t cap) {
+  if (!s || !s->finalized || k >= s->prev.size() || cap < s->prev[k]->carried_out.size()) return 1;
+  for (size_t q = 0; q < s->prev[k]->carried_out.size(); ++q) slots[q] = s->prev[k]->sched.slot_of[s->prev[k]->carried_out[q]];
+  return 0;
 }
 
 // ---- batch replay -------------------------------------------------------------
@@ -783,14 +966,24 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
       }
       s->engine.reset();
       // "stream" set: the same windows a streamed ingest would have scheduled (the cuts are a property of the tape)
-      s->sched = s->stream_window && !opt.retain_all ? build_schedule_windowed(t, s->backend.field(), opt)
-                                                     : build_schedule(t, s->backend.field(), opt);
+      s->sched = s->stream_window && !opt.retain_all && s->prev.empty() ? build_schedule_windowed(t, s->backend.field(), opt)
+                                                                        : build_schedule(t, s->backend.field(), opt);
+    }
+    // the field segments before the current one: everything their tapes hold is known; the wires the next segment
+    // carries on are the ones that must stay readable
+    for (auto& seg : s->prev) {
+      ScheduleOptions o = schedule_options(s, retain_all != 0);
+      o.pinned = seg->carried_out;
+      seg->sched = build_schedule(seg->backend.tape(), seg->backend.field(), o);
+      seg->engine.reset();
     }
     s->backend.set_window(0, nullptr, nullptr);
     s->retain_all = opt.retain_all;
     s->value_op_index.clear();  // built on first use (need_value_index): only trace dumps and the R1CS entry points read it
     s->engine_loaded = false;
-    Engine::validate_program(s->sched, lane_inputs(s, true), lane_inputs(s, false));  // host check of every index the kernels use
+    // host check of every index the kernels use
+    for (size_t k = 0; k < n_segments(s); ++k)
+      Engine::validate_program(seg_sched(s, k), lane_inputs(s, true), lane_inputs(s, false), seg_backend(s, k).tape().n_carry);
     s->finalized = true;
     s->results_fresh = false;
   });
@@ -798,9 +991,21 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
 
 size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size_t cap) {
   if (!s || !s->finalized) return 0;
-  const std::vector<uint8_t>& m = witness ? s->sched.strict_witness : s->sched.strict_instance;
+  if (witness == 2) {   // the values carried into the inspected field segment
+    const Schedule& sc = seg_sched(s, inspected(s));
+    const size_t nc = seg_backend(s, inspected(s)).tape().n_carry;
+    for (size_t k = 0; k < nc && k < cap && out; ++k) out[k] = k < sc.strict_carry.size() ? sc.strict_carry[k] : 0;
+    return nc;
+  }
   const size_t n = witness ? lane_inputs(s, false) : lane_inputs(s, true);
-  for (size_t k = 0; k < n && k < cap && out; ++k) out[k] = k < m.size() ? m[k] : 0;
+  for (size_t k = 0; k < n && k < cap && out; ++k) {
+    uint8_t m = 0;   // (a position is consumed by one field segment; the others say 0)
+    for (size_t g = 0; g < n_segments(s); ++g) {
+      const std::vector<uint8_t>& v = witness ? seg_sched(s, g).strict_witness : seg_sched(s, g).strict_instance;
+      if (k < v.size()) m = std::max(m, v[k]);
+    }
+    out[k] = m;
+  }
   return n;
 }
 
@@ -812,24 +1017,25 @@ int zkgpu_stream_info(const zkgpu_session* s, double out[3]) {
   return 0;
 }
 
-uint32_t zkgpu_elem_bytes(const zkgpu_session* s) {
+uint32_t zkgpu_elem_bytes(const zkgpu_session* s) {   // (several field segments: the limbs of the widest field)
   if (!s || !s->backend.field_set()) return 0;
-  return s->backend.field().is_two ? 1 : 4 * s->backend.field().nwords;
+  return session_elem_bytes(s);
 }
 uint32_t zkgpu_n_instance(const zkgpu_session* s) { return s ? lane_inputs(s, true) : 0; }
 uint32_t zkgpu_n_witness(const zkgpu_session* s) { return s ? lane_inputs(s, false) : 0; }
 
 int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]) {
   if (!s || !s->finalized) return 1;
+  const Schedule& sc = seg_sched(s, inspected(s));
   memset(out, 0, 8 * sizeof(uint64_t));
-  out[0] = s->sched.n_levels;
-  out[1] = s->sched.launches.size();
-  out[2] = s->sched.n_slots;
-  out[3] = s->sched.max_level_width;
-  for (const Launch& l : s->sched.launches) out[4] += l.sequential ? 1 : 0;
-  out[5] = s->sched.fused ? s->sched.ops2.size() : s->sched.ops.size();
-  out[6] = s->sched.const_words.size();
-  out[7] = s->sched.words_per_const;
+  out[0] = sc.n_levels;
+  out[1] = sc.launches.size();
+  out[2] = sc.n_slots;
+  out[3] = sc.max_level_width;
+  for (const Launch& l : sc.launches) out[4] += l.sequential ? 1 : 0;
+  out[5] = sc.fused ? sc.ops2.size() : sc.ops.size();
+  out[6] = sc.const_words.size();
+  out[7] = sc.words_per_const;
   return 0;
 }
 
@@ -854,7 +1060,7 @@ int zkgpu_lds_program(zkgpu_session* s, uint32_t block_rows, uint64_t sizes[6], 
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
                         uint32_t* slot_of) {
   if (!s || !s->finalized) return 1;
-  const Schedule& sc = s->sched;
+  const Schedule& sc = seg_sched(s, inspected(s));
   // ops8: {dst, kind(+operand-expression bits), a0, a1, b0, b1, 0, 0} per op, fused or not
   if (ops4) {
     uint32_t* o = ops4;
@@ -883,6 +1089,19 @@ int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launch
 int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* witnesses, uint32_t batch) {
   return guarded(s, [&] {
     need_engine(s);
+    if (!s->prev.empty()) {
+      // field segments: the first engine of the chain takes the buffers, the others read the same device copies
+      std::vector<Engine*> chain = chain_engines(s);
+      for (Engine* e : chain) e->synchronize();   // (no hand-over overlap here: every segment reads the inputs)
+      s->lane_first.assign(2, 0);
+      s->lane_first[1] = batch;
+      s->batch = batch;
+      for (Engine* e : chain) e->set_batch(batch);
+      chain[0]->upload_inputs(instances, witnesses);
+      for (size_t k = 1; k < chain.size(); ++k) chain[k]->use_device_inputs(chain[0]->device_instances(), chain[0]->device_witnesses());
+      s->results_fresh = false;
+      return;
+    }
     split_lanes(s, batch);
     const uint32_t w = s->engine->elem_bytes();
     const size_t irow = (size_t)lane_inputs(s, true) * w, wrow = (size_t)lane_inputs(s, false) * w;
@@ -901,6 +1120,10 @@ int zkgpu_set_inputs_device(zkgpu_session* s, const void* d_instances, const voi
     need_engine(s);
     single_device_only(s, "zkgpu_set_inputs_device");
     split_lanes(s, batch);
+    for (auto& seg : s->prev) {
+      seg->engine->set_batch(batch);
+      seg->engine->use_device_inputs(d_instances, d_witnesses);
+    }
     s->engine->set_batch(batch);
     s->engine->use_device_inputs(d_instances, d_witnesses);
     s->results_fresh = false;
@@ -910,12 +1133,12 @@ int zkgpu_set_inputs_device(zkgpu_session* s, const void* d_instances, const voi
 int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
-    const uint32_t w = s->engine->elem_bytes();
+    const uint32_t w = session_elem_bytes(s);
     const uint32_t ni = zkgpu_n_instance(s), nw = zkgpu_n_witness(s);
     std::vector<uint8_t> inst((size_t)ni * w, 0), wit((size_t)nw * w, 0);
     const auto& li = s->backend.lane0_instances();
     const auto& lw = s->backend.lane0_witnesses();
-    if (s->backend.tape().n_instance > li.size() || s->backend.tape().n_witness > lw.size())
+    if (ni > li.size() || nw > lw.size())
       throw std::runtime_error("the tape consumes more instance/witness values than the ingested messages hold");
     const FieldHost& f = s->backend.field();
     // a value too wide for the buffer is >= p.  Where only the residue matters (mode 0) the residue goes in; at a strict
@@ -935,8 +1158,23 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
                                    "zkgpu_set_inputs in full-width values instead");
       }
     };
-    fill(li, inst, s->sched.strict_instance);
-    fill(lw, wit, s->sched.strict_witness);
+    std::vector<uint8_t> mi(ni, 0), mw(nw, 0);
+    if (ni) zkgpu_input_modes(s, 0, mi.data(), mi.size());
+    if (nw) zkgpu_input_modes(s, 1, mw.data(), mw.size());
+    fill(li, inst, mi);
+    fill(lw, wit, mw);
+    if (!s->prev.empty()) {
+      std::vector<Engine*> chain = chain_engines(s);
+      for (Engine* e : chain) e->synchronize();
+      s->lane_first.assign(2, 0);
+      s->lane_first[1] = 1;
+      s->batch = 1;
+      for (Engine* e : chain) e->set_batch(1);
+      chain[0]->upload_inputs(inst.data(), wit.data());
+      for (size_t k = 1; k < chain.size(); ++k) chain[k]->use_device_inputs(chain[0]->device_instances(), chain[0]->device_witnesses());
+      s->results_fresh = false;
+      return;
+    }
     split_lanes(s, 1);
     s->engine->set_batch(1);
     s->engine->upload_inputs(inst.data(), wit.data());
@@ -988,6 +1226,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       }
       if (devs.size() > 64) throw std::runtime_error("devices: at most 64 engines");
       s->devices = devs;
+    } else if (k == "inspect_segment") {
+      s->inspect_segment = v.empty() ? -1 : atoi(v.c_str());
     } else if (k == "force_rccl") {
       s->force_rccl = v != "0";
     } else if (k == "stream") {
@@ -1041,7 +1281,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
 
 size_t zkgpu_modulus(const zkgpu_session* s, uint8_t* buf, size_t cap) {
   if (!s || !s->backend.field_set()) return 0;
-  const Value& m = s->backend.modulus();
+  const Value& m = seg_backend(s, inspected(s)).modulus();
   if (buf && cap) memcpy(buf, m.data(), std::min(cap, m.size()));
   return m.size();
 }
@@ -1089,7 +1329,19 @@ int zkgpu_replay(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
     s->results_fresh = false;
-    if (s->peers.empty()) {
+    if (!s->prev.empty()) {
+      // field segment after field segment on one stream; between two, the wires that live on travel as canonical integers
+      std::vector<Engine*> chain = chain_engines(s);
+      for (size_t k = 0; k < chain.size(); ++k) {
+        chain[k]->replay(false);
+        if (k + 1 < chain.size()) {
+          const FieldSegment& seg = *s->prev[k];
+          std::vector<uint32_t> slots(seg.carried_out.size());
+          for (size_t q = 0; q < slots.size(); ++q) slots[q] = seg.sched.slot_of[seg.carried_out[q]];
+          chain[k]->carry_out(slots, chain[k + 1]);
+        }
+      }
+    } else if (s->peers.empty()) {
       s->engine->replay(false);
     } else {
       std::vector<Engine*> eng = all_engines(s);
@@ -1101,6 +1353,7 @@ int zkgpu_replay_timed(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
     single_device_only(s, "zkgpu_replay_timed");
+    single_segment_only(s, "zkgpu_replay_timed");
     s->results_fresh = false;
     s->engine->replay(true);
     s->engine->synchronize();
@@ -1110,6 +1363,7 @@ int zkgpu_synchronize(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
     std::vector<Engine*> eng = all_engines(s);
+    for (auto& seg : s->prev) seg->engine->synchronize();
     if (s->peers.empty()) s->engine->synchronize();
     else
       for (size_t k : active_engines(s)) eng[k]->synchronize();
@@ -1119,6 +1373,8 @@ float zkgpu_last_replay_ms(const zkgpu_session* s) {   // several devices: the s
   if (!s || !s->engine) return 0.f;
   float ms = s->engine->last_replay_ms();
   for (const auto& p : s->peers) ms = std::max(ms, p->last_replay_ms());
+  for (const auto& seg : s->prev)
+    if (seg->engine) ms += seg->engine->last_replay_ms();   // field segments run one after the other
   return ms;
 }
 
@@ -1171,7 +1427,9 @@ size_t zkgpu_lane_violations(zkgpu_session* s, uint32_t lane, char* buf, size_t 
                   "without passing through an arithmetic gate; the reference evaluates those on the unreduced integer "
                   "(evaluator.rs:896-946) and this path does not");
     } else if (ff != ZKGPU_NO_FAIL) {
-      v.push_back("Wire_" + std::to_string(s->backend.tape().assert_wire[ff]) +
+      size_t g = n_segments(s) - 1;   // the field segment whose asserts include sequence number ff
+      while (g > 0 && ff < seg_assert_base(s, g)) --g;
+      v.push_back("Wire_" + std::to_string(seg_backend(s, g).tape().assert_wire.at(ff - seg_assert_base(s, g))) +
                   " (may be weighted) should be 0, while it is not");
     } else if (s->ev.has_error()) {
       v.push_back(s->ev.error());
@@ -1188,12 +1446,36 @@ int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, ui
     need_engine(s);
     if (!s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) is required for trace dumps");
     need_value_index(s);
-    if (first + count > s->value_op_index.size()) throw std::runtime_error("trace range out of bounds");
-    std::vector<uint32_t> slots(count);
-    for (uint64_t k = 0; k < count; ++k) slots[k] = s->sched.slot_of[s->value_op_index[first + k]];
-    std::vector<uint8_t> tmp;
-    dump_slots_all(s, slots, &tmp);
-    if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+    if (s->prev.empty()) {
+      if (first + count > s->value_op_index.size()) throw std::runtime_error("trace range out of bounds");
+      std::vector<uint32_t> slots(count);
+      for (uint64_t k = 0; k < count; ++k) slots[k] = s->sched.slot_of[s->value_op_index[first + k]];
+      std::vector<uint8_t> tmp;
+      dump_slots_all(s, slots, &tmp);
+      if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+      return;
+    }
+    // field segments: the calls run through the segments in order; every value is written in the session's element
+    // width (the limbs of the widest field), zero-extended
+    if (first + count > zkgpu_tape_value_ops(s)) throw std::runtime_error("trace range out of bounds");
+    const uint32_t w = session_elem_bytes(s), batch = s->batch;
+    memset(out, 0, (size_t)batch * count * w);
+    uint64_t base = 0;
+    for (size_t g = 0; g < n_segments(s); ++g) {
+      const std::vector<uint32_t>& idx = g < s->prev.size() ? s->prev[g]->value_op_index : s->value_op_index;
+      const uint64_t lo = std::max<uint64_t>(first, base), hi = std::min<uint64_t>(first + count, base + idx.size());
+      if (lo < hi) {
+        std::vector<uint32_t> slots(hi - lo);
+        for (uint64_t k = lo; k < hi; ++k) slots[k - lo] = seg_sched(s, g).slot_of[idx[k - base]];
+        std::vector<uint8_t> tmp;
+        seg_engine(s, g)->dump_slots(slots, &tmp);
+        const uint32_t ws = seg_engine(s, g)->elem_bytes();
+        for (uint32_t lane = 0; lane < batch; ++lane)
+          for (uint64_t k = lo; k < hi; ++k)
+            memcpy(out + ((size_t)lane * count + (k - first)) * w, tmp.data() + ((size_t)lane * (hi - lo) + (k - lo)) * ws, ws);
+      }
+      base += idx.size();
+    }
   });
 }
 
@@ -1206,12 +1488,19 @@ int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out) {
     std::vector<uint32_t> slots(1, s->sched.slot_of[w->h]);
     std::vector<uint8_t> tmp;
     dump_slots_all(s, slots, &tmp);
-    if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+    const uint32_t we = session_elem_bytes(s), ws = s->engine->elem_bytes();
+    if (we == ws) {
+      if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
+    } else {   // field segments: the caller's element width is that of the widest field
+      memset(out, 0, (size_t)s->batch * we);
+      for (uint32_t lane = 0; lane < s->batch; ++lane) memcpy(out + (size_t)lane * we, tmp.data() + (size_t)lane * ws, ws);
+    }
   });
 }
 
 int zkgpu_r1cs_from_tape(zkgpu_session* s, int use_correction) {
   return guarded(s, [&] {
+    single_segment_only(s, "the R1CS conversion");
     if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
     if (s->backend.field().is_two) throw std::runtime_error("R1CS conversion on the GPU path needs an odd field characteristic");
     const Tape& t = s->backend.tape();
@@ -1265,6 +1554,7 @@ int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_p
                         const uint32_t* term_coef, const uint8_t* coef_bytes, uint32_t coef_width, uint32_t n_coefs,
                         uint32_t n_extra_vars) {
   return guarded(s, [&] {
+    single_segment_only(s, "zkgpu_r1cs_load_csr");
     if (!s->finalized || !s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) first: variables are tape values");
     if (s->engine_loaded) throw std::runtime_error("load the CSR before the first zkgpu_set_inputs* call (the table is sized once)");
     if (!row_ptr || (n_coefs && (!coef_bytes || coef_width == 0)))

@@ -47,6 +47,7 @@ enum OpKind : u32 {
   OP_XOR = 11,
   OP_NOT = 12,
   OP_NZ = 13,  // 1 if the operand is non-zero else 0: x^(p-1) over a prime field (scheduler-made, schedule.cpp)
+  OP_CARRY = 14,  // dst = to_mont(carry[lane][a]): a wire of the previous field segment, as the integer it held
 };
 
 struct TapeOp {
@@ -82,6 +83,10 @@ struct ReplayArgs {
   u32 xcd_chunks;         // != 0: XCD-aware 1-D grid, see block_coords()
   const uint8_t* strict_inst;   // per input position: 0xFF = a value >= p flags the lane (Schedule::strict_instance)
   const uint8_t* strict_wit;
+  u32 in_stride_words;          // 32-bit words per input value in inst / wit (N, or more in a session of several fields)
+  const u32* carry;             // [lane][n_carry][carry_words]: canonical values of the wires carried over from the previous
+  u32 n_carry, carry_words;     // field segment (carry_words = that field's N)
+  const uint8_t* strict_carry;
 };
 
 struct ReplayArgs2 {
@@ -103,6 +108,10 @@ struct ReplayArgs2 {
   u32 op_stride;          // 1 or 4, see the kernel
   const uint8_t* strict_inst;   // as in ReplayArgs
   const uint8_t* strict_wit;
+  u32 in_stride_words;
+  const u32* carry;
+  u32 n_carry, carry_words;
+  const uint8_t* strict_carry;
 };
 
 // instantiations of replay_fused_kernel (replay_kernels.hpp)

@@ -86,39 +86,70 @@ __device__ __forceinline__ void wire_store(uint4* __restrict__ rec, const Fp<N>&
   }
 }
 
+// One input value of a lane: the low N words of its `stride_words`-word slot (the slot is narrower than N only for a
+// value carried over from a narrower field; it is wider in a session of several fields, whose input buffers have the
+// width of the widest one).  too_wide: the value has bits above the N words -- it is >= R > p and its residue cannot be
+// taken by to_mont: the caller flags the lane.
 template <int N>
-__device__ __forceinline__ Fp<N> input_load(const uint8_t* __restrict__ base, u32 lane_g, u32 n_vals,
-                                            u32 idx, bool valid) {
+__device__ __forceinline__ Fp<N> input_load(const void* __restrict__ base, u32 lane_g, u32 n_vals, u32 idx, bool valid,
+                                            u32 stride_words, bool& too_wide) {
   Fp<N> r;
+  too_wide = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = 0;
   if (valid) {
-    const u32* p = reinterpret_cast<const u32*>(base + ((size_t)lane_g * n_vals + idx) * (4 * N));
+    const u32* p = reinterpret_cast<const u32*>(base) + ((size_t)lane_g * n_vals + idx) * stride_words;
 #pragma unroll
-    for (int i = 0; i < N; ++i) r.w[i] = p[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.w[i] = 0;
+    for (int i = 0; i < N; ++i)
+      if ((u32)i < stride_words) r.w[i] = p[i];
+    u32 hi = 0;
+    for (u32 i = N; i < stride_words; ++i) hi |= p[i];
+    too_wide = hi != 0;
   }
   return r;
 }
 
-// The operand of an assert_zero / not that a constant, instance or witness value reaches through copies alone is, for the
-// reference, the UNREDUCED integer (evaluator.rs:862-864,896-906,932-946): a value >= p is not zero whatever its residue.
-// `code` (schedule.cpp track_unreduced_values): 0 = no such source, 1 = a constant >= p, 2 + 2 * position + is_witness =
-// an input, whose raw value is tested here beside the wire.
+// the raw value of input stream 0 (instance), 1 (witness) or 2 (carry) at `position`
 template <int N, class Args>
-__device__ __forceinline__ bool unreduced_source_is_nonzero(u32 code, const Args& args, u32 lane_g, bool lane_valid,
-                                                            const FieldParams& fp) {
-  if (code < 2) return code == 1;
-  const u32 q = code - 2;
-  const bool is_wit = (q & 1) != 0;
-  const Fp<N> raw = input_load<N>(is_wit ? args.wit : args.inst, lane_g, is_wit ? args.n_wit : args.n_inst, q >> 1, lane_valid);
-  return lane_valid && fp_geq_p<N>(raw, fp);
+__device__ __forceinline__ Fp<N> stream_load(u32 stream, u32 position, const Args& args, u32 lane_g, bool lane_valid, bool& too_wide) {
+  if (stream == 2) return input_load<N>(args.carry, lane_g, args.n_carry, position, lane_valid, args.carry_words, too_wide);
+  return input_load<N>(stream ? args.wit : args.inst, lane_g, stream ? args.n_wit : args.n_inst, position, lane_valid,
+                       args.in_stride_words, too_wide);
 }
 
 // Input positions whose value must be canonical (mode 0xFF in Schedule::strict_instance / strict_witness: it reaches an
 // integer bit operation or Evaluator::get unreduced): a value >= p there flags the lane.
 __device__ __forceinline__ bool position_is_strict(const uint8_t* __restrict__ modes, u32 position) {
   return modes[position] == 0xFF;
+}
+
+// The operand of an assert_zero / not that a constant, instance or witness value reaches through copies alone is, for the
+// reference, the UNREDUCED integer (evaluator.rs:862-864,896-906,932-946): a value >= p is not zero whatever its residue.
+// `code` (schedule.cpp track_unreduced_values): 0 = no such source, 1 = a constant >= p, 2 + 4 * position + stream (0
+// instance, 1 witness, 2 carried from the previous field segment) = an input, whose raw value is tested here beside the wire.
+template <int N, class Args>
+__device__ __forceinline__ bool unreduced_source_is_nonzero(u32 code, const Args& args, u32 lane_g, bool lane_valid,
+                                                            const FieldParams& fp) {
+  if (code < 2) return code == 1;
+  const u32 q = code - 2;
+  bool too_wide;
+  const Fp<N> raw = stream_load<N>(q & 3, q >> 2, args, lane_g, lane_valid, too_wide);
+  return lane_valid && (too_wide || fp_geq_p<N>(raw, fp));
+}
+
+// An input op of either replay kernel: load, flag the lane where the value cannot be represented (wider than the limbs)
+// or is >= p at a strict position, and return the Montgomery form of its residue.
+template <int N, class Args>
+__device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& args, u32 lane_g, bool lane_valid, const FieldParams& fp) {
+  const u32 stream = kind == OP_INSTANCE ? 0u : kind == OP_WITNESS ? 1u : 2u;
+  bool too_wide;
+  const Fp<N> raw = stream_load<N>(stream, position, args, lane_g, lane_valid, too_wide);
+  const uint8_t* modes = stream == 0 ? args.strict_inst : stream == 1 ? args.strict_wit : args.strict_carry;
+  // The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  At a strict position the value can reach an
+  // integer bit operation or Evaluator::get as it is, where the residue would not do: flag the lane.
+  if (lane_valid && (too_wide || (position_is_strict(modes, position) && fp_geq_p<N>(raw, fp))))
+    atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+  return fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
 }
 
 // One wave = 64 witnesses x `ops_per_wave` consecutive tape ops.
@@ -143,7 +174,7 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
   uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
   constexpr int REC = Layout<N>::kRecord;
 
-  auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_NOP; };  // OP_NZ reads a
+  auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_CARRY && k != OP_NOP; };  // OP_NZ reads a
   auto needs_b = [](u32 k) { return k == OP_ADD || k == OP_MUL || k == OP_AND || k == OP_XOR; };
 
   TapeOp op = load_op_scalar(args.ops, begin);
@@ -180,18 +211,8 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
         break;
       case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a * N); break;
       case OP_INSTANCE:
-      case OP_WITNESS: {
-        const bool is_inst = op.kind == OP_INSTANCE;
-        Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit,
-                                  op.a, lane_valid);
-        if (position_is_strict(is_inst ? args.strict_inst : args.strict_wit, op.a) && lane_valid && fp_geq_p<N>(raw, fp)) {
-          // The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  This one can reach an integer bit
-          // operation or Evaluator::get as it is, where the residue would not do: flag the lane.
-          atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
-        }
-        r = fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
-        break;
-      }
+      case OP_WITNESS:
+      case OP_CARRY: r = input_op<N>(op.kind, op.a, args, lane_g, lane_valid, fp); break;
       case OP_ASSERT: {
         has_out = false;
         const bool nz = !fp_is_zero<N>(a) || unreduced_source_is_nonzero<N>(op.dst, args, lane_g, lane_valid, fp);
@@ -305,14 +326,8 @@ __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict
       break;
     case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
     case OP_INSTANCE:
-    case OP_WITNESS: {
-      const bool is_inst = kind == OP_INSTANCE;
-      Fp<N> raw = input_load<N>(is_inst ? args.inst : args.wit, lane_g, is_inst ? args.n_inst : args.n_wit, op.a0, lane_valid);
-      if (position_is_strict(is_inst ? args.strict_inst : args.strict_wit, op.a0) && lane_valid && fp_geq_p<N>(raw, fp))
-        atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);   // strict positions only
-      r = fp_to_mont<N>(raw, fp);
-      break;
-    }
+    case OP_WITNESS:
+    case OP_CARRY: r = input_op<N>(kind, op.a0, args, lane_g, lane_valid, fp); break;
     case OP_ASSERT: {
       has_out = false;
       const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC)) ||

@@ -135,6 +135,8 @@ Engine::~Engine() {
   dfree(d_launches_);
   dfree(d_strict_inst_);
   dfree(d_strict_wit_);
+  dfree(d_strict_carry_);
+  dfree(d_carry_slots_);
   dfree(d_r1cs_rows_);
   dfree(d_r1cs_terms_);
   dfree(d_r1cs_coefs_);
@@ -157,7 +159,8 @@ Engine::~Engine() {
     if (ev_join_[k]) (void)hipEventDestroy((hipEvent_t)ev_join_[k]);
     if (side_streams_[k]) (void)hipStreamDestroy((hipStream_t)side_streams_[k]);
   }
-  if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
+  if (owned_stream_) (void)hipStreamDestroy((hipStream_t)owned_stream_);
+  else if (stream_) (void)hipStreamDestroy((hipStream_t)stream_);
 }
 
 void Engine::free_batch() {
@@ -172,6 +175,7 @@ void Engine::free_batch() {
   upload_pending_ = false;
   dfree(d_packed_inst_);
   dfree(d_packed_wit_);
+  dfree(d_carry_);
   dfree(d_r1cs_fail_);
   d_inst_ = d_wit_ = nullptr;
   batch_ = 0;
@@ -180,7 +184,7 @@ void Engine::free_batch() {
 
 // Every index a kernel will dereference is checked on the host before the program is uploaded: a slot, constant
 // or input position out of range must be an exception here, never a memory fault on the GPU.
-void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness) {
+void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness, uint32_t n_carry) {
   const uint32_t wpc = s.words_per_const ? s.words_per_const : 1;
   const uint64_t n_consts = s.const_words.size() / wpc;
   auto fail = [](size_t i, const char* what) {
@@ -189,11 +193,11 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
   auto slot = [&](size_t i, uint32_t v) {
     if (v >= s.n_slots) fail(i, ("a wire-table slot (" + std::to_string(v) + " of " + std::to_string(s.n_slots) + ")").c_str());
   };
-  // the unreduced source an assert_zero / not entry names (0 none, 1 a constant, 2 + 2 * position + is_witness)
+  // the unreduced source an assert_zero / not entry names (0 none, 1 a constant, 2 + 4 * position + stream)
   auto source = [&](size_t i, uint32_t code) {
     if (code < 2) return;
-    const uint32_t q = code - 2;
-    if ((q >> 1) >= ((q & 1) ? n_witness : n_instance)) fail(i, "the input position of its unreduced source");
+    const uint32_t q = code - 2, stream = q & 3;
+    if (stream > 2 || (q >> 2) >= (stream == 0 ? n_instance : stream == 1 ? n_witness : n_carry)) fail(i, "the input position of its unreduced source");
   };
   auto check = [&](size_t i, uint32_t kind, uint32_t dst, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t ea,
                    uint32_t eb, uint32_t second, uint32_t dst2, uint32_t c0, uint32_t src) {
@@ -216,6 +220,7 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
         break;
       case TK_INSTANCE: slot(i, dst); if (a0 >= n_instance) fail(i, "an instance position"); break;
       case TK_WITNESS: slot(i, dst); if (a0 >= n_witness) fail(i, "a witness position"); break;
+      case TK_CARRY: slot(i, dst); if (a0 >= n_carry) fail(i, "a carried value"); break;
       case TK_ASSERT: slot(i, a0); source(i, src); break;
       case TK_NOP: break;
       default: fail(i, "an unknown kind");
@@ -286,7 +291,8 @@ void Engine::upload_window(const void* entries, uint64_t n_entries, size_t entry
   window_entries_.push_back(n_entries);
 }
 
-void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness) {
+void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness, uint32_t n_carry,
+                          uint32_t carry_words) {
   use_device();
   free_batch();
   dfree(d_consts_);
@@ -299,6 +305,11 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   lanes_per_block_ = boolean_ ? 4096 : 64;
   n_inst_ = n_instance;
   n_wit_ = n_witness;
+  n_carry_ = n_carry;
+  carry_words_ = carry_words;
+  if (boolean_ && n_carry) throw std::runtime_error("Engine: values carried between field segments need an arithmetic field");
+  if (!in_stride_set_) in_stride_ = elem_bytes_;
+  if (in_stride_ < elem_bytes_ || in_stride_ % 4) throw std::runtime_error("Engine: the input stride is narrower than the field's limbs");
   zkgpu::FieldParams fp;
   memset(&fp, 0, sizeof fp);
   memcpy(fp.p, f.p, sizeof fp.p);
@@ -320,7 +331,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   }
   memset(field_params_, 0, sizeof field_params_);
   memcpy(field_params_, &fp, sizeof fp);
-  validate_program(s, n_instance, n_witness);
+  validate_program(s, n_instance, n_witness, n_carry);
   {
     // program entries window by window; windows a streamed ingest has already sent stay where they are
     const size_t eb = s.fused ? sizeof(DevOp2) : sizeof(DevOp);
@@ -354,6 +365,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
     };
     upload_mask(d_strict_inst_, s.strict_instance, n_instance);
     upload_mask(d_strict_wit_, s.strict_witness, n_witness);
+    upload_mask(d_strict_carry_, s.strict_carry, n_carry);
   }
   // GF(2): if every live wire of a 32-witness slice fits in one CU's LDS, run LDS-resident
   constexpr uint32_t kLdsBytes = 160 * 1024;
@@ -416,6 +428,7 @@ void Engine::set_batch(uint32_t batch) {
   HIP_OK(hipMalloc(&d_first_fail_, padded_lanes * 4));
   HIP_OK(hipMalloc(&d_flags_, padded_lanes * 4));
   HIP_OK(hipMalloc(&d_r1cs_fail_, padded_lanes * 4));
+  if (n_carry_) HIP_OK(hipMalloc(&d_carry_, std::max<size_t>((size_t)batch * n_carry_ * carry_words_ * 4, 64)));
   if (boolean_) {
     const size_t words = (size_t)lane_blocks_ * 64;
     HIP_OK(hipMalloc(&d_packed_inst_, std::max<size_t>((size_t)n_inst_ * words * 8, 64)));
@@ -426,7 +439,7 @@ void Engine::set_batch(uint32_t batch) {
 void Engine::upload_inputs(const uint8_t* inst, const uint8_t* wit) {
   use_device();
   if (!batch_) throw std::runtime_error("Engine: set_batch() first");
-  const size_t ib = (size_t)batch_ * n_inst_ * elem_bytes_, wb = (size_t)batch_ * n_wit_ * elem_bytes_;
+  const size_t ib = (size_t)batch_ * n_inst_ * in_stride_, wb = (size_t)batch_ * n_wit_ * in_stride_;
   if (ib && !inst) throw std::runtime_error("Engine: instance values missing");
   if (wb && !wit) throw std::runtime_error("Engine: witness values missing");
   if (!copy_stream_) {
@@ -554,7 +567,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.consts = (const zkgpu::u32*)d_consts_;
     a.packed_inst = (const zkgpu::u64*)d_packed_inst_;
     a.packed_wit = (const zkgpu::u64*)d_packed_wit_;
-    a.first_fail = (zkgpu::u32*)d_first_fail_;
+    a.first_fail = (zkgpu::u32*)verdict_first_fail();
     zkgpu::launch_bool_replay(grid, st, a);
     return;
   }
@@ -573,10 +586,15 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.wit = (const uint8_t*)d_wit_;
     a.n_inst = n_inst_;
     a.n_wit = n_wit_;
-    a.first_fail = (zkgpu::u32*)d_first_fail_;
-    a.lane_flags = (zkgpu::u32*)d_flags_;
+    a.first_fail = (zkgpu::u32*)verdict_first_fail();
+    a.lane_flags = (zkgpu::u32*)verdict_flags();
     a.strict_inst = (const uint8_t*)d_strict_inst_;
     a.strict_wit = (const uint8_t*)d_strict_wit_;
+    a.in_stride_words = in_stride_ / 4;
+    a.carry = (const zkgpu::u32*)d_carry_;
+    a.n_carry = n_carry_;
+    a.carry_words = carry_words_;
+    a.strict_carry = (const uint8_t*)d_strict_carry_;
     if (L.sequential) {
       // a strand: one workgroup per lane block walks the levels of the run, barrier between levels
       a.xcd_chunks = 0;
@@ -618,10 +636,15 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   a.wit = (const uint8_t*)d_wit_;
   a.n_inst = n_inst_;
   a.n_wit = n_wit_;
-  a.first_fail = (zkgpu::u32*)d_first_fail_;
-  a.lane_flags = (zkgpu::u32*)d_flags_;
+  a.first_fail = (zkgpu::u32*)verdict_first_fail();
+  a.lane_flags = (zkgpu::u32*)verdict_flags();
   a.strict_inst = (const uint8_t*)d_strict_inst_;
   a.strict_wit = (const uint8_t*)d_strict_wit_;
+  a.in_stride_words = in_stride_ / 4;
+  a.carry = (const zkgpu::u32*)d_carry_;
+  a.n_carry = n_carry_;
+  a.carry_words = carry_words_;
+  a.strict_carry = (const uint8_t*)d_strict_carry_;
   a.xcd_chunks = xcd_chunks;
   launch_plain(nwords_, sched_.has_bitops, grid, st, a, fp);
 }
@@ -737,15 +760,17 @@ void Engine::capture_graph() {
 void Engine::enqueue_replay(bool time_each_launch) {
   hipStream_t st = (hipStream_t)stream_;
   const size_t padded_lanes = (size_t)lane_blocks_ * lanes_per_block_;
-  HIP_OK(hipMemsetAsync(d_first_fail_, 0xFF, padded_lanes * 4, st));
-  HIP_OK(hipMemsetAsync(d_flags_, 0, padded_lanes * 4, st));
-  HIP_OK(hipMemsetAsync(d_counts_, 0, 16, st));
+  if (chain_first_) {   // (a later field segment of a session adds to the verdict words of the first)
+    HIP_OK(hipMemsetAsync(verdict_first_fail(), 0xFF, padded_lanes * 4, st));
+    HIP_OK(hipMemsetAsync(verdict_flags(), 0, padded_lanes * 4, st));
+    HIP_OK(hipMemsetAsync(verdict_counts(), 0, 16, st));
+  }
   if (boolean_) {
     const uint32_t words = lane_blocks_ * 64;
     // both streams in one launch (blockIdx.z)
     zkgpu::launch_pack_inputs(st, (const uint8_t*)d_inst_, n_inst_, (const uint8_t*)d_strict_inst_, (zkgpu::u64*)d_packed_inst_,
                               (const uint8_t*)d_wit_, n_wit_, (const uint8_t*)d_strict_wit_, (zkgpu::u64*)d_packed_wit_, batch_,
-                              words, (zkgpu::u32*)d_flags_);
+                              words, (zkgpu::u32*)verdict_flags());
   }
   if (lds_path_) {
     zkgpu::BoolLdsArgs a;
@@ -763,7 +788,7 @@ void Engine::enqueue_replay(bool time_each_launch) {
     a.consts = (const zkgpu::u32*)d_consts_;
     a.packed_inst = (const zkgpu::u32*)d_packed_inst_;
     a.packed_wit = (const zkgpu::u32*)d_packed_wit_;
-    a.first_fail = (zkgpu::u32*)d_first_fail_;
+    a.first_fail = (zkgpu::u32*)verdict_first_fail();
     a.table = (zkgpu::u64*)d_table_;
     a.writeback = (lds_writeback_ || force_writeback_) ? 1 : 0;
     const size_t lds_bytes = (((size_t)sched_.n_slots + zkgpu::kLdsExtraSlots) * 4 + 15) / 16 * 16;
@@ -784,8 +809,9 @@ void Engine::enqueue_replay(bool time_each_launch) {
   if (time_each_launch) group_blocks = lane_blocks_;  // per-launch events describe whole-batch launches
   for (uint32_t lb0 = 0; lb0 < lane_blocks_ && !lds_path_; lb0 += group_blocks)
     launch_range(lb0, std::min(group_blocks, lane_blocks_ - lb0), time_each_launch);
-  zkgpu::launch_verdict(dim3((batch_ + 255) / 256), st, (const zkgpu::u32*)d_first_fail_, (const zkgpu::u32*)d_flags_, batch_,
-                        (unsigned long long*)d_counts_);
+  if (chain_last_)
+    zkgpu::launch_verdict(dim3((batch_ + 255) / 256), st, (const zkgpu::u32*)verdict_first_fail(), (const zkgpu::u32*)verdict_flags(), batch_,
+                          (unsigned long long*)verdict_counts());
 }
 
 void Engine::reserve_extra_slots(uint32_t n) {
@@ -952,7 +978,7 @@ void Engine::r1cs_corrections(const std::vector<uint32_t>& calls4, const std::ve
 void Engine::r1cs_finish_check() {
   use_device();
   hipStream_t st = (hipStream_t)stream_;
-  zkgpu::launch_verdict(dim3((batch_ + 255) / 256), st, (const zkgpu::u32*)d_r1cs_fail_, (const zkgpu::u32*)d_flags_, batch_,
+  zkgpu::launch_verdict(dim3((batch_ + 255) / 256), st, (const zkgpu::u32*)d_r1cs_fail_, (const zkgpu::u32*)verdict_flags(), batch_,
                         (unsigned long long*)d_r1cs_counts_);
   HIP_OK(hipEventRecord((hipEvent_t)ev_r1cs_end_, st));
   HIP_OK(hipGetLastError());
@@ -981,13 +1007,13 @@ void Engine::download(std::vector<uint32_t>* first_fail, std::vector<uint32_t>* 
   synchronize();   // (makes the engine's device current)
   if (first_fail) {
     first_fail->resize(batch_);
-    HIP_OK(hipMemcpy(first_fail->data(), d_first_fail_, (size_t)batch_ * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(first_fail->data(), verdict_first_fail(), (size_t)batch_ * 4, hipMemcpyDeviceToHost));
   }
   if (flags) {
     flags->resize(batch_);
-    HIP_OK(hipMemcpy(flags->data(), d_flags_, (size_t)batch_ * 4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(flags->data(), verdict_flags(), (size_t)batch_ * 4, hipMemcpyDeviceToHost));
   }
-  if (counts) HIP_OK(hipMemcpy(counts, d_counts_, 16, hipMemcpyDeviceToHost));
+  if (counts) HIP_OK(hipMemcpy(counts, verdict_counts(), 16, hipMemcpyDeviceToHost));
 }
 
 void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out) {
@@ -1016,6 +1042,55 @@ void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>
   HIP_OK(hipMemcpy(out->data(), d_out, out->size(), hipMemcpyDeviceToHost));
   (void)hipFree(d_slots);
   (void)hipFree(d_out);
+}
+
+// ---- field segments of one session (capi.cpp): engines chained on ONE stream, sharing the verdict words of the first ----
+void Engine::chain_to(Engine* head, bool first, bool last) {
+  chain_first_ = first;
+  chain_last_ = last;
+  graph_dirty_ = true;
+  if (head == this || head == nullptr) {
+    chain_head_ = nullptr;
+    return;
+  }
+  if (head->device_ != device_) throw std::runtime_error("Engine: chained engines must live on one device");
+  chain_head_ = head;
+  if (stream_ != head->stream_) {   // everything this engine enqueues is ordered behind the segment before it
+    if (!owned_stream_) owned_stream_ = stream_;
+    stream_ = head->stream_;
+  }
+}
+
+void* Engine::verdict_first_fail() const { return chain_head_ ? chain_head_->d_first_fail_ : d_first_fail_; }
+void* Engine::verdict_flags() const { return chain_head_ ? chain_head_->d_flags_ : d_flags_; }
+void* Engine::verdict_counts() const { return chain_head_ ? chain_head_->d_counts_ : d_counts_; }
+
+void Engine::set_input_stride(uint32_t bytes) {
+  if (batch_) throw std::runtime_error("Engine: set_input_stride() must precede set_batch()");
+  in_stride_ = bytes;
+  in_stride_set_ = true;
+}
+
+// The canonical values of `slots` for every lane, written by THIS engine (on the shared stream, behind its replay) into
+// the carry buffer of the engine that runs the next field segment: [lane][k][nwords of this field].
+void Engine::carry_out(const std::vector<uint32_t>& slots, Engine* next) {
+  use_device();
+  if (boolean_ || next->boolean_) throw std::runtime_error("Engine: values carried between field segments need arithmetic fields");
+  if (next->n_carry_ != slots.size() || next->carry_words_ != nwords_ || next->batch_ != batch_ || !next->d_carry_)
+    throw std::runtime_error("Engine: the next segment does not expect these carried values");
+  if (slots.empty()) return;
+  for (uint32_t sl : slots)
+    if (sl >= table_slots_) throw std::runtime_error("Engine: a carried value names a wire-table slot out of range");
+  hipStream_t st = (hipStream_t)stream_;
+  if (!d_carry_slots_) {
+    HIP_OK(hipMalloc(&d_carry_slots_, slots.size() * 4));
+    HIP_OK(hipMemcpy(d_carry_slots_, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+  }
+  zkgpu::FieldParams fp;
+  memcpy(&fp, field_params_, sizeof fp);
+  launch_dump(nwords_, dim3((uint32_t)slots.size(), (batch_ + 63) / 64), st, (const uint4*)d_table_, table_slots_,
+              (const uint32_t*)d_carry_slots_, (uint32_t)slots.size(), batch_, (zkgpu::u32*)next->d_carry_, fp);
+  HIP_OK(hipGetLastError());
 }
 
 int current_device() {

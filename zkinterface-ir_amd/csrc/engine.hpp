@@ -35,8 +35,10 @@ class Engine {
   void upload_window(const void* entries, uint64_t n_entries, size_t entry_bytes);
   size_t windows_uploaded() const { return d_windows_.size(); }
   // Upload the program.  n_instance / n_witness = values per witness stream.
-  static void validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness);
-  void load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness);
+  static void validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness, uint32_t n_carry = 0);
+  // n_carry values of carry_words 32-bit words each arrive from the previous field segment of the session (TK_CARRY)
+  void load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness, uint32_t n_carry = 0,
+                    uint32_t carry_words = 0);
   // Bytes per input value the batch buffers must use: 4*nwords (arithmetic) or 1 (GF(2)).
   uint32_t elem_bytes() const { return elem_bytes_; }
 
@@ -66,7 +68,7 @@ class Engine {
   const std::vector<LaunchTiming>& launch_timings() const { return timings_; }
 
   void download(std::vector<uint32_t>* first_fail, std::vector<uint32_t>* flags, uint64_t counts[2]);
-  void* counts_device() const { return d_counts_; }  // u64[2] {satisfied, failed}
+  void* counts_device() const { return verdict_counts(); }  // u64[2] {satisfied, failed} (of the whole chain of field segments)
   void* stream() const { return stream_; }
   // out[lane][k][elem_bytes]: canonical value of slot slots[k] for every lane
   void dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out);
@@ -90,6 +92,18 @@ class Engine {
 
   uint64_t table_bytes() const { return table_bytes_; }
   uint32_t batch() const { return batch_; }
+
+  // ---- field segments of one session: a relation whose modulus changes between messages (evaluator.rs:232-237) is a chain
+  // of engines, one per field, replayed one after the other on the stream of the first (`head`), all writing the
+  // verdict words of the first; the wires alive at a boundary travel as canonical integers (carry_out -> TK_CARRY).
+  void chain_to(Engine* head, bool first, bool last);
+  // bytes per input value in the caller's buffers when that is wider than this field's limbs (the widest field of the
+  // session); before set_batch()
+  void set_input_stride(uint32_t bytes);
+  uint32_t input_stride() const { return in_stride_; }
+  const void* device_instances() const { return d_inst_; }
+  const void* device_witnesses() const { return d_wit_; }
+  void carry_out(const std::vector<uint32_t>& slots, Engine* next);
 
  private:
   int device_ = -1;
@@ -148,8 +162,20 @@ class Engine {
   bool set_read_[2] = {false, false};
   const void* d_inst_ = nullptr;
   const void* d_wit_ = nullptr;
-  void* d_strict_inst_ = nullptr;  // GF(2): per input position, 0xFF where a value > 1 must flag the lane
+  void* d_strict_inst_ = nullptr;  // per input position, the mode of a value >= p (Schedule::strict_instance)
   void* d_strict_wit_ = nullptr;
+  void* d_strict_carry_ = nullptr;
+  void* d_carry_ = nullptr;        // [lane][n_carry][carry_words]: values carried in from the previous field segment
+  void* d_carry_slots_ = nullptr;  // slots this engine carries out (device copy)
+  uint32_t n_carry_ = 0, carry_words_ = 0;
+  uint32_t in_stride_ = 0;
+  bool in_stride_set_ = false;
+  Engine* chain_head_ = nullptr;
+  bool chain_first_ = true, chain_last_ = true;
+  void* owned_stream_ = nullptr;   // this engine's own stream while it runs on the chain head's
+  void* verdict_first_fail() const;
+  void* verdict_flags() const;
+  void* verdict_counts() const;
   void* d_packed_inst_ = nullptr;  // GF(2) path
   void* d_packed_wit_ = nullptr;
   void* h_stage_[2] = {nullptr, nullptr};  // pinned staging for host -> HBM input uploads

@@ -70,6 +70,12 @@ class WireScope {
       if (present_[i]) f((WireId)i, dense_[i]);
     for (const auto& kv : sparse_) f(kv.first, kv.second);
   }
+  template <class F>
+  void for_each_mut(F&& f) {   // the same, the wires may be replaced (not the keys)
+    for (size_t i = 0; i < dense_.size(); ++i)
+      if (present_[i]) f((WireId)i, dense_[i]);
+    for (auto& kv : sparse_) f(kv.first, kv.second);
+  }
 
  private:
   static constexpr WireId kDenseLimit = 1ull << 24;
@@ -170,6 +176,9 @@ class Evaluator {
   // evaluator.rs:750-752
   const Wire* get(WireId id) const { return values_.find(id); }
   const Scope& values() const { return values_; }
+  // the top-level scope, wires replaceable: a backend that opens a new field segment re-binds the wires that live on
+  // (between messages no other scope exists)
+  Scope& values_mut() { return values_; }
 
   bool has_error() const { return found_error_; }
   bool panicked() const { return panicked_; }

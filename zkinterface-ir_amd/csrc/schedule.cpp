@@ -19,7 +19,7 @@ inline int n_inputs(uint8_t k) {
   switch (k) {
     case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR: return 2;
     case TK_ADDC: case TK_MULC: case TK_COPY: case TK_NOT: case TK_ASSERT: case TK_NZ: return 1;
-    default: return 0;  // CONST, INSTANCE, WITNESS, NOP
+    default: return 0;  // CONST, INSTANCE, WITNESS, CARRY, NOP
   }
 }
 
@@ -214,7 +214,7 @@ void StreamScheduler::Impl::refuse_unreduced(uint32_t r, const char* consumer) {
                   "(evaluator.rs:896-938) and this path does not");
     return;
   }
-  std::vector<uint8_t>& pos = src_kind[r] == TK_INSTANCE ? s.strict_instance : s.strict_witness;
+  std::vector<uint8_t>& pos = src_kind[r] == TK_INSTANCE ? s.strict_instance : src_kind[r] == TK_WITNESS ? s.strict_witness : s.strict_carry;
   if (pos.size() <= src_pos[r]) pos.resize((size_t)src_pos[r] + 1, 0);
   pos[src_pos[r]] = 0xFF;
 }
@@ -225,7 +225,7 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
   for (uint32_t i = lo; i < hi; ++i) {
     const uint8_t k = w.kind[i - lo];
     const uint32_t a = w.a[i - lo], b = w.b[i - lo];
-    if (k == TK_CONST || k == TK_INSTANCE || k == TK_WITNESS) {
+    if (k == TK_CONST || k == TK_INSTANCE || k == TK_WITNESS || k == TK_CARRY) {
       src_root[i] = i;
       src_kind[i] = k;
       src_pos[i] = k == TK_CONST ? (b != 0 ? 1u : 0u) : a;   // tape: b != 0 marks a constant that is not canonical
@@ -242,7 +242,8 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
       if (r == kInf) continue;
       if (k == TK_ASSERT || k == TK_NOT) {
         src_zero_test[r] = 1;
-        sink_code[i - lo] = src_kind[r] == TK_CONST ? (src_pos[r] ? 1u : 0u) : 2u + 2u * src_pos[r] + (src_kind[r] == TK_WITNESS ? 1u : 0u);
+        sink_code[i - lo] = src_kind[r] == TK_CONST ? (src_pos[r] ? 1u : 0u)
+                                                    : 2u + 4u * src_pos[r] + (src_kind[r] == TK_INSTANCE ? 0u : src_kind[r] == TK_WITNESS ? 1u : 2u);
       } else {
         src_other[r] = 1;
         if (bit_op) refuse_unreduced(r, "and / xor");
@@ -267,7 +268,7 @@ void StreamScheduler::Impl::finish_input_modes() {
         refuse_unreduced(h, "assert_zero / not and, as its low bit, a gate");
       continue;
     }
-    std::vector<uint8_t>& pos = src_kind[h] == TK_INSTANCE ? s.strict_instance : s.strict_witness;
+    std::vector<uint8_t>& pos = src_kind[h] == TK_INSTANCE ? s.strict_instance : src_kind[h] == TK_WITNESS ? s.strict_witness : s.strict_carry;
     if (pos.size() <= src_pos[h]) pos.resize((size_t)src_pos[h] + 1, 0);
     uint8_t& mode = pos[src_pos[h]];
     if (mode == 0xFF) continue;
@@ -489,7 +490,7 @@ void StreamScheduler::Impl::fuse_and_pair() {
 
 void StreamScheduler::Impl::order_by_level() {
   // ---- order ops by (level, kind): counting sort ------------------------
-  constexpr uint32_t kKinds = TK_NZ + 1;
+  constexpr uint32_t kKinds = TK_CARRY + 1;
   std::vector<uint64_t> bucket((size_t)n_wlevels * kKinds + 1, 0);
   const std::vector<uint32_t>& level = s.level_of;
   size_t n_live = 0;
@@ -918,7 +919,7 @@ void StreamScheduler::Impl::emit_entries() {
         case TK_COPY: case TK_NZ: d.a0 = s.slot_of[x]; break;
         case TK_NOT: d.a0 = s.slot_of[x]; d.a1 = sink_code[i - lo]; break;   // a1: the unreduced source behind the operand
         case TK_CONST: d.a0 = x; break;
-        case TK_INSTANCE: case TK_WITNESS: d.a0 = x; break;
+        case TK_INSTANCE: case TK_WITNESS: case TK_CARRY: d.a0 = x; break;
         case TK_ASSERT:
           d.a0 = s.slot_of[x];
           d.b0 = y;
@@ -953,7 +954,7 @@ void StreamScheduler::Impl::emit_entries() {
         // GF(2): a constant >= 2 that only zero tests read (through copies) is `non-zero` to them: the constant 1
         d.a = (field.is_two && src_pos[i] && src_zero_test[i] && !src_other[i]) ? kSyntheticOne : x;
         break;
-      case TK_INSTANCE: case TK_WITNESS: d.a = x; break;
+      case TK_INSTANCE: case TK_WITNESS: case TK_CARRY: d.a = x; break;
       case TK_ASSERT:
         d.a = s.slot_of[x];
         d.b = y;

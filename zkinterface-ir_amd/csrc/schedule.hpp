@@ -73,6 +73,7 @@ struct Schedule {
   // input positions whose value must be canonical (an unreduced value would reach copy / assert_zero / not / a bit
   // operation / Evaluator::get): the GF(2) input packing flags a lane only for these (arithmetic entries carry the flag)
   std::vector<uint8_t> strict_instance, strict_witness;
+  std::vector<uint8_t> strict_carry;       // the same per value carried in from the previous field segment (TK_CARRY)
   std::vector<uint32_t> strand_level_ptr;  // level bounds of the strands (see Launch::level_ptr)
   std::vector<uint64_t> window_first_op;   // per window: index of its first program entry (+ a final end marker)
   uint32_t n_slots = 0;

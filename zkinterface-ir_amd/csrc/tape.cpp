@@ -7,7 +7,7 @@ namespace zki {
 const char* tape_kind_name(uint8_t k) {
   static const char* names[] = {"nop", "add", "mul", "addc", "mulc", "copy", "constant",
                                 "instance", "witness", "assert_zero", "and", "xor", "not"};
-  return k <= TK_NOT ? names[k] : k == TK_NZ ? "nz" : "?";
+  return k <= TK_NOT ? names[k] : k == TK_NZ ? "nz" : k == TK_CARRY ? "carry" : "?";
 }
 
 // ---------------------------------------------------------------- FieldHost
@@ -105,8 +105,13 @@ void TapeBackend::set_field(const Value& modulus, uint32_t degree, bool is_boole
   f.init(modulus);
   if (degree != 1) throw Error("Field should be of degree 1");
   if (field_set_) {
-    if (memcmp(f.p, field_.p, sizeof f.p) != 0 || is_boolean != is_boolean_)
-      throw Error("GPU backend: the field changed between Relation messages");
+    // A new modulus opens a new field segment of the session (capi.cpp switch_field), which gives it a backend of its
+    // own before the Evaluator gets here; a caller that drives this backend itself (zkgpu_backend_*) owns wires the
+    // library cannot see, so for it the change stays refused.
+    if (memcmp(f.p, field_.p, sizeof f.p) != 0)
+      throw Error("GPU backend: the field characteristic changed on a backend that already holds wires (the bundled Evaluator "
+                  "opens a new field segment for that, evaluator.rs:232-237; a caller-driven backend cannot)");
+    is_boolean_ = is_boolean;   // the gate set may change from message to message: it only selects the Evaluator's own arms
     return;
   }
   field_ = f;
@@ -136,7 +141,7 @@ uint32_t TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
   tape_.kind.push_back(kind);
   tape_.a.push_back(a);
   tape_.b.push_back(b);
-  if (kind != TK_ASSERT) ++tape_.n_value_ops;
+  if (kind != TK_ASSERT && kind != TK_CARRY) ++tape_.n_value_ops;
   const uint32_t h = (uint32_t)(tape_.kind.size() - 1);
   maybe_cut();
   return h;
@@ -187,7 +192,7 @@ uint32_t TapeBackend::h_mul_constant(uint32_t x, FieldElement c) {
 
 void TapeBackend::h_assert_zero(uint32_t w) {
   need_field();
-  const uint32_t seq = (uint32_t)tape_.assert_op.size();
+  const uint32_t seq = assert_base_ + (uint32_t)tape_.assert_op.size();   // global over the field segments of the session
   // the bookkeeping goes first: push() may close a window and hand the tape over
   tape_.assert_op.push_back((uint32_t)tape_.size());
   tape_.assert_wire.push_back(pending_assert_wire_);
@@ -220,6 +225,12 @@ uint32_t TapeBackend::h_instance(FieldElement val) {
   if (val.kind != TapeElement::INSTANCE_REF) throw Error("GPU backend: instance() needs a stream position");
   if (val.position + 1 > tape_.n_instance) tape_.n_instance = val.position + 1;
   return push(TK_INSTANCE, val.position, 0);
+}
+
+uint32_t TapeBackend::h_carry(uint32_t index) {
+  need_field();
+  if (index + 1 > tape_.n_carry) tape_.n_carry = index + 1;
+  return push(TK_CARRY, index, 0);
 }
 
 uint32_t TapeBackend::h_witness(const FieldElement* val) {

@@ -18,6 +18,9 @@ enum TapeKind : uint8_t {
   TK_NOP = 0, TK_ADD = 1, TK_MUL = 2, TK_ADDC = 3, TK_MULC = 4, TK_COPY = 5, TK_CONST = 6,
   TK_INSTANCE = 7, TK_WITNESS = 8, TK_ASSERT = 9, TK_AND = 10, TK_XOR = 11, TK_NOT = 12,
   TK_NZ = 13,  // scheduler only: 1 if the operand is non-zero else 0 (= x^(p-1) for a prime p), never recorded
+  TK_CARRY = 14,  // a value carried over from the previous field segment of the session (a: its index in the carry
+                  // stream).  Not a backend call of the reference: the wire simply lived on when the modulus changed
+                  // (evaluator.rs:232-237); a source like Instance / Witness, holding the UNREDUCED integer
 };
 const char* tape_kind_name(uint8_t k);  // names of SURVEY.md Appendix A ("copy", "mul", ...)
 
@@ -59,6 +62,7 @@ struct Tape {
   std::vector<Ladder> ladders;
   uint32_t ladder_open = kNoWire;          // tape size at note_ladder_begin while a ladder is being recorded
   uint32_t n_instance = 0, n_witness = 0;  // input positions referenced (max + 1)
+  uint32_t n_carry = 0;                    // values carried in from the previous field segment
   uint64_t n_value_ops = 0;
   // Dropped wires, in order: handle drop_handle[k] went out of the caller's reach when the tape held drop_pos[k]
   // entries -- no call recorded at or after that position can name it.  The reference's evaluator owns its wires
@@ -158,6 +162,7 @@ class TapeBackend {
   uint32_t h_not(uint32_t x) { return bitwise(TK_NOT, x, 0); }
   uint32_t h_instance(FieldElement val);
   uint32_t h_witness(const FieldElement* val);
+  uint32_t h_carry(uint32_t index);   // a wire of the previous field segment, alive in the scope when the modulus changed
   void h_ladder(size_t first, uint32_t base, uint32_t result) {
     tape_.ladder_open = kNoWire;
     // with is_boolean the "multiplies" of the ladder are `and` gates and Fermat says nothing about them
@@ -194,6 +199,16 @@ class TapeBackend {
   bool is_boolean() const { return is_boolean_; }
   const std::vector<Value>& lane0_instances() const { return lane0_instances_; }
   const std::vector<Value>& lane0_witnesses() const { return lane0_witnesses_; }
+  // a new field segment continues the input streams of the one before it (positions are global)
+  void adopt_streams(TapeBackend& from) {
+    lane0_instances_ = std::move(from.lane0_instances_);
+    lane0_witnesses_ = std::move(from.lane0_witnesses_);
+    from.lane0_instances_.clear();
+    from.lane0_witnesses_.clear();
+    max_ops_ = from.max_ops_;
+  }
+  void set_assert_base(uint32_t n) { assert_base_ = n; }   // global sequence number of this segment's first assert
+  uint32_t assert_base() const { return assert_base_; }
 
  private:
   static FieldElement literal(uint8_t v) {
@@ -223,6 +238,7 @@ class TapeBackend {
   Value modulus_;
   std::map<Value, uint32_t> const_index_;
   WireId pending_assert_wire_ = 0;
+  uint32_t assert_base_ = 0;
   uint64_t max_ops_ = 1ull << 30;
   std::vector<Value> lane0_instances_, lane0_witnesses_;
 };
