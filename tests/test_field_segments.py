@@ -195,7 +195,7 @@ def test_a_wide_field_after_a_narrow_one_on_the_gpu():
         w0, w1 = (7 * k) % P1, (11 * k + 3) % P1
         good = k % 5 != 2
         rows.append(([((w0 * w1) % P1 * big + (0 if good else 1)) % p2], [w0, w1, big]))
-    rows.append(([0], [0, 0, 2 ** 200]))        # a witness of the GF(101) segment that does not fit its limbs: refused
+    rows.append(([0], [2 ** 200, 0, 5]))        # a witness of the GF(101) segment that does not fit its limbs: refused
     inst, wit = batch_arrays([r[0] for r in rows], [r[1] for r in rows], 32)
     ev.set_inputs(inst, wit, len(rows))
     ev.replay()
@@ -207,3 +207,35 @@ def test_a_wide_field_after_a_narrow_one_on_the_gpu():
         n_ok += ref.violations == []
     assert ev.counts() == (n_ok, len(rows) - n_ok)
     assert 'not canonical' in ev.get_violations(len(rows) - 1)[0]
+
+
+def test_functions_and_a_switch_survive_the_field_change():
+    """known functions belong to the Evaluator, not to a field: a function declared under GF(101) is called under 2^61 - 1,
+    where the Switch weights are exponent ladders over THAT modulus (evaluator.rs:801-839), rewritten by Fermat per segment"""
+    functions = [('seg::mul', 1, 2, 0, 0, [('mul', 0, 1, 2)])]
+    first = sw.write_relation(sw.int_to_le(P1), 'arithmetic', '@function,@switch,', functions,
+                              [('witness', 0), ('witness', 1), ('call', 'seg::mul', [2], [0, 1])])
+    second = sw.write_relation(sw.int_to_le(P2), 'arithmetic', '@function,@switch,', [],
+                               [('witness', 3),                                          # the switch condition: 0 or 1
+                                ('call', 'seg::mul', [4], [2, 2]),                       # (w0 w1 mod 101)^2 over the new field
+                                ('switch', 3, [5], [bytes([0]), bytes([1])], [
+                                    ('anon', [4, 0], 0, 0, [('add', 0, 1, 2)]),          # case 0: t + w0
+                                    ('anon', [4, 1], 0, 0, [('mul', 0, 1, 2)]),          # case 1: t * w1
+                                ]),
+                                ('instance', 6), ('mulc', 7, 6, sw.int_to_le(P2 - 1)), ('add', 8, 5, 7), ('assert_zero', 8),
+                                ('free', 0, 8)])
+    msgs = [first, second]
+    ev = _session(msgs, 1, 3)
+    assert ev.host_violations() == [] and ev.n_field_segments == 2
+    ev.set_option('inspect_segment', '1')
+    kinds = (ev.schedule_dump()[0][:, 1] & 0xFF).tolist()
+    assert kinds.count(13) == 2        # both exponent ladders of the second segment became `x != 0` entries
+    ev.set_option('inspect_segment', '')
+    for w0, w1, c, good in ((3, 4, 0, True), (3, 4, 1, True), (100, 99, 1, False), (0, 7, 0, True), (5, 5, 2, True)):
+        t = ((w0 * w1) % P1) ** 2 % P2
+        out = (t + w0) % P2 if c == 0 else (t * w1) % P2 if c == 1 else 0     # no case matches: the weighted sum is 0
+        inst, wit = [(out + (0 if good else 1)) % P2], [w0, w1, c]
+        ref = oracle_lane(sw.int_to_le(P1), inst, wit, msgs, 32, trace=False)
+        ff, flagged = _simulate(ev, [P1, P2], inst, wit)
+        assert not flagged and expected_product_violations(ev, ff) == ref.violations, (w0, w1, c)
+        assert (ref.violations == []) == good
