@@ -309,7 +309,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   carry_words_ = carry_words;
   if (boolean_ && n_carry) throw std::runtime_error("Engine: values carried between field segments need an arithmetic field");
   if (!in_stride_set_) in_stride_ = elem_bytes_;
-  if (in_stride_ < elem_bytes_ || in_stride_ % 4) throw std::runtime_error("Engine: the input stride is narrower than the field's limbs");
+  if (in_stride_ < elem_bytes_ || (!boolean_ && in_stride_ % 4)) throw std::runtime_error("Engine: the input stride is narrower than the field's limbs");
   zkgpu::FieldParams fp;
   memset(&fp, 0, sizeof fp);
   memcpy(fp.p, f.p, sizeof fp.p);
