@@ -239,3 +239,75 @@ def test_functions_and_a_switch_survive_the_field_change():
         ff, flagged = _simulate(ev, [P1, P2], inst, wit)
         assert not flagged and expected_product_violations(ev, ff) == ref.violations, (w0, w1, c)
         assert (ref.violations == []) == good
+
+
+# ---- fuzz: random structured relations cut into two Relation messages under two moduli ---------------------------------
+FIELD_PAIRS = [(P1, P2), (P2, P1), (circuits.BN254_R, P1), (P1, circuits.BN254_R), (P3, P1), (P1, P3), (P2, circuits.P320)]
+
+
+def _two_field_case(seed):
+    """(messages, moduli, generator) or None: a random relation of tests/random_circuits.py whose top-level gates are cut
+    at a random place; the functions travel with the first message, constants and inputs are below both moduli, so what is
+    >= a modulus is what the first segment hands to a second one over a SMALLER field"""
+    from random_circuits import Gen
+    import random
+    pa, pb = FIELD_PAIRS[seed % len(FIELD_PAIRS)]
+    g = Gen(seed, min(pa, pb), False)
+    g.relation()
+    gates = g.spec['gates']
+    cut = random.Random(seed).randrange(1, max(2, len(gates)))
+    msgs = [sw.write_relation(sw.int_to_le(pa), 'arithmetic', g.spec['features'], g.spec['functions'], gates[:cut]),
+            sw.write_relation(sw.int_to_le(pb), 'arithmetic', g.spec['features'], [], gates[cut:])]
+    return msgs, [pa, pb], g
+
+
+@pytest.mark.parametrize('seed', range(70))
+def test_random_relations_under_two_moduli_against_the_oracle(seed):
+    msgs, moduli, g = _two_field_case(seed)
+    rows_i, rows_w = g.lane_inputs(3, seed + 500)
+    ev = zk.Evaluator()
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    for m in msgs:
+        ev.ingest_message(m)
+    if ev.n_field_segments == 1:        # the first message already ended in an error: nothing was recorded after it
+        assert ev.host_violations() != []
+        return
+    try:
+        ev.finalize()
+    except zk.ZkGpuError as e:          # e.g. nothing recorded at all
+        assert 'no Relation' in str(e) or 'constant >=' in str(e), e
+        return
+    for lane in range(3):
+        ref = oracle_lane(sw.int_to_le(moduli[0]), rows_i[lane], rows_w[lane], msgs, 32, trace=False)
+        ff, flagged = _simulate(ev, moduli, rows_i[lane], rows_w[lane])
+        if flagged:                     # a carried integer >= the smaller modulus where its bits / Evaluator::get matter
+            continue
+        assert expected_product_violations(ev, ff) == ref.violations, (seed, lane)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(0, 70, 3))
+def test_random_relations_under_two_moduli_on_the_gpu(seed):
+    msgs, moduli, g = _two_field_case(seed)
+    lanes = 5
+    rows_i, rows_w = g.lane_inputs(lanes, seed + 500)
+    ev = zk.Evaluator()
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    for m in msgs:
+        ev.ingest_message(m)
+    if ev.n_field_segments == 1:
+        return
+    try:
+        ev.finalize()
+    except zk.ZkGpuError:
+        return
+    inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+    ev.set_inputs(inst if g.n_inst else None, wit if g.n_wit else None, lanes)
+    ev.replay()
+    ev.synchronize()
+    _, flags = ev.lane_results(lanes)
+    for lane in range(lanes):
+        if flags[lane]:
+            continue
+        ref = oracle_lane(sw.int_to_le(moduli[0]), rows_i[lane], rows_w[lane], msgs, 32, trace=False)
+        assert ev.get_violations(lane) == ref.violations, (seed, lane)

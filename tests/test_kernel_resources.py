@@ -79,5 +79,6 @@ def test_arithmetic_kernels_at_bn254_width():
     row = res['zkgpu::r1cs_row_kernel<8, false>']
     assert row['scratch'] == 0 and row['vgpr_spill'] == 0 and row['sgpr_spill'] == 0, row
     for name, k in res.items():
-        # (the cold kernels -- inputs of three streams, asserts, strands -- may park a few SGPRs in VGPR lanes; nothing goes to memory)
-        assert k['scratch'] == 0 and k['vgpr_spill'] == 0, (name, k)
+        # (the input streams' descriptors sit behind one pointer, device/args.hpp InputAux: in the kernarg block they made
+        # the cold kernels spill 28 SGPRs and the strands of a structured relation 13 % slower)
+        assert k['scratch'] == 0 and k['vgpr_spill'] == 0 and k['sgpr_spill'] == 0, (name, k)

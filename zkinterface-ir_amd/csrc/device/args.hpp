@@ -65,6 +65,19 @@ struct TapeOp2 {
 constexpr u32 kNoFail = 0xFFFFFFFFu;
 constexpr u32 kLaneFlagNonCanonical = 1u;
 
+// What only the input arms of the replay kernels read (instance / witness / carried values and their modes): kept behind
+// ONE pointer so that the eleven words do not sit in SGPRs through every other arm of the cold kernels (with them in the
+// kernarg block the cold kernels spilled 28 SGPRs and the strands of a structured relation ran 13 % slower).
+struct InputAux {
+  const uint8_t* strict_inst;   // per input position: 0xFF = a value >= p flags the lane (Schedule::strict_instance)
+  const uint8_t* strict_wit;
+  const uint8_t* strict_carry;
+  const u32* carry;             // [lane][n_carry][carry_words]: canonical values of the wires carried over from the previous
+  u32 n_carry, carry_words;     // field segment (carry_words = that field's N)
+  u32 in_stride_words;          // 32-bit words per input value in inst / wit (N, or more in a session of several fields)
+  u32 pad;
+};
+
 struct ReplayArgs {
   const TapeOp* ops;      // ops of this launch (device)
   u32 n_ops;
@@ -81,12 +94,7 @@ struct ReplayArgs {
   u32* first_fail;        // [lane] min assert sequence number that failed
   u32* lane_flags;        // [lane] sticky flags (non-canonical input ...)
   u32 xcd_chunks;         // != 0: XCD-aware 1-D grid, see block_coords()
-  const uint8_t* strict_inst;   // per input position: 0xFF = a value >= p flags the lane (Schedule::strict_instance)
-  const uint8_t* strict_wit;
-  u32 in_stride_words;          // 32-bit words per input value in inst / wit (N, or more in a session of several fields)
-  const u32* carry;             // [lane][n_carry][carry_words]: canonical values of the wires carried over from the previous
-  u32 n_carry, carry_words;     // field segment (carry_words = that field's N)
-  const uint8_t* strict_carry;
+  const InputAux* aux;    // device memory, wave-uniform: read on the scalar path
 };
 
 struct ReplayArgs2 {
@@ -106,12 +114,7 @@ struct ReplayArgs2 {
   u32* lane_flags;
   u32 xcd_chunks;
   u32 op_stride;          // 1 or 4, see the kernel
-  const uint8_t* strict_inst;   // as in ReplayArgs
-  const uint8_t* strict_wit;
-  u32 in_stride_words;
-  const u32* carry;
-  u32 n_carry, carry_words;
-  const uint8_t* strict_carry;
+  const InputAux* aux;    // as in ReplayArgs
 };
 
 // instantiations of replay_fused_kernel (replay_kernels.hpp)

@@ -110,11 +110,13 @@ __device__ __forceinline__ Fp<N> input_load(const void* __restrict__ base, u32 l
 }
 
 // the raw value of input stream 0 (instance), 1 (witness) or 2 (carry) at `position`
+typedef const InputAux __attribute__((address_space(4))) InputAuxS;   // (scalar loads)
 template <int N, class Args>
 __device__ __forceinline__ Fp<N> stream_load(u32 stream, u32 position, const Args& args, u32 lane_g, bool lane_valid, bool& too_wide) {
-  if (stream == 2) return input_load<N>(args.carry, lane_g, args.n_carry, position, lane_valid, args.carry_words, too_wide);
+  InputAuxS* aux = (InputAuxS*)(unsigned long long)args.aux;
+  if (stream == 2) return input_load<N>(aux->carry, lane_g, aux->n_carry, position, lane_valid, aux->carry_words, too_wide);
   return input_load<N>(stream ? args.wit : args.inst, lane_g, stream ? args.n_wit : args.n_inst, position, lane_valid,
-                       args.in_stride_words, too_wide);
+                       aux->in_stride_words, too_wide);
 }
 
 // Input positions whose value must be canonical (mode 0xFF in Schedule::strict_instance / strict_witness: it reaches an
@@ -144,7 +146,8 @@ __device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& ar
   const u32 stream = kind == OP_INSTANCE ? 0u : kind == OP_WITNESS ? 1u : 2u;
   bool too_wide;
   const Fp<N> raw = stream_load<N>(stream, position, args, lane_g, lane_valid, too_wide);
-  const uint8_t* modes = stream == 0 ? args.strict_inst : stream == 1 ? args.strict_wit : args.strict_carry;
+  InputAuxS* aux = (InputAuxS*)(unsigned long long)args.aux;
+  const uint8_t* modes = stream == 0 ? aux->strict_inst : stream == 1 ? aux->strict_wit : aux->strict_carry;
   // The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  At a strict position the value can reach an
   // integer bit operation or Evaluator::get as it is, where the residue would not do: flag the lane.
   if (lane_valid && (too_wide || (position_is_strict(modes, position) && fp_geq_p<N>(raw, fp))))

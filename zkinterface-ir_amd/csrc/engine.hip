@@ -137,6 +137,7 @@ Engine::~Engine() {
   dfree(d_strict_wit_);
   dfree(d_strict_carry_);
   dfree(d_carry_slots_);
+  dfree(d_input_aux_);
   dfree(d_r1cs_rows_);
   dfree(d_r1cs_terms_);
   dfree(d_r1cs_coefs_);
@@ -429,6 +430,19 @@ void Engine::set_batch(uint32_t batch) {
   HIP_OK(hipMalloc(&d_flags_, padded_lanes * 4));
   HIP_OK(hipMalloc(&d_r1cs_fail_, padded_lanes * 4));
   if (n_carry_) HIP_OK(hipMalloc(&d_carry_, std::max<size_t>((size_t)batch * n_carry_ * carry_words_ * 4, 64)));
+  {   // what the input arms of the arithmetic kernels read, behind one pointer (device/args.hpp InputAux)
+    zkgpu::InputAux aux;
+    memset(&aux, 0, sizeof aux);
+    aux.strict_inst = (const uint8_t*)d_strict_inst_;
+    aux.strict_wit = (const uint8_t*)d_strict_wit_;
+    aux.strict_carry = (const uint8_t*)d_strict_carry_;
+    aux.carry = (const zkgpu::u32*)d_carry_;
+    aux.n_carry = n_carry_;
+    aux.carry_words = carry_words_;
+    aux.in_stride_words = in_stride_ / 4;
+    if (!d_input_aux_) HIP_OK(hipMalloc(&d_input_aux_, sizeof aux));
+    HIP_OK(hipMemcpy(d_input_aux_, &aux, sizeof aux, hipMemcpyHostToDevice));
+  }
   if (boolean_) {
     const size_t words = (size_t)lane_blocks_ * 64;
     HIP_OK(hipMalloc(&d_packed_inst_, std::max<size_t>((size_t)n_inst_ * words * 8, 64)));
@@ -588,13 +602,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.n_wit = n_wit_;
     a.first_fail = (zkgpu::u32*)verdict_first_fail();
     a.lane_flags = (zkgpu::u32*)verdict_flags();
-    a.strict_inst = (const uint8_t*)d_strict_inst_;
-    a.strict_wit = (const uint8_t*)d_strict_wit_;
-    a.in_stride_words = in_stride_ / 4;
-    a.carry = (const zkgpu::u32*)d_carry_;
-    a.n_carry = n_carry_;
-    a.carry_words = carry_words_;
-    a.strict_carry = (const uint8_t*)d_strict_carry_;
+    a.aux = (const zkgpu::InputAux*)d_input_aux_;
     if (L.sequential) {
       // a strand: one workgroup per lane block walks the levels of the run, barrier between levels
       a.xcd_chunks = 0;
@@ -638,13 +646,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   a.n_wit = n_wit_;
   a.first_fail = (zkgpu::u32*)verdict_first_fail();
   a.lane_flags = (zkgpu::u32*)verdict_flags();
-  a.strict_inst = (const uint8_t*)d_strict_inst_;
-  a.strict_wit = (const uint8_t*)d_strict_wit_;
-  a.in_stride_words = in_stride_ / 4;
-  a.carry = (const zkgpu::u32*)d_carry_;
-  a.n_carry = n_carry_;
-  a.carry_words = carry_words_;
-  a.strict_carry = (const uint8_t*)d_strict_carry_;
+  a.aux = (const zkgpu::InputAux*)d_input_aux_;
   a.xcd_chunks = xcd_chunks;
   launch_plain(nwords_, sched_.has_bitops, grid, st, a, fp);
 }

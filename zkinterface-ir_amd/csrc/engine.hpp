@@ -167,6 +167,7 @@ class Engine {
   void* d_strict_carry_ = nullptr;
   void* d_carry_ = nullptr;        // [lane][n_carry][carry_words]: values carried in from the previous field segment
   void* d_carry_slots_ = nullptr;  // slots this engine carries out (device copy)
+  void* d_input_aux_ = nullptr;    // zkgpu::InputAux of this batch
   uint32_t n_carry_ = 0, carry_words_ = 0;
   uint32_t in_stride_ = 0;
   bool in_stride_set_ = false;
