@@ -99,12 +99,17 @@ __device__ __forceinline__ Fp<N> input_load(const void* __restrict__ base, u32 l
   for (int i = 0; i < N; ++i) r.w[i] = 0;
   if (valid) {
     const u32* p = reinterpret_cast<const u32*>(base) + ((size_t)lane_g * n_vals + idx) * stride_words;
+    if (stride_words == (u32)N) {   // the usual case (wave-uniform): N unconditional loads, which hipcc merges into dwordx4
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-      if ((u32)i < stride_words) r.w[i] = p[i];
-    u32 hi = 0;
-    for (u32 i = N; i < stride_words; ++i) hi |= p[i];
-    too_wide = hi != 0;
+      for (int i = 0; i < N; ++i) r.w[i] = p[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if ((u32)i < stride_words) r.w[i] = p[i];
+      u32 hi = 0;
+      for (u32 i = N; i < stride_words; ++i) hi |= p[i];
+      too_wide = hi != 0;
+    }
   }
   return r;
 }
