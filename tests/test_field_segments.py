@@ -311,3 +311,35 @@ def test_random_relations_under_two_moduli_on_the_gpu(seed):
             continue
         ref = oracle_lane(sw.int_to_le(moduli[0]), rows_i[lane], rows_w[lane], msgs, 32, trace=False)
         assert ev.get_violations(lane) == ref.violations, (seed, lane)
+
+
+def test_a_streamed_ingest_gives_up_streaming_at_the_field_change_and_nothing_else():
+    """option "stream": the windows scheduled for the first field are dropped at the change (the segment is scheduled at
+    finalize like the others), later segments are not streamed; the program is the one a plain ingest makes"""
+    chain = [('witness', 0)] + [('addc', k, k - 1, bytes([1])) for k in range(1, 50)] + [('free', 0, 48)]
+    msgs = [sw.write_relation(sw.int_to_le(P1), 'arithmetic', 'simple', [], chain),
+            sw.write_relation(sw.int_to_le(P2), 'arithmetic', 'simple', [],
+                              [('mul', 50, 49, 49), ('instance', 51), ('mulc', 52, 51, sw.int_to_le(P2 - 1)), ('add', 53, 50, 52),
+                               ('assert_zero', 53), ('free', 49, 53)])]
+    dumps = {}
+    for stream in ('0', '16'):
+        ev = zk.Evaluator()
+        ev.set_option('stream', stream)
+        ev.declare_inputs(1, 1)
+        for m in msgs:
+            ev.ingest_message(m)
+        ev.finalize()
+        assert ev.n_field_segments == 2 and ev.host_violations() == []
+        per_segment = []
+        for k in range(2):
+            ev.set_option('inspect_segment', str(k))
+            ops, launches, consts, _ = ev.schedule_dump()
+            per_segment.append((ops.tolist(), launches.tolist(), consts.tolist()))
+        ev.set_option('inspect_segment', '')
+        dumps[stream] = per_segment
+        for w, good in ((3, True), (77, False)):
+            e = ((w + 49) % P1) ** 2 % P2 + (0 if good else 5)
+            ref = oracle_lane(sw.int_to_le(P1), [e], [w], msgs, 32, trace=False)
+            ff, flagged = _simulate(ev, [P1, P2], [e], [w])
+            assert not flagged and expected_product_violations(ev, ff) == ref.violations and (ref.violations == []) == good
+    assert dumps['0'] == dumps['16']
