@@ -75,8 +75,13 @@ def interpret(prog, consts, inst_bits, wit_bits):
                 assert (off // 2) + br * ROW * 3 <= len(rows), 'a block fetches block_rows rows: they must lie in the stream'
                 for r in range(n):
                     rec = rows[off // 2 + r * ROW * 3: off // 2 + (r + 1) * ROW * 3].reshape(ROW, 3).astype(np.int64)
-                    dst, a, b = rec[:, 0], rec[:, 1], rec[:, 2]
+                    dst, a, b = rec[:, 0].copy(), rec[:, 1], rec[:, 2]
+                    # the even op of a thread names the slot PAIR (dst / 2): the thread stores its two results with one
+                    # ds_write_b64, so the odd op's slot must be the other half of that pair
+                    dst[0::2] *= 2
+                    assert np.array_equal(dst[1::2], dst[0::2] + 1), 'the two results of a thread are not one aligned slot pair'
                     assert dst.max() < real + 32 and a.max() < words and b.max() < words
+                    assert real % 2 == 0, 'the scratch slots start at an even slot'
                     real_dst = dst[dst < real]
                     assert len(np.unique(real_dst)) == len(real_dst), 'two ops of a row write one slot'
                     level_reads.update(a[a < real].tolist())

@@ -193,7 +193,9 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
 
 // The xor / and / not / copy ops of a level are stored as ROWS of 2048 ops of one kind -- and or xor: `not a` is stored
 // as a xor ONES, a copy as a xor ZERO (args.hpp) -- padded to whole rows with ops on scratch slots, without their kind:
-// three u16 per op, two ops = 12 bytes per thread and row -- {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}.
+// three u16 per op, two ops = 12 bytes per thread and row -- {pair | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}.  The two
+// results of a thread go to the two halves of ONE 8-byte slot pair (slots 2 * pair and 2 * pair + 1: the scheduler
+// allocates the result slots of a row pair by pair), so a row step has one address shift and one ds_write_b64 for them.
 // Consecutive rows of a level form BLOCKS of at most BR rows (args.hpp: block header).
 
 // wave-uniform table read on the scalar path (s_load)
@@ -216,7 +218,7 @@ __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
 // hipcc cannot be told that a register is waiting for a load: it is free to copy it (at a branch join, say) before the
 // data is there.  So everything that is in flight lives in registers the compiler does not own -- the kernel is
 // compiled for kLdsCompilerVgprs registers (amdgpu_num_vgpr) and the registers above are named in the asm text:
-//   v[kRegP + 4 r .. + 2]  program words of row r: {dst0 | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}
+//   v[kRegP + 4 r .. + 2]  program words of row r: {pair | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}
 //   v[kRegV + 4 s .. + 3]  operand values a0, a1, b0, b1 of the row in value set s (row r uses set r mod (kLdsAhead + 1))
 //   v[kRegT .. + 3]        address / result temporaries of a row step
 //   v[kRegH .. + 1]        block header in flight
@@ -231,13 +233,14 @@ constexpr int kLdsAhead = ZKGPU_LDS_AHEAD;
 constexpr int kRegP = 64, kRegH = 124, kRegT = kRegH - 4;   // kRegT .. + 3: address / result temporaries of a step
 template <int BR> constexpr int kRegV = kRegP + 4 * BR;   // value sets follow the BR rows of program words
 template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1) <= kRegT;
+static_assert((kRegT + 2) % 2 == 0, "the two results of a row step are the data of one ds_write_b64: an aligned register pair");
 
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
 #define ZKGPU_SDWA_HI " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n\t"
 
 // The kernel is bound by instruction issue (a SIMD hands out one slot every four cycles and the 16 waves of the
-// workgroup fill them): a row step is two asm statements holding nothing but 8 VALU (six address shifts, two gates),
-// 6 LDS, 1 VMEM and the waits (vmcnt every other row, lgkmcnt every row).  What hipcc makes of a C++ if-chain over the
+// workgroup fill them): a row step is two asm statements holding nothing but 7 VALU (five address shifts, two gates),
+// 5 LDS (four reads, one 64-bit write), 1 VMEM and the waits (vmcnt every other row, lgkmcnt every row).  What hipcc makes of a C++ if-chain over the
 // row kind is a dozen scalar instructions and up to five branches per row, and between statements it puts address adds.
 template <int BR, int R>   // issue the four operand reads of row R (block start: rows 0 .. kLdsAhead - 1)
 __device__ __forceinline__ void ldsp_read() {
@@ -262,9 +265,7 @@ __device__ __forceinline__ void ldsp_wait_row() {
 // A statement that DEFINES a register (an output, a clobbered flag) makes hipcc put an s_nop behind it on gfx940+ (it
 // cannot see inside and assumes a forwarding hazard): the steps define nothing -- their four temporaries are registers
 // of the hand-managed range (kRegT) -- except the one form that decides and / xor at run time (it clobbers scc).
-#define ZKGPU_LDS_STEP_DST                                           \
-  "v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[px]]" ZKGPU_SDWA_LO      \
-  "v_lshlrev_b32_sdwa v[%[t1]], %[two], v[%[py]]" ZKGPU_SDWA_HI
+#define ZKGPU_LDS_STEP_DST "v_lshlrev_b32_sdwa v[%[t0]], %[three], v[%[px]]" ZKGPU_SDWA_LO   /* byte address of the slot pair */
 #define ZKGPU_LDS_STEP_AHEAD                                           \
   "v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[ax]]" ZKGPU_SDWA_HI        \
   "v_lshlrev_b32_sdwa v[%[t1]], %[two], v[%[az]]" ZKGPU_SDWA_LO        \
@@ -281,7 +282,7 @@ template <int BR, int N, int R, int KIND>
 __device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 voff) {
   constexpr int S = kLdsAhead + 1;
   constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % S);
-  constexpr int w = 2 * (R < kLdsAhead ? R : kLdsAhead);                        // writes behind the reads of row R
+  constexpr int w = R < kLdsAhead ? R : kLdsAhead;                              // writes (one per row) behind the reads of row R
   constexpr int ahead = N - 1 - R < kLdsAhead ? N - 1 - R : kLdsAhead;         // rows whose reads are behind them
   constexpr int lg = 4 * ahead + w < 15 ? 4 * ahead + w : 15;                  // lgkmcnt counts to 15: beyond, wait for a little more
   if constexpr (R + kLdsAhead < N) {
@@ -290,7 +291,7 @@ __device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 vof
     constexpr int vm = BR - kLdsAhead - 1;
 #define ZKGPU_LDS_STEP_AHEAD_OPERANDS                                                                                      \
   :                                                                                                                        \
-  : [two] "s"(2u), [vm] "n"(vm), [lg] "n"(lg), [ax] "n"(PA), [ay] "n"(PA + 1), [az] "n"(PA + 2), [a0] "n"(VA),              \
+  : [two] "s"(2u), [three] "s"(3u), [vm] "n"(vm), [lg] "n"(lg), [ax] "n"(PA), [ay] "n"(PA + 1), [az] "n"(PA + 2), [a0] "n"(VA),              \
     [a1] "n"(VA + 1), [a2] "n"(VA + 2), [a3] "n"(VA + 3), [px] "n"(P), [py] "n"(P + 1), ZKGPU_LDS_STEP_TEMPS               \
   : "memory"
     if constexpr (R % 2 == 0)
@@ -300,15 +301,14 @@ __device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 vof
   } else {
     asm volatile(ZKGPU_LDS_STEP_DST "s_waitcnt lgkmcnt(%[lg])"
                  :
-                 : [two] "s"(2u), [lg] "n"(lg), [px] "n"(P), [py] "n"(P + 1), ZKGPU_LDS_STEP_TEMPS
+                 : [three] "s"(3u), [lg] "n"(lg), [px] "n"(P), ZKGPU_LDS_STEP_TEMPS
                  : "memory");
   }
   // gates of row R, their writes, and the refill of the row's registers.  KIND 0 / 1: the row is known to be and / xor
   // (a full block whose rows are `A` and-rows followed by xor-rows: one instantiation per A, no decision per row);
   // KIND 2: by the row's bit of the block header (s_bitcmp1 + a branch inside the statement, which then clobbers scc).
 #define ZKGPU_LDS_STEP_WRITE                                         \
-  "ds_write_b32 v[%[t0]], v[%[t2]]\n\t"                              \
-  "ds_write_b32 v[%[t1]], v[%[t3]]\n\t"                              \
+  "ds_write_b64 v[%[t0]], v[%[t2]:%[t3]]\n\t"                        \
   "global_load_dwordx3 v[%[px]:%[pz]], %[voff], %[base]"
 #define ZKGPU_LDS_STEP_GATES(OP)                                     \
   OP " v[%[t2]], v[%[v0]], v[%[v2]]\n\t"                             \

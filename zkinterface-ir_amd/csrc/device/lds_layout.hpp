@@ -13,7 +13,8 @@ struct LdsOp {  // 8-byte program entry of a generic chunk; wide fields are spli
 // constants, asserts, sequential segments) holds 8-byte entries: `first` indexes `ops`, `rows` counts rows of
 // kLdsRowOps entries (or entries, for a sequential chunk).  A chunk with bit 10 set is a run of `run` BLOCKS starting at
 // block `first`: the xor / and / not / copy ops of a level as rows of kLdsRowOps ops of one kind, 12 bytes per thread
-// and row in `ops6` (two ops of three u16 {dst, a, b}).  Block header (two u32 in `blocks`):
+// and row in `ops6` (two ops of three u16 {dst, a, b}; the dst field of the EVEN op holds the slot PAIR, dst / 2: the two
+// results of a thread are the halves of one aligned 8-byte pair of slots, written by one ds_write_b64).  Block header (two u32 in `blocks`):
 //   { rows (1..block_rows) | barrier_after << 4 | (row r is xor) << (kLdsBlockKindShift + r) | (a + 1) << kLdsBlockAndShift
 //     when the block is full and its rows are `a` and-rows followed by xor-rows (0 otherwise),  byte offset of the block's first row in ops6 }
 // Rows know two kinds only, and / xor: `not a` is stored as a xor ONES and a copy as a xor ZERO, two constant slots

@@ -158,9 +158,22 @@ LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& blo
           const LdsOp o = encode(s.ops[L.first + q]);
           put6(o.dst, o.a, kind == TK_NOT ? ones : kind == TK_COPY ? zero : o.b);
         }
-        // padding ops write 32 scratch slots, one per bank and lane group (the op at position n runs on lane
-        // (n / 2) % 64): 32 lanes storing to ONE address would serialise in the LDS
-        while (n % zkgpu::kLdsRowOps) put6((unsigned short)(scratch + (n / 2) % zkgpu::kLdsScratchSlots), zero, zero);
+        // padding ops write the scratch slots -- 16 pairs, one per pair of banks: the op pair of thread t (positions 2t,
+        // 2t + 1) goes to pair (t % 16), so the 16 lanes one ds_write_b64 cycle serves hit 16 different bank pairs
+        const size_t run_start = lo6.size() - 3 * n;
+        while (n % zkgpu::kLdsRowOps) {
+          const unsigned short pair_slot = (unsigned short)(scratch + 2 * ((n / 2) % (zkgpu::kLdsScratchSlots / 2)) + (n & 1));
+          // (an odd run: the partner of its last op is the unused half of that op's own pair)
+          put6((n & 1) ? (unsigned short)(lo6[lo6.size() - 3] + 1) : pair_slot, zero, zero);
+        }
+        // the even op of every thread names the slot PAIR: its result and its neighbour's are the two halves
+        for (size_t q = 0; q < n; q += 2) {
+          unsigned short& d0 = lo6[run_start + 3 * q];
+          const unsigned short d1 = lo6[run_start + 3 * (q + 1)];
+          if ((d0 & 1) || d1 != d0 + 1)
+            throw std::runtime_error("Engine: the results of a row are not allocated as aligned slot pairs (scheduler / LDS program mismatch)");
+          d0 = (unsigned short)(d0 >> 1);
+        }
         for (size_t r = 0; r < n / zkgpu::kLdsRowOps; ++r) open_kinds.push_back((uint32_t)rk);
         if (last_kind) close_blocks(true);
       } else {

@@ -25,6 +25,7 @@ inline int n_inputs(uint8_t k) {
 
 constexpr uint32_t kInf = 0xFFFFFFFFu;
 constexpr uint32_t kSyntheticOne = 0xFFFFFFFEu;   // GF(2) CONST entry: the pool's synthetic 1 (resolved in finish())
+constexpr uint32_t kSyntheticZero = 0xFFFFFFFDu;  // ... and its synthetic 0 (mul_constant by an even constant)
 
 // Depth-first walk of the "reads the same wire" graph of one level: ops become neighbours of an op they
 // share an operand with, so the second reader of a wire runs while the first reader's fetch is still in
@@ -127,8 +128,14 @@ struct StreamScheduler::Impl {
   std::vector<uint8_t> flags;
   std::vector<uint32_t> open_list;   // values with a slot that may still get readers
   std::vector<uint32_t> free_slots;
-  std::vector<std::vector<uint32_t>> free_by_bank;  // GF(2), bank-aware slots: free slots per LDS bank
-  std::vector<uint32_t> next_fresh;                 // smallest never-used slot of each bank
+  // GF(2): slots are handed out in aligned PAIRS (2d, 2d + 1) -- the two results of a thread of the LDS-resident kernel
+  // are one 8-byte store (device/bool_kernels.hpp) -- from free lists per pair bank (d mod 16: the 16 lanes one
+  // ds_write_b64 cycle serves hit 16 different bank pairs) when the schedule is bank-aware
+  std::vector<std::vector<uint32_t>> free_pairs;    // free pairs per pair bank (one list without bank-awareness)
+  std::vector<uint32_t> next_fresh_pair;            // smallest never-used pair of each pair bank
+  std::vector<uint8_t> pair_live;                   // per pair: values living in it (0, 1 or 2)
+  uint32_t open_single = kInf;                      // a pair one half of which went to an op outside the rows
+  uint32_t row_pair = kInf;                         // the pair of the even op just placed (its odd neighbour takes the other half)
   uint32_t n_slots = 0;
   uint32_t n_windows = 0;
 
@@ -557,30 +564,61 @@ void StreamScheduler::Impl::assign_slots() {
   // banks: `banked` (below) orders the ops of a (level, kind) run so that the 32 ops one `ds_read_b32` group serves
   // read operands from different banks, and gives the op at lane k a result slot in bank k mod 32.
   const bool banked = s.boolean_path && opt.bank_aware && !opt.retain_all;
-  constexpr uint32_t kBanks = 32;
-  auto take_slot = [&](uint32_t bank) {
-    if (banked && bank == kInf) {
-      // no bank wanted (ops of narrow levels, pair seconds): any free slot, else the smallest slot never used
+  constexpr uint32_t kBanks = 32, kPairBanks = 16;
+  const uint32_t n_pair_lists = banked ? kPairBanks : 1;
+  if (s.boolean_path && free_pairs.empty()) {
+    free_pairs.resize(n_pair_lists);
+    next_fresh_pair.resize(n_pair_lists);
+    for (uint32_t b = 0; b < n_pair_lists; ++b) next_fresh_pair[b] = b;
+  }
+  // a free pair of the wanted pair bank (kInf: any -- the fullest free list, else the smallest pair never used)
+  auto take_pair = [&](uint32_t bank) {
+    if (bank == kInf || !banked) {
       uint32_t best = kInf;
-      for (uint32_t b = 0; b < kBanks; ++b)
-        if (!free_by_bank[b].empty() && (best == kInf || free_by_bank[b].size() > free_by_bank[best].size())) best = b;
+      for (uint32_t b = 0; b < n_pair_lists; ++b)
+        if (!free_pairs[b].empty() && (best == kInf || free_pairs[b].size() > free_pairs[best].size())) best = b;
       if (best == kInf)
-        for (uint32_t b = 0; b < kBanks; ++b)
-          if (best == kInf || next_fresh[b] < next_fresh[best]) best = b;
+        for (uint32_t b = 0; b < n_pair_lists; ++b)
+          if (best == kInf || next_fresh_pair[b] < next_fresh_pair[best]) best = b;
       bank = best;
     }
-    if (banked) {
-      std::vector<uint32_t>& f = free_by_bank[bank];
-      if (!f.empty()) {
-        const uint32_t slot = f.back();
-        f.pop_back();
-        return slot;
-      }
-      const uint32_t slot = next_fresh[bank];
-      next_fresh[bank] += kBanks;
-      n_slots = std::max(n_slots, slot + 1);
-      return slot;
+    uint32_t d;
+    if (!free_pairs[bank].empty()) {
+      d = free_pairs[bank].back();
+      free_pairs[bank].pop_back();
+    } else {
+      d = next_fresh_pair[bank];
+      next_fresh_pair[bank] += n_pair_lists;
     }
+    if (pair_live.size() <= d) pair_live.resize((size_t)d + 1, 0);
+    n_slots = std::max(n_slots, 2 * d + 2);
+    return d;
+  };
+  // GF(2).  position: kInf = an op outside the rows (inputs, constants, narrow levels: one half of a shared pair);
+  // otherwise the op's position in its (level, kind) run -- the even op of a thread opens a pair of the thread's pair
+  // bank, its odd neighbour takes the other half.
+  bool prefer_bank = false;   // the run being placed is long enough for whole groups of lanes: its threads get their pair banks
+  auto take_bool_slot = [&](uint32_t position) {
+    uint32_t slot;
+    if (position == kInf) {
+      if (open_single == kInf) {
+        open_single = take_pair(kInf);
+        slot = 2 * open_single;
+      } else {
+        slot = 2 * open_single + 1;
+        open_single = kInf;
+      }
+    } else if ((position & 1) == 0) {
+      row_pair = take_pair(banked && prefer_bank ? (position / 2) % kPairBanks : kInf);
+      slot = 2 * row_pair;
+    } else {
+      slot = 2 * row_pair + 1;
+    }
+    ++pair_live[slot / 2];
+    return slot;
+  };
+  auto take_slot = [&](uint32_t position) {
+    if (s.boolean_path) return take_bool_slot(position);
     if (!free_slots.empty()) {
       const uint32_t slot = free_slots.back();
       free_slots.pop_back();
@@ -589,14 +627,13 @@ void StreamScheduler::Impl::assign_slots() {
     return n_slots++;
   };
   auto give_back = [&](uint32_t slot) {
-    if (banked) free_by_bank[slot % kBanks].push_back(slot);
-    else free_slots.push_back(slot);
+    if (!s.boolean_path) {
+      free_slots.push_back(slot);
+      return;
+    }
+    const uint32_t d = slot / 2;
+    if (--pair_live[d] == 0 && d != open_single) free_pairs[banked ? d % kPairBanks : 0].push_back(d);   // both halves are dead
   };
-  if (banked && free_by_bank.empty()) {
-    free_by_bank.resize(kBanks);
-    next_fresh.resize(kBanks);
-    for (uint32_t b = 0; b < kBanks; ++b) next_fresh[b] = b;
-  }
   // Order the ops of one (level, kind) run [k0, k1) of `order` for the LDS kernel.  Thread t of the workgroup executes
   // ops 2t and 2t + 1 of a 2048-op row, so one LDS instruction of a wave serves the even (or the odd) ops of a
   // 128-op block, in two groups of 32 lanes: positions q and q' of the run conflict when q / 64 == q' / 64, q % 2 == q' % 2
@@ -810,24 +847,30 @@ void StreamScheduler::Impl::assign_slots() {
     for (uint32_t h = expire_head[l]; h != kInf; h = expire_next[h - lo]) give_back(s.slot_of[h]);
     for (uint32_t e = ext_head[l]; e != kInf; e = ext[e].next) give_back(s.slot_of[ext[e].h]);
   };
+  auto row_class = [&](uint8_t k) { return k == TK_AND || k == TK_XOR || k == TK_NOT || k == TK_COPY; };
   for (uint32_t l = 0; l < n_wlevels; ++l) {
     if (!opt.retain_all && l > 0) release_level(l - 1);
     uint64_t run0 = level_start[l];   // start of the current (level, kind) run
     bool wide_run = false;            // long enough for whole groups of 32 lanes
+    // GF(2): a level wide enough for a launch of its own runs as rows of the LDS-resident kernel (lds_program.cpp), two
+    // ops per thread in run order; a narrower one joins a sequential segment (emit_launches)
+    const bool rows_level = s.boolean_path && level_start[l + 1] - level_start[l] >= opt.narrow_width;
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
-      if (banked && (k == level_start[l] || kind[order[k] - lo] != kind[order[k - 1] - lo])) {
+      if (s.boolean_path && (k == level_start[l] || kind[order[k] - lo] != kind[order[k - 1] - lo])) {
         run0 = k;
         uint64_t e = k;
         while (e < level_start[l + 1] && kind[order[e] - lo] == kind[order[k] - lo]) ++e;
         wide_run = e - k >= 2 * kBanks;
-        if (wide_run && kind[order[k] - lo] != TK_ASSERT) {
+        if (banked && wide_run && kind[order[k] - lo] != TK_ASSERT) {
           if (n_inputs(kind[order[k] - lo]) == 2) bank_order_two(k, e);
           else if (n_inputs(kind[order[k] - lo]) == 1) bank_order(k, e);
         }
       }
       const uint32_t i = order[k];
       if (kind[i - lo] == TK_ASSERT || kind[i - lo] == TK_NOP) continue;
-      place(i, (banked && wide_run) ? (uint32_t)(((k - run0) / 2) % kBanks) : kInf);   // lane of the op's thread, modulo the banks
+      // position of the op in its run (the thread that executes it is position / 2), for the ops that run as rows
+      prefer_bank = wide_run;
+      place(i, (rows_level && row_class(kind[i - lo])) ? (uint32_t)(k - run0) : kInf);
       if (!pair_second.empty() && pair_second[i - lo] != kInf) place(pair_second[i - lo]);  // the second value of a pair entry
     }
   }
@@ -1056,6 +1099,24 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     m.state.assign(n, ST_ENTRY);
     m.ra.assign(w.a, w.a + n);
     m.rb.assign(w.b, w.b + n);
+    if (m.field.is_two) {
+      // Arithmetic mod 2 on {0, 1}, lowered here and not when the pool is converted: (a + b) % 2 = xor, (a * b) % 2 = and,
+      // a + c = not / copy and a * c = copy / 0 by the parity of c.  The (level, kind) runs the slots are allocated for
+      // are then the runs the LDS-resident kernel's program is cut into (lds_program.cpp): its threads store their two
+      // results as one aligned pair.
+      for (uint32_t i = 0; i < n; ++i) {
+        uint8_t& k = m.kind[i];
+        const bool odd_const = (k == TK_ADDC || k == TK_MULC) && w.consts && m.rb[i] < w.consts->size() &&
+                               !(*w.consts)[m.rb[i]].empty() && ((*w.consts)[m.rb[i]][0] & 1);
+        if (k == TK_ADD) k = TK_XOR;
+        else if (k == TK_MUL) k = TK_AND;
+        else if (k == TK_ADDC) { k = odd_const ? TK_NOT : TK_COPY; m.rb[i] = 0; }
+        else if (k == TK_MULC) {
+          if (odd_const) { k = TK_COPY; m.rb[i] = 0; }
+          else { k = TK_CONST; m.ra[i] = kSyntheticZero; m.rb[i] = 0; }
+        }
+      }
+    }
     m.rewrite_ladders(w);
     m.propagate_copies();
     lap();
@@ -1107,6 +1168,7 @@ Schedule StreamScheduler::finish(const std::vector<Value>& consts) {
     s.const_words[n_consts + 1] = 1;  // synthetic 1: a constant >= 2 in front of zero tests (track_unreduced_values)
     for (DevOp& d : s.ops)
       if (d.kind == TK_CONST && d.a == kSyntheticOne) d.a = n_consts + 1;
+      else if (d.kind == TK_CONST && d.a == kSyntheticZero) d.a = n_consts;
     // arithmetic mod 2 on {0,1}: (a+b)%2 = xor, (a*b)%2 = and
     for (DevOp& d : s.ops) {
       if (d.kind == TK_ADD) d.kind = TK_XOR;
@@ -1158,6 +1220,7 @@ Schedule schedule_windows(const Tape& tape, const FieldHost& field, const Schedu
     ladder_at = l1;
     w.final = final;
     w.pinned = &opt.pinned;
+    w.consts = &tape.consts;
     sch.add_window(w);
     lo = hi;
   }

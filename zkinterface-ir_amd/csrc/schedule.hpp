@@ -100,6 +100,7 @@ struct TapeWindow {
   size_t n_ladders = 0;
   bool final = false;                     // last window: every value not in `pinned` has seen its last reader
   const std::vector<uint32_t>* pinned = nullptr;
+  const std::vector<Value>* consts = nullptr;   // the tape's constant pool (GF(2): the parity of a constant decides what add_constant / mul_constant become)
 };
 
 struct WindowResult {  // what add_window() appended to the schedule
