@@ -194,3 +194,58 @@ def test_lds_program_refuses_a_field_that_is_not_gf2():
     ev.finalize()
     with pytest.raises(zk.ZkGpuError):
         ev.lds_program()
+
+
+@pytest.mark.parametrize('seed', range(12))
+@pytest.mark.parametrize('variant', ['retain_all', 'bank_unaware', 'arithmetic_gates'])
+def test_lds_program_of_every_schedule_variant(seed, variant):
+    """the row format rests on the scheduler's slot PAIRS (one ds_write_b64 per thread and row): they must also hold for the
+    schedules the GPU tier's dumps and switches use -- retain_all (every value keeps its slot), bank_aware = 0 -- and for
+    relations whose gates are ADD / MUL / ADDC / MULC over GF(2) (lowered to xor / and / not / copy before the runs are
+    formed, so that the runs the slots were paired in are the runs of the program)"""
+    from random_circuits import Gen
+    g = Gen(2000 + seed, 2, variant != 'arithmetic_gates')
+    rel, mod_le = g.relation(n_top=14)
+    lanes = 5
+    rows_i, rows_w = g.lane_inputs(lanes, seed + 99)
+    ev = zk.Evaluator()
+    if variant == 'bank_unaware':
+        ev.set_option('bank_aware', '0')
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    ev.ingest_message(rel)
+    if not ev.n_value_ops:
+        return
+    ev.finalize(retain_all=variant == 'retain_all')
+    inst = np.array(rows_i, dtype=np.uint8).reshape(lanes, -1)
+    wit = np.array(rows_w, dtype=np.uint8).reshape(lanes, -1)
+    _, _, consts, _ = ev.schedule_dump()
+    got = interpret(ev.lds_program([0, 6, 9][seed % 3]), consts, inst, wit)
+    asserts = ev.assert_wires()
+    for lane in range(lanes):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32, trace=False)
+        if ev.host_violations() and not len(asserts):
+            continue
+        failing = [v for v in ref.violations if v.startswith('Wire_')]
+        if not failing:
+            assert int(got[lane]) == NO_FAIL, (seed, lane)
+        else:
+            assert int(got[lane]) != NO_FAIL and failing[0].startswith('Wire_%d ' % asserts[int(got[lane])]), (seed, lane)
+
+
+def test_wide_levels_of_every_schedule_variant_keep_their_pairs():
+    wl = workloads.BoolLayered(W=2500, D=4, n_instance0=64, n_out=16, seed=0x77)      # runs longer than 64 ops, ragged rows
+    batch = 9
+    inst, wit = wl.inputs(batch)
+    outs = cpu_checkers.bool_layered_outputs(wl, inst, wit)
+    inst = inst.copy()
+    wl.set_expected_outputs(inst, outs, corrupt_every=4)
+    want = [0 if lane % 4 == 0 else NO_FAIL for lane in range(batch)]
+    for retain, bank in ((True, '1'), (False, '0'), (False, '1')):
+        ev = zk.Evaluator()
+        ev.set_option('bank_aware', bank)
+        ev.declare_inputs(wl.n_instance, wl.n_witness)
+        for m in wl.relation_messages():
+            ev.ingest_message(m)
+        ev.finalize(retain_all=retain)
+        _, _, consts, _ = ev.schedule_dump()
+        assert interpret(ev.lds_program(), consts, inst[:, :, 0], wit[:, :, 0]).tolist() == want, (retain, bank)

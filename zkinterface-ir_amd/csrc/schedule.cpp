@@ -881,7 +881,9 @@ void StreamScheduler::Impl::assign_slots() {
 void StreamScheduler::Impl::order_levels() {
   // ---- order of the entries inside a level (independent per level: done on `threads` threads) ----
   if (!opt.sort_by_operand) return;
-  if (s.boolean_path && opt.bank_aware && !opt.retain_all) return;   // ordered for the LDS banks while the slots were assigned
+  // GF(2): the order inside a run is final when the slots are assigned -- the two results of a thread (run positions 2t,
+  // 2t + 1) are the halves of one slot pair, and a bank-aware schedule has ordered the run for the LDS banks by then
+  if (s.boolean_path) return;
   parallel_levels(n_wlevels, threads, [&](uint32_t l) {
     // inside a (level, kind) run, order the ops by the slot of their first operand: gates that read
     // the same wire become neighbours (same workgroup), so the repeat read is an L1/L2 hit
