@@ -251,13 +251,26 @@ int zkgpu_n_engines(const zkgpu_session* s);                  /* engines the bat
  * zkgpu_input_modes); the segments replay one after the other on one stream and share the verdict words, assert
  * sequence numbers run through them.  zkgpu_elem_bytes is then the width of the WIDEST field: instance / witness values
  * are handed over in that width whichever segment consumes them (a value that does not fit the limbs of the field that
- * consumes it flags its lane).  Not supported, with an error that says so: a change between GF(2) and another field, a
+ * consumes it flags its lane).  A session that changes between GF(2) and another field keeps its GF(2) wires as
+ * integers too (the any-modulus kernels, zkgpu_field_representation 2): one value per input position in the common
+ * width instead of one byte.  Not supported, with an error that says so: a
  * change on a caller-driven backend (zkgpu_backend_set_field: the library cannot see which wires are alive), several
  * devices, R1CS entry points, zkgpu_replay_timed; option "stream" is switched off at the first change.
  * _info: out = {values carried in, first assert sequence number, 32-bit words per value, values carried out}. */
 int zkgpu_n_field_segments(const zkgpu_session* s);
 int zkgpu_field_segment_info(const zkgpu_session* s, uint32_t k, uint32_t out[4]);
 int zkgpu_field_segment_carried(const zkgpu_session* s, uint32_t k, uint32_t* slots, uint32_t cap);
+/* How field segment k keeps a wire on the device: 0 = one bit per witness (GF(2)), 1 = Montgomery form (an odd
+ * characteristic of at most 512 bits), 2 = the canonical residue (the any-modulus kernels: an even characteristic, one
+ * of up to 4096 bits, GF(2) beside another field; PlaintextBackend takes any BigUint modulus, evaluator.rs:866-938).
+ * -1: no such segment, or its field is not set yet. */
+int zkgpu_field_representation(const zkgpu_session* s, uint32_t k);
+/* Test hook: the modular arithmetic of the any-modulus kernels run on the host (the kernels call the same functions).
+ * op 0: out = a + b mod p, 1: a * b mod p (a, b < p), 2: a mod p (a: any value of *nwords words), 3: a & b, 4: (a ^ b) mod p;
+ * operands and result hold *nwords 32-bit words (little-endian), which the call also reports (a == NULL: only that).
+ * Returns 0, 1 for an unknown op, 2 for a modulus the path does not take (0, 1, more than 4096 bits). */
+int zkgpu_generic_selftest(const uint8_t* modulus_le, size_t modulus_len, int op, const uint32_t* a, const uint32_t* b,
+                           uint32_t* out, uint32_t* nwords);
 uint64_t zkgpu_rccl_reductions(const zkgpu_session* s);       /* zkgpu_counts calls answered by an RCCL all-reduce */
 size_t zkgpu_rccl_note(const zkgpu_session* s, char* buf, size_t cap); /* why RCCL was not used ("" = it was, or was not needed) */
 int zkgpu_lane_results(zkgpu_session* s, uint32_t* first_fail, uint32_t* flags); /* [batch] each */

@@ -9,19 +9,30 @@ OP = {'nop': 0, 'add': 1, 'mul': 2, 'addc': 3, 'mulc': 4, 'copy': 5, 'const': 6,
       'assert': 9, 'and': 10, 'xor': 11, 'not': 12, 'nz': 13, 'carry': 14}
 
 
+def is_canonical_field(p):
+    """the moduli whose wires the device keeps as canonical residues (the any-modulus kernels) unless told otherwise:
+    even ones other than 2 and those wider than 512 bits (csrc/tape.cpp FieldHost::init)"""
+    return (p % 2 == 0 and p != 2) or p.bit_length() > 512
+
+
 def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None, modes=None,
-             carries=()):
+             carries=(), canonical=None):
     """Run one lane.  instances / witnesses: python ints.  Returns (slots, first_fail_seq, noncanonical).
     modes = (instance modes, witness modes) as zkgpu_input_modes gives them (how a value >= p is treated per position:
     0xFF flags the lane; GF(2): 0x01 packs `v != 0`); None = every position 0.
     Within a non-sequential launch the ops are executed in a shuffled order when shuffle_seed is given
     (they must be independent), mimicking the arbitrary order of waves on the GPU."""
     import random
-    boolean = p == 2
-    if not boolean:
+    if canonical is None:
+        canonical = is_canonical_field(p)
+    boolean = p == 2 and not canonical
+    if canonical:   # zkgpu_field_representation 2: no Montgomery factor; a value must still fit the limbs
+        R, rinv, wide = 1, 1, 1 << (32 * words_per_const)
+    elif not boolean:
         nbits = 32 * words_per_const
         R = 1 << nbits
         rinv = pow(R, -1, p)
+        wide = R
     consts = []
     for i in range(len(const_words) // max(words_per_const, 1)):
         v = 0
@@ -114,7 +125,7 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                 stream = {OP['instance']: 0, OP['witness']: 1, OP['carry']: 2}[kind]
                 v = streams[stream][a]
                 mode = mode_of(stream, a)
-                if not boolean and v >= R:      # wider than the limbs of this field: cannot be represented, the lane is flagged
+                if not boolean and v >= wide:      # wider than the limbs of this field: cannot be represented, the lane is flagged
                     noncanon = True
                 if v >= p and mode == 0xFF:     # the unreduced value would reach an integer bit operation / Evaluator::get
                     noncanon = True
@@ -140,7 +151,9 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
     return slots, first_fail, noncanon
 
 
-def from_device_form(v, p, words_per_const):
-    if p == 2 or v is None:
+def from_device_form(v, p, words_per_const, canonical=None):
+    if canonical is None:
+        canonical = is_canonical_field(p)
+    if (p == 2 and not canonical) or v is None or canonical:
         return v
     return v * pow(1 << (32 * words_per_const), -1, p) % p

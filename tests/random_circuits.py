@@ -9,10 +9,11 @@ from zkinterface_ir_amd import sieve_writer as sw
 
 
 class Gen:
-    def __init__(self, seed, p, boolean=False):
+    def __init__(self, seed, p, boolean=False, switches=True):
         self.r = random.Random(seed)
         self.p = p
         self.boolean = boolean
+        self.switches = switches   # False: no Switch gates (each case costs a ladder of bits(p) products)
         self.functions = []  # (name, n_out, n_in, n_inst, n_wit, body)
         self.n_inst = 0      # top-level consumption counters
         self.n_wit = 0
@@ -85,7 +86,7 @@ class Gen:
         if depth == 0 and self.functions and self.r.random() < 0.4:
             g, nid = self.call_gate(live, nid, counters)
             body += g
-        if depth == 0 and self.r.random() < 0.3 and live:
+        if depth == 0 and self.r.random() < 0.3 and live and self.switches:
             g, nid = self.switch_gate(live, nid, counters, depth=1)
             body += g
         for o in range(n_out):  # outputs must be assigned exactly once
@@ -228,7 +229,7 @@ class Gen:
                 g, nid = self.anoncall_gate(live, nid, counters)
             elif k == 'for':
                 g, nid = self.for_gate(live, nid, counters)
-            elif k == 'switch':
+            elif k == 'switch' and self.switches:
                 g, nid = self.switch_gate(live, nid, counters)
             elif k == 'free' and len(live) > 3:
                 w = self.r.choice(live)
@@ -253,7 +254,7 @@ class Gen:
                 if self.boolean and self.p == 2:
                     return r.randrange(2)
                 if self.boolean:  # boolean gateset over an odd field: the gates are integer bit operations
-                    return r.choice(small) if r.random() < 0.3 else r.randrange(self.p)
+                    return r.choice(small) % self.p if r.random() < 0.3 else r.randrange(self.p)
                 return r.choice(small) % self.p if r.random() < 0.6 else r.randrange(self.p)
             rows_i.append([val() for _ in range(self.n_inst)])
             rows_w.append([val() for _ in range(self.n_wit)])

@@ -94,8 +94,9 @@ def test_fields_wider_than_256_bits(p):
             vals = [program_sim.from_device_form(slots[slot_of[i]], p, info['words_per_const'])
                     for i in range(len(kinds)) if kinds[i] != 9]
             assert vals == ref.trace_values()
-    too_wide = circuits.arith_example(2 ** 520 + 1)[2]
-    assert any('wider than 512 bits' in m for m in zk.Evaluator.from_messages([too_wide]).host_violations())
+    # (beyond 512 bits: the any-modulus kernels, tests/test_any_modulus.py)
+    too_wide = circuits.arith_example(2 ** 4100 + 1)[2]
+    assert any('wider than 4096 bits' in m for m in zk.Evaluator.from_messages([too_wide]).host_violations())
 
 
 def test_reader_file_ordering_and_framing(tmp_path):

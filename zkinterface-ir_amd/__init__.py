@@ -111,6 +111,8 @@ def lib():
         'zkgpu_n_field_segments': (ci, [vp]),
         'zkgpu_field_segment_info': (ci, [vp, u32, u32p]),
         'zkgpu_field_segment_carried': (ci, [vp, u32, u32p, u32]),
+        'zkgpu_field_representation': (ci, [vp, u32]),
+        'zkgpu_generic_selftest': (ci, [ctypes.c_char_p, sz, ci, vp, vp, vp, u32p]),
         'zkgpu_rccl_reductions': (u64, [vp]),
         'zkgpu_rccl_note': (sz, [vp, ctypes.c_char_p, sz]),
         'zkgpu_lane_results': (ci, [vp, vp, vp]),
@@ -425,6 +427,10 @@ class Evaluator:
         self._ck(self.L.zkgpu_field_segment_carried(self.h, k, out, n))
         return [int(x) for x in out[:n]]
 
+    def field_representation(self, k=0):
+        """0 = bit-packed GF(2), 1 = Montgomery form, 2 = canonical residues (the any-modulus kernels)"""
+        return int(self.L.zkgpu_field_representation(self.h, k))
+
     def input_modes(self, witness=False):
         """per input position how a value >= p is treated (include/zkgpu.h zkgpu_input_modes): list of 0x00 / 0x01 / 0x02 / 0xFF
         (witness = 2: the values carried into the inspected field segment)"""
@@ -615,6 +621,25 @@ class Evaluator:
     @property
     def table_bytes(self):
         return self.L.zkgpu_table_bytes(self.h)
+
+
+def generic_selftest(p, op, a, b=0):
+    """Test hook (include/zkgpu.h zkgpu_generic_selftest): the any-modulus kernels' arithmetic on the host, Python integers
+    in and out.  op: 'add', 'mul', 'reduce', 'and', 'xor'."""
+    L = lib()
+    mod = int(p).to_bytes((int(p).bit_length() + 7) // 8 or 1, 'little')
+    nw = ctypes.c_uint32(0)
+    rc = L.zkgpu_generic_selftest(mod, len(mod), 0, None, None, None, ctypes.byref(nw))
+    if rc:
+        raise ZkGpuError('zkgpu_generic_selftest: the modulus is not supported (%d)' % rc)
+    n = nw.value
+    A = (ctypes.c_uint32 * n)(*[(int(a) >> (32 * i)) & 0xFFFFFFFF for i in range(n)])
+    B = (ctypes.c_uint32 * n)(*[(int(b) >> (32 * i)) & 0xFFFFFFFF for i in range(n)])
+    out = (ctypes.c_uint32 * n)()
+    rc = L.zkgpu_generic_selftest(mod, len(mod), {'add': 0, 'mul': 1, 'reduce': 2, 'and': 3, 'xor': 4}[op], A, B, out, ctypes.byref(nw))
+    if rc:
+        raise ZkGpuError('zkgpu_generic_selftest failed (%d)' % rc)
+    return sum(int(out[i]) << (32 * i) for i in range(n))
 
 
 def _ingest_any(ev, paths_or_buffers):

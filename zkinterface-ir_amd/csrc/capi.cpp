@@ -496,10 +496,10 @@ void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
   FieldHost next;
   next.init(header.field_characteristic);
   if (header.field_degree != 1) return;   // (set_field reports it, with the reference's text)
-  if (s->backend.field().is_two || next.is_two)
-    throw std::runtime_error("GPU backend: a change of the field characteristic between GF(2) and another field is not supported "
-                             "(bit-packed and Montgomery wires do not mix); the reference would carry the wires over as integers "
-                             "(evaluator.rs:232-237)");
+  // Between GF(2) and another field the reference carries the wires over as the integers they are (evaluator.rs:232-237);
+  // bit-packed wires cannot be: such a session keeps its GF(2) segments as integers too (the any-modulus kernels) --
+  // the one that has been recorded (its tape does not depend on the representation) as well as a new one.
+  const bool from_gf2 = s->backend.field().is_two, to_gf2 = next.is_two;
   if (s->devices.size() > 1) throw std::runtime_error("GPU backend: a field change between Relation messages is not available with several devices (option \"devices\")");
   if (s->r1cs_ready) throw std::runtime_error("GPU backend: a field change between Relation messages is not available for R1CS sessions");
   if (s->stream) {   // a streamed schedule of the old segment: dropped, the segment is scheduled at finalize like the others
@@ -514,6 +514,7 @@ void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
     s->engine.reset();
   }
   s->backend.set_window(0, nullptr, nullptr);
+  if (from_gf2) s->backend.use_generic_field();
   // the wires of the scope live on: detach them from the old backend (no drop record: the old segment keeps them readable) ...
   std::unique_ptr<FieldSegment> seg(new FieldSegment());
   std::vector<WireId> ids;
@@ -528,6 +529,7 @@ void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
   fresh.adopt_streams(s->backend);
   seg->backend = std::move(s->backend);
   s->backend = std::move(fresh);
+  if (to_gf2) s->backend.use_generic_field();
   s->backend.set_assert_base(assert_base);
   s->backend.set_field(header.field_characteristic, header.field_degree, is_boolean);
   // ... and re-bind them, in the same order, to the carry stream of the new one
@@ -931,6 +933,25 @@ int zkgpu_field_segment_info(const zkgpu_session* s, uint32_t k, uint32_t out[4]
   out[2] = seg_backend(s, k).field().is_two ? 0 : seg_backend(s, k).field().nwords;
   out[3] = k < s->prev.size() ? (uint32_t)s->prev[k]->carried_out.size() : 0;
   return 0;
+}
+// how segment k keeps a wire on the device: 0 = one bit (GF(2)), 1 = Montgomery form, 2 = the canonical residue
+int zkgpu_field_representation(const zkgpu_session* s, uint32_t k) {
+  if (!s || k >= n_segments(s) || !seg_backend(s, k).field_set()) return -1;
+  const FieldHost& f = seg_backend(s, k).field();
+  return f.is_two ? 0 : f.generic ? 2 : 1;
+}
+// The arithmetic of the any-modulus kernels, run on the host (the same functions the kernels call): CPU-tier tests.
+int zkgpu_generic_selftest(const uint8_t* modulus_le, size_t modulus_len, int op, const uint32_t* a, const uint32_t* b,
+                           uint32_t* out, uint32_t* nwords) {
+  try {
+    FieldHost f;
+    f.init(Value(modulus_le, modulus_le + modulus_len), true);
+    if (nwords) *nwords = f.nwords;
+    if (!a) return 0;   // (a query for the width)
+    return Engine::generic_selftest(f, op, a, b, out);
+  } catch (const std::exception&) {
+    return 2;
+  }
 }
 // wire-table slots of the values segment k hands to segment k + 1, in carry order (after zkgpu_finalize)
 int zkgpu_field_segment_carried(const zkgpu_session* s, uint32_t k, uint32_t* slots, uint32_t cap) {
@@ -1511,7 +1532,8 @@ int zkgpu_r1cs_from_tape(zkgpu_session* s, int use_correction) {
   return guarded(s, [&] {
     single_segment_only(s, "the R1CS conversion");
     if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
-    if (s->backend.field().is_two) throw std::runtime_error("R1CS conversion on the GPU path needs an odd field characteristic");
+    if (s->backend.field().is_two || s->backend.field().generic)
+      throw std::runtime_error("R1CS conversion on the GPU path needs an odd field characteristic of at most 512 bits");
     const Tape& t = s->backend.tape();
     Value modulus(4 * kFieldWords, 0);
     for (int i = 0; i < 4 * kFieldWords; ++i) modulus[i] = (uint8_t)(s->backend.field().p[i / 4] >> (8 * (i % 4)));
@@ -1565,6 +1587,8 @@ int zkgpu_r1cs_load_csr(zkgpu_session* s, uint32_t n_rows, const uint32_t* row_p
   return guarded(s, [&] {
     single_segment_only(s, "zkgpu_r1cs_load_csr");
     if (!s->finalized || !s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) first: variables are tape values");
+    if (s->backend.field().is_two || s->backend.field().generic)
+      throw std::runtime_error("R1CS rows on the GPU path need an odd field characteristic of at most 512 bits");
     if (s->engine_loaded) throw std::runtime_error("load the CSR before the first zkgpu_set_inputs* call (the table is sized once)");
     if (!row_ptr || (n_coefs && (!coef_bytes || coef_width == 0)))
       throw std::runtime_error("zkgpu_r1cs_load_csr: row_ptr / coefficient bytes missing or coef_width is 0");
@@ -1658,7 +1682,7 @@ int zkgpu_r1cs_correction_values(zkgpu_session* s, const uint64_t* tape_ops, uin
     if (!s->retain_all) throw std::runtime_error("zkgpu_finalize(retain_all=1) is required: the quotients are computed from the wire values");
     const Tape& t = s->backend.tape();
     const FieldHost& f = s->backend.field();
-    if (f.is_two) throw std::runtime_error("quotient wires need an odd field characteristic");
+    if (f.is_two || f.generic) throw std::runtime_error("quotient wires need an odd field characteristic of at most 512 bits");
     const uint32_t one_const = (uint32_t)t.consts.size();   // the literal 1 of `not` = add_constant(a, 1) (to_r1cs.rs:369-371)
     std::vector<uint32_t> calls, const_words((size_t)(t.consts.size() + 1) * f.nwords, 0);
     for (size_t c = 0; c < t.consts.size(); ++c) {

@@ -32,6 +32,16 @@ struct FieldParams {
   u32 lazy_dot3;
 };
 
+// Any-modulus path (generic_kernels.hpp): canonical residues, Barrett reduction.  Lives in device memory (520 words are
+// too many for the kernarg block); filled by Engine::load_program from FieldHost.
+constexpr int kGenericMaxWords = 128;   // characteristics up to 4096 bits
+struct GenericParams {
+  u32 k;                            // 32-bit words of p, the top one non-zero
+  u32 nwords;                       // words per wire value: 2 * ceil(bits / 64), k or k + 1
+  u32 p[kGenericMaxWords];
+  u32 mu[kGenericMaxWords + 2];     // floor(2^(64 k) / p): k + 2 words (the last is 0 unless p is a power of 2^32)
+};
+
 enum OpKind : u32 {
   OP_NOP = 0,
   OP_ADD = 1,       // dst = a + b
@@ -215,6 +225,14 @@ ZKGPU_DECLARE_WIDTH(12)
 ZKGPU_DECLARE_WIDTH(14)
 ZKGPU_DECLARE_WIDTH(16)
 #undef ZKGPU_DECLARE_WIDTH
+
+// any-modulus path (kernels_generic.hip)
+void launch_replay_generic(dim3 grid, hipStream_t st, const ReplayArgs& a, const GenericParams* gp_device, u32 nwords);
+void launch_dump_generic(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump, u32 batch,
+                         u32* out, u32 nwords);
+// the arithmetic of that path run on the HOST (the same functions): op 0 add, 1 mul, 2 reduce(a), 3 and, 4 xor; a, b, out
+// hold gp->nwords words (op 2: a holds gp->nwords raw words).  Returns 0, or 1 for an unknown op.
+int generic_selftest(const GenericParams* gp, int op, const u32* a, const u32* b, u32* out);
 
 void launch_verdict(dim3 grid, hipStream_t st, const u32* first_fail, const u32* lane_flags, u32 batch,
                     unsigned long long* counts);

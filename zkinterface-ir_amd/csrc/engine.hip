@@ -28,6 +28,17 @@ static_assert(sizeof(DevOp2) == sizeof(zkgpu::TapeOp2), "DevOp2 must match the d
 static_assert(sizeof(R1csRowDev) == sizeof(zkgpu::R1csRow) && sizeof(R1csTermDev) == sizeof(zkgpu::R1csTerm),
               "host and device R1CS records must match");
 static_assert(sizeof(zkgpu::FieldParams) <= 256, "FieldParams must fit Engine::field_params_");
+static_assert(kFieldWords == zkgpu::kGenericMaxWords && kMontWords == zkgpu::kMaxWords, "host and device field widths");
+
+static zkgpu::GenericParams generic_params(const FieldHost& f) {
+  zkgpu::GenericParams gp;
+  memset(&gp, 0, sizeof gp);
+  gp.k = f.kwords;
+  gp.nwords = f.nwords;
+  memcpy(gp.p, f.p, sizeof gp.p);
+  memcpy(gp.mu, f.mu, sizeof gp.mu);
+  return gp;
+}
 
 template <typename T>
 void dfree(T*& p) {
@@ -138,6 +149,7 @@ Engine::~Engine() {
   dfree(d_strict_carry_);
   dfree(d_carry_slots_);
   dfree(d_input_aux_);
+  dfree(d_generic_params_);
   dfree(d_r1cs_rows_);
   dfree(d_r1cs_terms_);
   dfree(d_r1cs_coefs_);
@@ -332,6 +344,17 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   }
   memset(field_params_, 0, sizeof field_params_);
   memcpy(field_params_, &fp, sizeof fp);
+  generic_ = f.generic;
+  if (generic_) {
+    // the any-modulus kernels (device/generic_kernels.hpp): canonical residues, p and Barrett's mu in device memory
+    if (s.fused || s.boolean_path) throw std::runtime_error("Engine: the any-modulus kernels replay the unfused program");
+    if (f.nwords > (uint32_t)zkgpu::kGenericMaxWords) throw std::runtime_error("Engine: the field characteristic is wider than the any-modulus kernels");
+    zkgpu::GenericParams gp = generic_params(f);
+    if (!d_generic_params_) HIP_OK(hipMalloc(&d_generic_params_, sizeof gp));
+    HIP_OK(hipMemcpy(d_generic_params_, &gp, sizeof gp, hipMemcpyHostToDevice));
+  } else if (!s.boolean_path && f.nwords > (uint32_t)zkgpu::kMaxWords) {
+    throw std::runtime_error("Engine: the field characteristic is wider than the Montgomery kernels");
+  }
   validate_program(s, n_instance, n_witness, n_carry);
   {
     // program entries window by window; windows a streamed ingest has already sent stay where they are
@@ -648,7 +671,8 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   a.lane_flags = (zkgpu::u32*)verdict_flags();
   a.aux = (const zkgpu::InputAux*)d_input_aux_;
   a.xcd_chunks = xcd_chunks;
-  launch_plain(nwords_, sched_.has_bitops, grid, st, a, fp);
+  if (generic_) zkgpu::launch_replay_generic(grid, st, a, (const zkgpu::GenericParams*)d_generic_params_, nwords_);
+  else launch_plain(nwords_, sched_.has_bitops, grid, st, a, fp);
 }
 
 void Engine::launch_range(uint32_t lb0, uint32_t lbs, bool time_each) {
@@ -821,6 +845,13 @@ void Engine::reserve_extra_slots(uint32_t n) {
   extra_slots_ = n;
 }
 
+int Engine::generic_selftest(const FieldHost& f, int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+  if (!f.generic) return 1;
+  const zkgpu::GenericParams gp = generic_params(f);
+  return zkgpu::generic_selftest(&gp, op, a, b, out);
+}
+
+// (R1CS sessions are refused for fields of the any-modulus path in capi.cpp: the row kernels are Montgomery kernels)
 void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<R1csTermDev>& terms,
                          const std::vector<uint32_t>& coef_words) {
   use_device();
@@ -1036,6 +1067,8 @@ void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>
   // grid.x is limited to 2^31-1, grid.y to 65535: chunk the slot list
   if (boolean_) {
     zkgpu::launch_bool_dump(dim3(k, lb64), st, (const zkgpu::u64*)d_table_, sched_.n_slots, d_slots, k, batch_, (uint8_t*)d_out);
+  } else if (generic_) {
+    zkgpu::launch_dump_generic(dim3(k, lb64), st, (const uint4*)d_table_, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, nwords_);
   } else {
     launch_dump(nwords_, dim3(k, lb64), st, (const uint4*)d_table_, table_slots_, d_slots, k, batch_, (zkgpu::u32*)d_out, fp);
   }
@@ -1090,8 +1123,12 @@ void Engine::carry_out(const std::vector<uint32_t>& slots, Engine* next) {
   }
   zkgpu::FieldParams fp;
   memcpy(&fp, field_params_, sizeof fp);
-  launch_dump(nwords_, dim3((uint32_t)slots.size(), (batch_ + 63) / 64), st, (const uint4*)d_table_, table_slots_,
-              (const uint32_t*)d_carry_slots_, (uint32_t)slots.size(), batch_, (zkgpu::u32*)next->d_carry_, fp);
+  if (generic_)
+    zkgpu::launch_dump_generic(dim3((uint32_t)slots.size(), (batch_ + 63) / 64), st, (const uint4*)d_table_, table_slots_,
+                               (const uint32_t*)d_carry_slots_, (uint32_t)slots.size(), batch_, (zkgpu::u32*)next->d_carry_, nwords_);
+  else
+    launch_dump(nwords_, dim3((uint32_t)slots.size(), (batch_ + 63) / 64), st, (const uint4*)d_table_, table_slots_,
+                (const uint32_t*)d_carry_slots_, (uint32_t)slots.size(), batch_, (zkgpu::u32*)next->d_carry_, fp);
   HIP_OK(hipGetLastError());
 }
 

@@ -39,6 +39,10 @@ class Engine {
   // n_carry values of carry_words 32-bit words each arrive from the previous field segment of the session (TK_CARRY)
   void load_program(const Schedule& s, const FieldHost& f, uint32_t n_instance, uint32_t n_witness, uint32_t n_carry = 0,
                     uint32_t carry_words = 0);
+  // The arithmetic of the any-modulus kernels (device/generic_kernels.hpp) run on the HOST -- the same functions -- for
+  // the CPU-tier tests: op 0 add, 1 mul, 2 reduce(a), 3 and, 4 xor over f.nwords words each.  Returns non-zero if `f`
+  // is not a generic field or the op is unknown.
+  static int generic_selftest(const FieldHost& f, int op, const uint32_t* a, const uint32_t* b, uint32_t* out);
   // Bytes per input value the batch buffers must use: 4*nwords (arithmetic) or 1 (GF(2)).
   uint32_t elem_bytes() const { return elem_bytes_; }
 
@@ -116,6 +120,8 @@ class Engine {
   Schedule sched_;  // host copy (launch list)
   bool loaded_ = false;
   bool boolean_ = false;
+  bool generic_ = false;           // canonical residues, the any-modulus kernels (FieldHost::generic)
+  void* d_generic_params_ = nullptr;   // zkgpu::GenericParams
   uint32_t nwords_ = 0, elem_bytes_ = 0;
   uint32_t n_inst_ = 0, n_wit_ = 0;
   uint32_t batch_ = 0, lane_blocks_ = 0, lanes_per_block_ = 64, lane_group_ = 0;

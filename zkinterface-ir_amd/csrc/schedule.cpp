@@ -243,7 +243,7 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
       continue;
     }
     const int ni = n_inputs(k);
-    const bool bit_op = (k == TK_AND || k == TK_XOR) && !field.is_two;
+    const bool bit_op = (k == TK_AND || k == TK_XOR) && !field.p_is_two();   // (the low bit of a & b, a ^ b only depends on the low bits)
     for (int q = 0; q < ni; ++q) {
       const uint32_t r = src_root[q == 0 ? a : b];
       if (r == kInf) continue;
@@ -292,7 +292,7 @@ void StreamScheduler::Impl::finish_input_modes() {
 // characteristic passes the primality test (sieve/bignum.cpp), the range IS the reference's recursion, and nothing
 // outside the ladder reads or can still read its intermediates.
 void StreamScheduler::Impl::rewrite_ladders(const TapeWindow& w) {
-  if (!w.n_ladders || !opt.fermat || opt.retain_all || field.is_two) return;
+  if (!w.n_ladders || !opt.fermat || opt.retain_all || field.p_is_two()) return;
   if (prime < 0) {
     Value p_le;
     for (uint32_t i = 0; i < field.nwords; ++i)
@@ -441,7 +441,7 @@ void StreamScheduler::Impl::fuse_and_pair() {
   const std::vector<uint32_t>& level = s.level_of;
   const uint32_t n = hi - lo;
   pair_second.clear();
-  if (!(opt.fuse && !opt.retain_all && !s.boolean_path)) return;
+  if (!s.fused) return;   // (opt.fuse, no retain_all, a Montgomery field)
   std::vector<uint32_t> reads(n, 0), reader(n, 0), reader0(n, 0);
   std::vector<uint8_t> has_absorbed(n, 0);
   auto note_read = [&](uint32_t p, uint32_t i) {
@@ -1063,7 +1063,7 @@ StreamScheduler::StreamScheduler(const FieldHost& field, const ScheduleOptions& 
   m.s.retain_all = opt.retain_all;
   m.s.boolean_path = field.is_two;
   // fused entry format whenever fusion may happen: a window cannot know whether a later one will absorb a gate
-  m.s.fused = opt.fuse && !opt.retain_all && !field.is_two;
+  m.s.fused = opt.fuse && !opt.retain_all && !field.is_two && !field.generic;   // (the any-modulus kernel replays unfused entries)
   m.s.window_first_op.push_back(0);
 }
 

@@ -13,14 +13,14 @@ const char* tape_kind_name(uint8_t k) {
 // ---------------------------------------------------------------- FieldHost
 namespace {
 constexpr int W = kFieldWords;
-bool geq8(const uint32_t* a, const uint32_t* b) {
-  for (int i = W - 1; i >= 0; --i)
+bool geq_words(const uint32_t* a, const uint32_t* b, int n) {
+  for (int i = n - 1; i >= 0; --i)
     if (a[i] != b[i]) return a[i] > b[i];
   return true;
 }
-void sub8(uint32_t* a, const uint32_t* b) {
+void sub_words(uint32_t* a, const uint32_t* b, int n) {
   uint64_t borrow = 0;
-  for (int i = 0; i < W; ++i) {
+  for (int i = 0; i < n; ++i) {
     const uint64_t d = (uint64_t)a[i] - b[i] - borrow;
     a[i] = (uint32_t)d;
     borrow = (d >> 63) & 1;
@@ -34,33 +34,53 @@ size_t significant_bytes(const Value& v) {
 }  // namespace
 
 void FieldHost::add(const uint32_t a[W], const uint32_t b[W], uint32_t out[W]) const {
+  // (operands are below p, so only the words in use carry anything; the rest of `out` is cleared)
+  const int n = (int)nwords;
   uint32_t r[W];
   uint64_t c = 0;
-  for (int i = 0; i < W; ++i) {
+  for (int i = 0; i < n; ++i) {
     c += (uint64_t)a[i] + b[i];
     r[i] = (uint32_t)c;
     c >>= 32;
   }
-  if (c || geq8(r, p)) sub8(r, p);
-  memcpy(out, r, sizeof r);
+  if (c || geq_words(r, p, n)) sub_words(r, p, n);
+  memcpy(out, r, 4 * (size_t)n);
+  if (n < W) memset(out + n, 0, 4 * (size_t)(W - n));
 }
 
-void FieldHost::init(const Value& modulus_le) {
+void FieldHost::init(const Value& modulus_le, bool force_generic) {
   *this = FieldHost();
   const size_t n = significant_bytes(modulus_le);
   if (n == 0) throw Error("Modulus cannot be zero.");  // evaluator.rs:868-869
-  if (n > 4 * (size_t)W) throw Error("GPU backend: field characteristic wider than 512 bits is not supported");
+  if (n > 4 * (size_t)W) throw Error("GPU backend: field characteristic wider than 4096 bits is not supported");
   for (size_t i = 0; i < n; ++i) p[i / 4] |= (uint32_t)modulus_le[i] << (8 * (i % 4));
   for (int i = W - 1; i >= 0 && bits == 0; --i)
     if (p[i]) bits = 32 * i + (32 - __builtin_clz(p[i]));
-  if (bits == 2 && p[0] == 2) {
-    is_two = true;
-    nwords = 2;
-    return;
-  }
-  if ((p[0] & 1) == 0) throw Error("GPU backend: even field characteristic other than 2 is not supported");
   if (bits < 2) throw Error("GPU backend: field characteristic 1 is not supported");
   nwords = 2 * ((bits + 63) / 64);
+  if (p_is_two() && !force_generic) {
+    is_two = true;
+    return;
+  }
+  if (force_generic || (p[0] & 1) == 0 || bits > 32 * kMontWords) {
+    // canonical residues, Barrett reduction: mu = floor(b^(2k) / p), b = 2^32, by long division bit by bit
+    generic = true;
+    kwords = (bits + 31) / 32;
+    one[0] = 1;
+    uint32_t rem[W + 1] = {0};
+    const int rw = (int)kwords + 1;
+    uint32_t pw[W + 1] = {0};
+    memcpy(pw, p, 4 * (size_t)kwords);
+    for (int bit = 64 * (int)kwords; bit >= 0; --bit) {
+      for (int i = rw - 1; i > 0; --i) rem[i] = (rem[i] << 1) | (rem[i - 1] >> 31);
+      rem[0] = (rem[0] << 1) | (bit == 64 * (int)kwords ? 1u : 0u);
+      if (geq_words(rem, pw, rw)) {
+        sub_words(rem, pw, rw);
+        mu[bit / 32] |= 1u << (bit % 32);   // (bit / 32 <= kwords + 1: the quotient is at most b^(kwords + 1))
+      }
+    }
+    return;
+  }
   // R = 2^(32*nwords).  one = R mod p by doubling; r2 = R^2 mod p the same way.
   uint32_t x[W] = {1};
   for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
@@ -77,7 +97,7 @@ bool FieldHost::is_canonical(const Value& v) const {
   if (n > 4 * (size_t)W) return false;
   uint32_t w[W] = {0};
   for (size_t i = 0; i < n; ++i) w[i / 4] |= (uint32_t)v[i] << (8 * (i % 4));
-  return !geq8(w, p);
+  return !geq_words(w, p, W);
 }
 
 void FieldHost::reduce(const Value& v, uint32_t out[W]) const {
@@ -94,7 +114,8 @@ void FieldHost::reduce(const Value& v, uint32_t out[W]) const {
 void FieldHost::to_mont(const uint32_t in[W], uint32_t out[W]) const {
   uint32_t x[W];
   memcpy(x, in, sizeof x);
-  for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
+  if (!generic)
+    for (uint32_t i = 0; i < 32 * nwords; ++i) add(x, x, x);
   memcpy(out, x, sizeof x);
 }
 
@@ -102,7 +123,7 @@ void FieldHost::to_mont(const uint32_t in[W], uint32_t out[W]) const {
 void TapeBackend::set_field(const Value& modulus, uint32_t degree, bool is_boolean) {
   // PlaintextBackend::set_field checks (evaluator.rs:866-875), same strings
   FieldHost f;
-  f.init(modulus);
+  f.init(modulus, force_generic_);
   if (degree != 1) throw Error("Field should be of degree 1");
   if (field_set_) {
     // A new modulus opens a new field segment of the session (capi.cpp switch_field), which gives it a backend of its

@@ -26,22 +26,32 @@ const char* tape_kind_name(uint8_t k);  // names of SURVEY.md Appendix A ("copy"
 
 constexpr uint32_t kNoWire = 0xFFFFFFFFu;
 
-constexpr int kFieldWords = 16;  // 32-bit words of the widest supported field (512 bits)
+constexpr int kFieldWords = 128;  // 32-bit words of the widest supported field characteristic (4096 bits)
+constexpr int kMontWords = 16;    // ... of the widest one the Montgomery kernels take (512 bits, device/fp_mont.hpp)
 
-// Host-side description of GF(p), p < 2^512: limbs and Montgomery constants
-// for the device (device/fp_mont.hpp FieldParams), plus canonicalisation of
-// arbitrary-length little-endian Values.
+// Host-side description of the field: limbs and the constants the device needs, plus canonicalisation of
+// arbitrary-length little-endian Values.  Three representations of a wire on the device:
+//   * is_two   -- p == 2, one bit per witness (device/bool_kernels.hpp);
+//   * default  -- odd p < 2^512: Montgomery form (device/fp_mont.hpp FieldParams: r2, one, n0inv);
+//   * generic  -- every other modulus >= 2 up to 4096 bits (even, wider than 512 bits), and any modulus when asked for
+//                 (GF(2) in a session that also works in another field): canonical residues, Barrett reduction with
+//                 `mu` (device/generic_kernels.hpp GenericParams).
 struct FieldHost {
-  uint32_t nwords = 0;          // 32-bit words in use: 2, 4, ..., 16 (64-bit limb granularity)
+  uint32_t nwords = 0;          // 32-bit words per wire value: 2, 4, ... (64-bit limb granularity)
   uint32_t bits = 0;
-  bool is_two = false;          // p == 2: Boolean/bit-packed path, no Montgomery form
+  bool is_two = false;          // p == 2 on the bit-packed path
+  bool generic = false;         // canonical residues + Barrett (the any-modulus kernels)
+  uint32_t kwords = 0;          // generic: 32-bit words of p, the top one non-zero
   uint32_t p[kFieldWords] = {0}, r2[kFieldWords] = {0}, one[kFieldWords] = {0};
+  uint32_t mu[kFieldWords + 2] = {0};   // generic: floor(2^(64 kwords) / p)
   uint32_t n0inv = 0;
 
-  void init(const Value& modulus_le);                         // throws zki::Error if unsupported
+  void init(const Value& modulus_le, bool force_generic = false);   // throws zki::Error if unsupported
+  bool p_is_two() const { return bits == 2 && p[0] == 2; }    // whatever the representation
   bool is_canonical(const Value& v) const;                    // v < p as integers
   void reduce(const Value& v, uint32_t out[kFieldWords]) const;         // v mod p
-  void to_mont(const uint32_t in[kFieldWords], uint32_t out[kFieldWords]) const;  // in * R mod p
+  // the form constants and inputs take in the wire table: in * R mod p (Montgomery), or `in` itself (generic)
+  void to_mont(const uint32_t in[kFieldWords], uint32_t out[kFieldWords]) const;
   void add(const uint32_t a[kFieldWords], const uint32_t b[kFieldWords], uint32_t out[kFieldWords]) const;
 };
 
@@ -207,6 +217,13 @@ class TapeBackend {
     from.lane0_witnesses_.clear();
     max_ops_ = from.max_ops_;
   }
+  // A session that works in GF(2) AND in another field keeps every wire as an integer (the any-modulus kernels), GF(2)
+  // included: bit-packed wires cannot be carried over (capi.cpp switch_field).  The recorded tape does not depend on the
+  // representation, so a backend that has recorded GF(2) gates already can still be told.
+  void use_generic_field() {
+    force_generic_ = true;
+    if (field_set_) field_.init(modulus_, true);
+  }
   void set_assert_base(uint32_t n) { assert_base_ = n; }   // global sequence number of this segment's first assert
   uint32_t assert_base() const { return assert_base_; }
 
@@ -234,7 +251,7 @@ class TapeBackend {
 
   Tape tape_;
   FieldHost field_;
-  bool field_set_ = false, is_boolean_ = false;
+  bool field_set_ = false, is_boolean_ = false, force_generic_ = false;
   Value modulus_;
   std::map<Value, uint32_t> const_index_;
   WireId pending_assert_wire_ = 0;
