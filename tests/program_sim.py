@@ -79,17 +79,30 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                 v1 = slots[x1]
                 assert v1 is not None, 'read of an unwritten slot'
                 return (v0 + v1) % p if e == 1 else v0 * v1 * rinv % p
-            if kind in (OP['add'], OP['mul'], OP['and'], OP['xor']):
+            if kind in (OP['and'], OP['xor']) and not boolean:
+                # integer bit operation, then % p (evaluator.rs:924-933).  An operand is the canonical value of a wire or,
+                # reference 0x80000000 | code, the RAW value of the input it is a copy of (device/args.hpp kOperandIsSource)
+                vals = []
+                for ref in (a, b):
+                    if ref & 0x80000000:
+                        q = (ref & 0x7FFFFFFF) - 2
+                        v = streams[q & 3][q >> 2]
+                        if v >= wide:
+                            noncanon = True
+                        vals.append(v % wide)
+                    else:
+                        reads.add(ref)
+                        assert slots[ref] is not None, 'read of an unwritten slot'
+                        vals.append(slots[ref] * rinv % p)
+                r = ((vals[0] & vals[1]) if kind == OP['and'] else (vals[0] ^ vals[1])) % p * R % p
+            elif kind in (OP['add'], OP['mul'], OP['and'], OP['xor']):
                 x, y = operand(a, a1, ea), operand(b, b1, eb)
                 if kind == OP['add']:
                     r = (x + y) % p
                 elif kind == OP['mul']:
                     r = x * y * rinv % p
-                elif boolean:
+                else:
                     r = x & y if kind == OP['and'] else x ^ y
-                else:  # integer bit operation on the canonical values, then % p (evaluator.rs:924-933)
-                    xi, yi = x * rinv % p, y * rinv % p
-                    r = ((xi & yi) if kind == OP['and'] else (xi ^ yi)) % p * R % p
                 if second:  # pair entry: a second gate of the level shares operand a
                     assert kind in (OP['add'], OP['mul'])
                     reads.add(c0)

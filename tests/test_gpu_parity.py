@@ -172,12 +172,12 @@ def test_switch_weights_in_the_production_schedule(modulus):
     assert np.array_equal(off.lane_results(lanes)[0], ev.lane_results(lanes)[0])
 
 
-def test_unreduced_inputs_get_the_reference_verdict_or_a_refusal():
+def test_unreduced_inputs_get_the_reference_verdict():
     """The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  Where a value >= p first meets an
     arithmetic gate its residue is what the reference computes with too: the kernels reduce it on load and the lane
     gets the oracle's verdict.  Where it reaches assert_zero / not through copies alone it is "not zero", as it is for the
-    reference's integer test: the oracle's verdict again.  Where its BITS matter (and / xor over an odd field) the lane is
-    refused with a text that says so (tests/test_unreduced.py has the cases one by one)."""
+    reference's integer test: the oracle's verdict again.  Where its BITS matter (and / xor over an odd field, Evaluator::get)
+    the entry reads the raw input itself (tests/test_unreduced.py has the cases one by one)."""
     _, _, rel = circuits.arith_example(101)
     ev = zk.Evaluator()
     ev.declare_inputs(3, 4)
@@ -222,23 +222,50 @@ def test_unreduced_inputs_get_the_reference_verdict_or_a_refusal():
         assert ev.get_violations(3) == ['Wire_5 (may be weighted) should be 0, while it is not']     # not(p) = 0
         assert ev.counts() == (n_true, len(rows_w) - n_true) and n_true == 1
         assert not ev.lane_results(len(rows_w))[1].any()                                              # nobody flagged
-    # what stays refused: the bits of an unreduced integer in `and` over an odd field
-    rel3 = sw.write_relation(bytes([101]), 'arithmetic,boolean', 'simple', [],
-                             [('witness', 0), ('constant', 1, bytes([3])), ('and', 2, 0, 1), ('addc', 3, 2, bytes([100])), ('assert_zero', 3),
-                              ('free', 0, 3)])
+    # and / xor over an odd field work on the bits of the unreduced integer (evaluator.rs:924-933): the entry reads the raw
+    # input instead of the wire -- unfused entries (retain_all), fused entries, and the any-modulus kernels (an even p)
+    for p in (101, 2 ** 64 - 2):
+        neg = sw.int_to_le(p - 1)
+        gates = [('witness', 0), ('instance', 1), ('copy', 2, 0), ('copy', 3, 2), ('xor', 4, 3, 1), ('and', 5, 1, 2), ('mul', 6, 0, 0),
+                 ('witness', 7), ('witness', 8), ('witness', 9),
+                 ('mulc', 10, 7, neg), ('add', 11, 4, 10), ('assert_zero', 11),
+                 ('mulc', 12, 8, neg), ('add', 13, 5, 12), ('assert_zero', 13),
+                 ('mulc', 14, 9, neg), ('add', 15, 6, 14), ('assert_zero', 15), ('free', 0, 15)]
+        rel3 = sw.write_relation(sw.int_to_le(p), 'arithmetic,boolean', 'simple', [], gates)
+        top = 2 ** 64 - 1
+        rows = [(7, 9), (p + 3 if p + 3 <= top else top, 2), (200, 255), (p, p), (0, 2 ** 32 - 1), (top, p), (top, top - 1)]
+        rows_i = [[i1] for _, i1 in rows]
+        rows_w = [[w0, (w0 ^ i1) % p, (i1 & w0) % p, (w0 * w0) % p] for w0, i1 in rows]
+        rows_i.append([9])
+        rows_w.append([7, ((7 ^ 9) + 1) % p, 1, 49 % p])      # a wrong xor: Wire_11
+        for retain in (False, True):
+            ev = zk.Evaluator()
+            ev.declare_inputs(1, 4)
+            ev.ingest_message(rel3)
+            ev.finalize(retain_all=retain)
+            assert ev.input_modes(True)[0] == 0x03 and ev.input_modes(False) == [0x03]
+            inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+            ev.set_inputs(inst, wit, len(rows_w))
+            ev.replay()
+            ev.synchronize()
+            for lane in range(len(rows_w)):
+                ref = oracle_lane(sw.int_to_le(p), rows_i[lane], rows_w[lane], [rel3], 8, trace=False)
+                assert ev.get_violations(lane) == ref.violations, (p, retain, lane)
+                assert (ref.violations == []) == (lane != len(rows_w) - 1)
+            assert ev.counts() == (len(rows_w) - 1, 1) and not ev.lane_results(len(rows_w))[1].any()
+    # Evaluator::get of a wire that is a copy of an input returns the integer the witness holds (evaluator.rs:750-752)
+    rel5 = sw.write_relation(bytes([101]), 'arithmetic', 'simple', [], [('witness', 0), ('copy', 1, 0), ('mul', 2, 0, 0)])
     ev = zk.Evaluator()
     ev.declare_inputs(0, 1)
-    ev.ingest_message(rel3)
+    ev.ingest_message(rel5)
     ev.finalize()
-    assert ev.input_modes(True) == [0xFF]
-    _, wit = batch_arrays([[], []], [[5], [106]], ev.elem_bytes)
-    ev.set_inputs(None, wit, 2)
+    _, wit = batch_arrays([[]] * 3, [[5], [106], [2 ** 32 - 1]], ev.elem_bytes)
+    ev.set_inputs(None, wit, 3)
     ev.replay()
     ev.synchronize()
-    assert ev.get_violations(0) == []                                    # 5 & 3 = 1
-    v = ev.get_violations(1)                                             # the reference: 106 & 3 = 2 -> Wire_3 fails
-    assert len(v) == 1 and 'not canonical' in v[0] and 'evaluator.rs:896-946' in v[0]
-    assert ev.counts() == (1, 1)
+    assert ev.get(0, 3) == [5, 106, 2 ** 32 - 1] and ev.get(1, 3) == [5, 106, 2 ** 32 - 1]
+    assert ev.get(2, 3) == [25, 25, ((2 ** 32 - 1) ** 2) % 101]
+    assert ev.counts() == (3, 0)
     # GF(2): a position only zero tests read is packed as `v != 0` (both kernels)
     rel4 = sw.write_relation(bytes([2]), 'boolean', 'simple', [],
                              [('witness', 0), ('not', 1, 0), ('assert_zero', 1), ('witness', 2), ('copy', 3, 2), ('assert_zero', 3)]

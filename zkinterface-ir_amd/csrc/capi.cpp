@@ -186,8 +186,8 @@ void need_value_index(zkgpu_session* s) {
   auto build = [](const Tape& t, std::vector<uint32_t>& idx) {
     if (!idx.empty() || !t.size()) return;
     idx.reserve(t.n_value_ops);
-    for (size_t i = 0; i < t.size(); ++i)
-      if (t.kind[i] != TK_ASSERT && t.kind[i] != TK_CARRY) idx.push_back((uint32_t)i);   // (a carried value is no backend call)
+    for (size_t i = t.n_rebound; i < t.size(); ++i)   // (the wires re-bound at a field change are no backend calls)
+      if (t.kind[i] != TK_ASSERT && t.kind[i] != TK_CARRY) idx.push_back((uint32_t)i);
   };
   build(s->backend.tape(), s->value_op_index);
   for (auto& seg : s->prev) build(seg->backend.tape(), seg->value_op_index);
@@ -515,15 +515,35 @@ void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
   }
   s->backend.set_window(0, nullptr, nullptr);
   if (from_gf2) s->backend.use_generic_field();
-  // the wires of the scope live on: detach them from the old backend (no drop record: the old segment keeps them readable) ...
+  // The wires of the scope live on as the integers they hold (evaluator.rs:232-237).  What a wire holds is known from the
+  // old tape: behind copies alone it is still the instance / witness value or the constant it started as -- possibly
+  // >= the old characteristic, since PlaintextBackend never reduces those (evaluator.rs:862-864,896-898,940-946) -- and
+  // the new segment reads that input or constant itself, under its own field; anything a gate has produced is a
+  // canonical value of the old field and travels through the carry stream.  Detach the wires from the old backend (no
+  // drop record: the old segment keeps them readable) ...
   std::unique_ptr<FieldSegment> seg(new FieldSegment());
+  struct Origin {
+    uint8_t kind;      // TK_INSTANCE / TK_WITNESS: position `at`; TK_CONST: constant `at` of the old tape; TK_CARRY: carried
+    uint32_t at;
+  };
   std::vector<WireId> ids;
-  s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
-    ids.push_back(id);
-    seg->carried_out.push_back(w.h);
-    w.h = kNoWire;
-    w.owner = nullptr;
-  });
+  std::vector<Origin> origin;
+  {
+    const Tape& old = s->backend.tape();
+    s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
+      uint32_t h = w.h;
+      while (old.kind[h] == TK_COPY) h = old.a[h];
+      ids.push_back(id);
+      if (old.kind[h] == TK_INSTANCE || old.kind[h] == TK_WITNESS || old.kind[h] == TK_CONST) {
+        origin.push_back(Origin{old.kind[h], old.a[h]});
+      } else {
+        origin.push_back(Origin{TK_CARRY, (uint32_t)seg->carried_out.size()});
+        seg->carried_out.push_back(w.h);
+      }
+      w.h = kNoWire;
+      w.owner = nullptr;
+    });
+  }
   const uint32_t assert_base = s->backend.assert_base() + (uint32_t)s->backend.tape().assert_op.size();
   TapeBackend fresh;
   fresh.adopt_streams(s->backend);
@@ -532,13 +552,19 @@ void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
   if (to_gf2) s->backend.use_generic_field();
   s->backend.set_assert_base(assert_base);
   s->backend.set_field(header.field_characteristic, header.field_degree, is_boolean);
-  // ... and re-bind them, in the same order, to the carry stream of the new one
+  // ... and re-bind them, in the same order
   size_t k = 0;
   s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
     if (k >= ids.size() || ids[k] != id) throw std::runtime_error("GPU backend: the scope changed while a field segment was opened");
-    w = TapeWire(s->backend.h_carry((uint32_t)k), &s->backend);
+    const Origin& o = origin[k];
+    uint32_t h;
+    if (o.kind == TK_CARRY) h = s->backend.h_carry(o.at);
+    else if (o.kind == TK_CONST) h = s->backend.h_constant(TapeBackend::literal_bytes(seg->backend.tape().consts[o.at]));
+    else h = s->backend.h_input_at(o.kind, o.at);
+    w = TapeWire(h, &s->backend);
     ++k;
   });
+  s->backend.end_rebinding();
   s->value_op_index.clear();
   s->prev.push_back(std::move(seg));
 }
@@ -1004,6 +1030,7 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     for (auto& seg : s->prev) {
       ScheduleOptions o = schedule_options(s, retain_all != 0);
       o.pinned = seg->carried_out;
+      o.pinned_are_carried = true;
       seg->sched = build_schedule(seg->backend.tape(), seg->backend.field(), o);
       seg->engine.reset();
     }
@@ -1181,6 +1208,9 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
         put_value(vals[k], &buf[k * w], w, f, &big);
         const uint8_t mode = k < modes.size() ? modes[k] : 0;
         if (big && (mode == 0xFF || mode == 0x01)) memset(&buf[k * w], 0xff, w);
+        if (big && mode == 0x03)
+          throw std::runtime_error("GPU backend: input value " + std::to_string(k) + " is wider than the field's limbs and its bits are "
+                                   "read as they are (and / xor over this field, Evaluator::get: evaluator.rs:750-752,924-933)");
         if (big && mode == 0x02)
           throw std::runtime_error("GPU backend: input value " + std::to_string(k) + " is wider than the field's limbs and is read both by "
                                    "arithmetic gates (which need its residue) and, through copies, by assert_zero / not (which "
@@ -1515,15 +1545,34 @@ int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out) {
   if (!w) return 3;  // "No value given for wire_{id}"
   return guarded(s, [&] {
     need_engine(s);
-    std::vector<uint32_t> slots(1, s->sched.slot_of[w->h]);
     std::vector<uint8_t> tmp;
-    dump_slots_all(s, slots, &tmp);
-    const uint32_t we = session_elem_bytes(s), ws = s->engine->elem_bytes();
+    uint32_t ws = s->engine->elem_bytes();
+    const auto& raw = s->sched.raw_source;
+    const auto it = std::lower_bound(raw.begin(), raw.end(), std::make_pair(w->h, 0u));
+    if (it != raw.end() && it->first == w->h) {
+      // the wire is an input the relation has only copied: Evaluator::get returns the integer the witness holds, reduced
+      // or not (evaluator.rs:750-752, 940-946) -- read it where the caller put it
+      const uint32_t q = it->second - 2;
+      if (s->peers.empty()) {
+        s->engine->read_input(q & 3, q >> 2, &tmp, &ws);
+      } else {
+        std::vector<Engine*> eng = all_engines(s);
+        for (size_t k : active_engines(s)) {   // shares are contiguous and in lane order
+          std::vector<uint8_t> part;
+          eng[k]->read_input(q & 3, q >> 2, &part, &ws);
+          tmp.insert(tmp.end(), part.begin(), part.end());
+        }
+      }
+    } else {
+      std::vector<uint32_t> slots(1, s->sched.slot_of[w->h]);
+      dump_slots_all(s, slots, &tmp);
+    }
+    const uint32_t we = session_elem_bytes(s);
     if (we == ws) {
       if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
     } else {   // field segments: the caller's element width is that of the widest field
       memset(out, 0, (size_t)s->batch * we);
-      for (uint32_t lane = 0; lane < s->batch; ++lane) memcpy(out + (size_t)lane * we, tmp.data() + (size_t)lane * ws, ws);
+      for (uint32_t lane = 0; lane < s->batch; ++lane) memcpy(out + (size_t)lane * we, tmp.data() + (size_t)lane * ws, std::min(ws, we));
     }
   });
 }

@@ -73,6 +73,9 @@ struct TapeOp2 {
 };
 
 constexpr u32 kNoFail = 0xFFFFFFFFu;
+// an operand of `and` / `xor` over a field other than GF(2) that names the RAW value of an input instead of a wire-table
+// slot: kOperandIsSource | (2 + 4 * position + stream), the code of the assert_zero / not sinks (schedule.cpp)
+constexpr u32 kOperandIsSource = 0x80000000u;
 constexpr u32 kLaneFlagNonCanonical = 1u;
 
 // What only the input arms of the replay kernels read (instance / witness / carried values and their modes): kept behind

@@ -48,25 +48,6 @@ __device__ __forceinline__ bool fp_geq_p(const Fp<N>& a, const FieldParams& fp);
 template <int N>
 __device__ __forceinline__ Fp<N> fp_cond_sub(const u32* t, u64 force, const FieldParams& fp, u64* borrow_out, const u32* pv = nullptr);
 
-// `and` / `xor` of PlaintextBackend over an odd field (evaluator.rs:924-933): the bit operation on the canonical
-// integers, then `% p`.  a & b <= min(a, b) < p needs no reduction; a ^ b < 2^bits(p) < 2p needs one subtraction.
-template <int N>
-__device__ __forceinline__ Fp<N> fp_bit_and(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
-  const Fp<N> x = fp_from_mont<N>(a, fp), y = fp_from_mont<N>(b, fp);
-  Fp<N> r;
-#pragma unroll
-  for (int i = 0; i < N; ++i) r.w[i] = x.w[i] & y.w[i];
-  return fp_to_mont<N>(r, fp);
-}
-template <int N>
-__device__ __forceinline__ Fp<N> fp_bit_xor(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp) {
-  const Fp<N> x = fp_from_mont<N>(a, fp), y = fp_from_mont<N>(b, fp);
-  Fp<N> r;
-#pragma unroll
-  for (int i = 0; i < N; ++i) r.w[i] = x.w[i] ^ y.w[i];
-  r = fp_cond_sub<N>(r.w, 0ull, fp, nullptr);   // a ^ b < 2^bits(p) < 2p
-  return fp_to_mont<N>(r, fp);
-}
 // 1 (Montgomery form) or 0: `not` of PlaintextBackend (evaluator.rs:935-938) is fp_indicator(the integer is zero)
 template <int N>
 __device__ __forceinline__ Fp<N> fp_indicator(bool set, const FieldParams& fp) {

@@ -231,15 +231,25 @@ __global__ __launch_bounds__(256) void replay_generic_kernel(const ReplayArgs ar
     switch (op.kind) {
       case OP_ADD:
       case OP_MUL:
-      case OP_AND:
-      case OP_XOR:
         g_wire_load(T + (size_t)op.a * rec, n, a);
         g_wire_load(T + (size_t)op.b * rec, n, b);
         if (op.kind == OP_ADD) g_add<CAP>(a, b, r, gp);
-        else if (op.kind == OP_MUL) g_mul<CAP>(a, b, r, gp);
-        else if (op.kind == OP_AND) g_and(a, b, r, gp);
-        else g_xor(a, b, r, gp);
+        else g_mul<CAP>(a, b, r, gp);
         break;
+      case OP_AND:
+      case OP_XOR: {
+        // an operand may name the RAW value of an input the relation has only copied (args.hpp kOperandIsSource):
+        // PlaintextBackend works on those bits (evaluator.rs:924-933); the result is reduced like any raw value
+        bool wide = false;
+        if (op.a & kOperandIsSource) wide |= g_stream_load(((op.a & ~kOperandIsSource) - 2) & 3, ((op.a & ~kOperandIsSource) - 2) >> 2, args, lane_g, lane_valid, n, a);
+        else g_wire_load(T + (size_t)op.a * rec, n, a);
+        if (op.b & kOperandIsSource) wide |= g_stream_load(((op.b & ~kOperandIsSource) - 2) & 3, ((op.b & ~kOperandIsSource) - 2) >> 2, args, lane_g, lane_valid, n, b);
+        else g_wire_load(T + (size_t)op.b * rec, n, b);
+        if (lane_valid && wide) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+        for (u32 w = 0; w < n; ++w) a[w] = op.kind == OP_AND ? (a[w] & b[w]) : (a[w] ^ b[w]);
+        g_reduce<CAP>(a, r, gp);
+        break;
+      }
       case OP_ADDC:
       case OP_MULC:
         g_wire_load(T + (size_t)op.a * rec, n, a);

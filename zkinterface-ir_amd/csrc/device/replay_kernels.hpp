@@ -160,6 +160,32 @@ __device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& ar
   return fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
 }
 
+// An operand of an integer bit operation (`and` / `xor` over an odd field, evaluator.rs:924-933): the canonical integer of
+// a wire -- or, where the wire is an input the relation has only copied, the RAW value of that input (reference
+// kOperandIsSource | code, the code of unreduced_source_is_nonzero): PlaintextBackend keeps inputs unreduced and the bit
+// operations work on those bits.  A raw value that does not fit the limbs flags the lane.
+template <int N, class Args>
+__device__ __forceinline__ Fp<N> bit_operand(u32 ref, const uint4* __restrict__ T, const Args& args, u32 lane_g, bool lane_valid,
+                                             const FieldParams& fp) {
+  if (ref & kOperandIsSource) {
+    const u32 q = (ref & ~kOperandIsSource) - 2;
+    bool too_wide;
+    const Fp<N> raw = stream_load<N>(q & 3, q >> 2, args, lane_g, lane_valid, too_wide);
+    if (lane_valid && too_wide) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+    return raw;
+  }
+  return fp_from_mont<N>(wire_load<N>(T + (size_t)ref * Layout<N>::kRecord), fp);
+}
+template <int N, class Args>
+__device__ __forceinline__ Fp<N> bit_operation(u32 kind, u32 ref_a, u32 ref_b, const uint4* __restrict__ T, const Args& args, u32 lane_g,
+                                               bool lane_valid, const FieldParams& fp) {
+  const Fp<N> x = bit_operand<N>(ref_a, T, args, lane_g, lane_valid, fp), y = bit_operand<N>(ref_b, T, args, lane_g, lane_valid, fp);
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = kind == OP_AND ? (x.w[i] & y.w[i]) : (x.w[i] ^ y.w[i]);
+  return fp_to_mont<N>(r, fp);   // of any value below R: the Montgomery form of its residue
+}
+
 // One wave = 64 witnesses x `ops_per_wave` consecutive tape ops.
 // PIPE: operands of op i+1 are requested before op i is computed; legal only
 // when the ops of one wave are mutually independent (a level of the schedule).
@@ -182,8 +208,9 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
   uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
   constexpr int REC = Layout<N>::kRecord;
 
-  auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_CARRY && k != OP_NOP; };  // OP_NZ reads a
-  auto needs_b = [](u32 k) { return k == OP_ADD || k == OP_MUL || k == OP_AND || k == OP_XOR; };
+  // (and / xor fetch their own operands: they may name an input instead of a wire, bit_operand)
+  auto needs_a = [](u32 k) { return k != OP_CONST && k != OP_INSTANCE && k != OP_WITNESS && k != OP_CARRY && k != OP_NOP && k != OP_AND && k != OP_XOR; };  // OP_NZ reads a
+  auto needs_b = [](u32 k) { return k == OP_ADD || k == OP_MUL; };
 
   TapeOp op = load_op_scalar(args.ops, begin);
   Fp<N> a, b;
@@ -209,10 +236,8 @@ __global__ __launch_bounds__(256) void replay_kernel(const ReplayArgs args, cons
       case OP_COPY: r = a; break;
       case OP_NZ: r = fp_nonzero_indicator<N>(a, fp); break;
       case OP_AND:   // integer bit ops of PlaintextBackend over an odd field
-        if constexpr (BITOPS) r = fp_bit_and<N>(a, b, fp); else has_out = false;
-        break;
       case OP_XOR:
-        if constexpr (BITOPS) r = fp_bit_xor<N>(a, b, fp); else has_out = false;
+        if constexpr (BITOPS) r = bit_operation<N>(op.kind, op.a, op.b, T, args, lane_g, lane_valid, fp); else has_out = false;
         break;
       case OP_NOT:   // op.b: the unreduced source behind the operand, if any
         r = fp_indicator<N>(fp_is_zero<N>(a) && !unreduced_source_is_nonzero<N>(op.b, args, lane_g, lane_valid, fp), fp);
@@ -321,11 +346,8 @@ __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict
     case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
     case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
     case OP_AND:
-      if constexpr (CLS == kFusedAll) r = fp_bit_and<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
-      else has_out = false;
-      break;
     case OP_XOR:
-      if constexpr (CLS == kFusedAll) r = fp_bit_xor<N>(wire_load<N>(T + (size_t)op.a0 * REC), wire_load<N>(T + (size_t)op.b0 * REC), fp);
+      if constexpr (CLS == kFusedAll) r = bit_operation<N>(kind, op.a0, op.b0, T, args, lane_g, lane_valid, fp);
       else has_out = false;
       break;
     case OP_NOT:   // op.a1: the unreduced source behind the operand, if any

@@ -215,7 +215,20 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
   auto check = [&](size_t i, uint32_t kind, uint32_t dst, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t ea,
                    uint32_t eb, uint32_t second, uint32_t dst2, uint32_t c0, uint32_t src) {
     switch (kind) {
-      case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR:
+      case TK_AND: case TK_XOR:
+        // over a field other than GF(2) an operand may name an input instead of a slot (device/args.hpp kOperandIsSource)
+        slot(i, dst);
+        for (uint32_t ref : {a0, b0}) {
+          if (!s.boolean_path && (ref & zkgpu::kOperandIsSource)) {
+            if ((ref & ~zkgpu::kOperandIsSource) < 2) fail(i, "the input behind an operand");
+            source(i, ref & ~zkgpu::kOperandIsSource);
+          } else {
+            slot(i, ref);
+          }
+        }
+        if (ea || eb || second) fail(i, "its kind word");
+        break;
+      case TK_ADD: case TK_MUL:
         slot(i, dst); slot(i, a0); slot(i, b0);
         if (ea) slot(i, a1);
         if (eb) slot(i, b1);
@@ -1049,6 +1062,20 @@ void Engine::download(std::vector<uint32_t>* first_fail, std::vector<uint32_t>* 
   if (counts) HIP_OK(hipMemcpy(counts, verdict_counts(), 16, hipMemcpyDeviceToHost));
 }
 
+void Engine::read_input(uint32_t stream, uint32_t position, std::vector<uint8_t>* out, uint32_t* width) {
+  use_device();
+  if (!batch_) throw std::runtime_error("Engine: no batch");
+  const uint32_t n_vals = stream == 0 ? n_inst_ : stream == 1 ? n_wit_ : n_carry_;
+  const uint32_t w = stream == 2 ? 4 * carry_words_ : in_stride_;
+  const uint8_t* base = (const uint8_t*)(stream == 0 ? d_inst_ : stream == 1 ? d_wit_ : d_carry_);
+  if (stream > 2 || position >= n_vals || !base) throw std::runtime_error("Engine: no such input value");
+  synchronize();
+  if (copy_stream_) HIP_OK(hipStreamSynchronize((hipStream_t)copy_stream_));   // (an upload still in flight)
+  out->assign((size_t)batch_ * w, 0);
+  HIP_OK(hipMemcpy2D(out->data(), w, base + (size_t)position * w, (size_t)n_vals * w, w, batch_, hipMemcpyDeviceToHost));
+  *width = w;
+}
+
 void Engine::dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out) {
   use_device();
   synchronize();
@@ -1111,9 +1138,11 @@ void Engine::set_input_stride(uint32_t bytes) {
 void Engine::carry_out(const std::vector<uint32_t>& slots, Engine* next) {
   use_device();
   if (boolean_ || next->boolean_) throw std::runtime_error("Engine: values carried between field segments need arithmetic fields");
-  if (next->n_carry_ != slots.size() || next->carry_words_ != nwords_ || next->batch_ != batch_ || !next->d_carry_)
+  if (next->n_carry_ != slots.size() || next->batch_ != batch_)
     throw std::runtime_error("Engine: the next segment does not expect these carried values");
-  if (slots.empty()) return;
+  if (slots.empty()) return;   // (everything that crossed the field change was an input or a constant: capi.cpp switch_field)
+  if (next->carry_words_ != nwords_ || !next->d_carry_)
+    throw std::runtime_error("Engine: the next segment does not expect these carried values");
   for (uint32_t sl : slots)
     if (sl >= table_slots_) throw std::runtime_error("Engine: a carried value names a wire-table slot out of range");
   hipStream_t st = (hipStream_t)stream_;

@@ -76,6 +76,9 @@ class Engine {
   void* stream() const { return stream_; }
   // out[lane][k][elem_bytes]: canonical value of slot slots[k] for every lane
   void dump_slots(const std::vector<uint32_t>& slots, std::vector<uint8_t>* out);
+  // out[lane][*width bytes]: the RAW value every lane handed over at `position` of input stream 0 (instance), 1 (witness)
+  // or 2 (carried in from the previous field segment): what Evaluator::get returns for a wire that is a copy of an input
+  void read_input(uint32_t stream, uint32_t position, std::vector<uint8_t>* out, uint32_t* width);
 
   // ---- R1CS rows over the same wire table (arithmetic fields) ----------------------------------
   // extra table slots behind the program's own (variables assigned by r1cs_run(assign=true)); call

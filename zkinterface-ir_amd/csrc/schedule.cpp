@@ -24,6 +24,7 @@ inline int n_inputs(uint8_t k) {
 }
 
 constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr uint32_t kOperandIsSource = 0x80000000u;   // device/args.hpp: an and / xor operand that names an input, not a slot
 constexpr uint32_t kSyntheticOne = 0xFFFFFFFEu;   // GF(2) CONST entry: the pool's synthetic 1 (resolved in finish())
 constexpr uint32_t kSyntheticZero = 0xFFFFFFFDu;  // ... and its synthetic 0 (mul_constant by an even constant)
 
@@ -161,6 +162,8 @@ struct StreamScheduler::Impl {
   std::vector<uint8_t> src_kind;         // per handle: TK_CONST / TK_INSTANCE / TK_WITNESS for sources, 0 otherwise
   std::vector<uint32_t> src_pos;         // per source handle: input position, or 1 for a constant >= p (0: canonical)
   std::vector<uint8_t> src_zero_test, src_other;   // per source handle: read by assert_zero / not through copies; by anything else
+  std::vector<uint8_t> src_bits;         // per source handle: its raw bits are an operand of and / xor (through copies)
+  std::vector<uint32_t> opnd_code[2];    // window: per and / xor op and operand, the input it is a copy of (sink_code's codes), or 0
   std::vector<uint32_t> sink_code;       // window: per op, for assert_zero / not reached from a source through copies alone:
                                          // 1 = the source is a constant >= p, 2 + 2 * position + is_witness = an input
   void grow(uint32_t n);
@@ -193,6 +196,7 @@ void StreamScheduler::Impl::grow(uint32_t n) {
   src_pos.resize(n, 0);
   src_zero_test.resize(n, 0);
   src_other.resize(n, 0);
+  src_bits.resize(n, 0);
 }
 
 // PlaintextBackend keeps constants, instance and witness values UNREDUCED (evaluator.rs:862-864,896-898,940-946):
@@ -229,6 +233,11 @@ void StreamScheduler::Impl::refuse_unreduced(uint32_t r, const char* consumer) {
 void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
   const uint32_t n = hi - lo;
   sink_code.assign(n, 0);
+  opnd_code[0].assign(n, 0);
+  opnd_code[1].assign(n, 0);
+  auto code_of = [&](uint32_t r) {
+    return 2u + 4u * src_pos[r] + (src_kind[r] == TK_INSTANCE ? 0u : src_kind[r] == TK_WITNESS ? 1u : 2u);
+  };
   for (uint32_t i = lo; i < hi; ++i) {
     const uint8_t k = w.kind[i - lo];
     const uint32_t a = w.a[i - lo], b = w.b[i - lo];
@@ -249,27 +258,42 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
       if (r == kInf) continue;
       if (k == TK_ASSERT || k == TK_NOT) {
         src_zero_test[r] = 1;
-        sink_code[i - lo] = src_kind[r] == TK_CONST ? (src_pos[r] ? 1u : 0u)
-                                                    : 2u + 4u * src_pos[r] + (src_kind[r] == TK_INSTANCE ? 0u : src_kind[r] == TK_WITNESS ? 1u : 2u);
+        sink_code[i - lo] = src_kind[r] == TK_CONST ? (src_pos[r] ? 1u : 0u) : code_of(r);
+      } else if (bit_op && src_kind[r] != TK_CONST) {
+        // the entry reads the raw input instead of the wire (device/replay_kernels.hpp bit_operand)
+        src_bits[r] = 1;
+        opnd_code[q][i - lo] = code_of(r);
       } else {
         src_other[r] = 1;
         if (bit_op) refuse_unreduced(r, "and / xor");
       }
     }
   }
-  if (final && w.pinned)   // wires alive at the end can be asked for with Evaluator::get, which returns the integer as it is
-    for (uint32_t h : *w.pinned)
-      if (h < hi && src_root[h] != kInf) {
-        src_other[src_root[h]] = 1;
-        refuse_unreduced(src_root[h], "Evaluator::get (a wire alive at the end)");
+  if (final && w.pinned)
+    for (uint32_t h : *w.pinned) {
+      if (h >= hi || src_root[h] == kInf) continue;
+      const uint32_t r = src_root[h];
+      if (opt.pinned_are_carried || src_kind[r] == TK_CONST) {
+        // The next field segment takes the value from the wire table, which holds the residue (capi.cpp switch_field
+        // re-reads inputs and constants under the new field itself: what is left here is a value carried in and only
+        // copied); a constant alive at the end: Evaluator::get would return the integer as it is.
+        src_other[r] = 1;
+        refuse_unreduced(r, opt.pinned_are_carried ? "the next field segment (carried over twice without passing through a gate)"
+                                                   : "Evaluator::get (a wire alive at the end)");
+      } else {
+        // Evaluator::get returns the integer as it is (evaluator.rs:750-752): zkgpu_get_wire reads the input itself
+        src_bits[r] = 1;
+        s.raw_source.emplace_back(h, code_of(r));
       }
+    }
+  if (final) std::sort(s.raw_source.begin(), s.raw_source.end());
 }
 
 // after the last window: the input modes of the positions no refusal has claimed, and -- GF(2) -- the sources one bit
 // cannot serve
 void StreamScheduler::Impl::finish_input_modes() {
   for (uint32_t h = 0; h < (uint32_t)src_kind.size(); ++h) {
-    if (!src_kind[h] || !src_zero_test[h]) continue;
+    if (!src_kind[h] || !(src_zero_test[h] || src_bits[h])) continue;
     if (src_kind[h] == TK_CONST) {
       if (src_pos[h] && field.is_two && src_other[h])
         refuse_unreduced(h, "assert_zero / not and, as its low bit, a gate");
@@ -280,8 +304,9 @@ void StreamScheduler::Impl::finish_input_modes() {
     uint8_t& mode = pos[src_pos[h]];
     if (mode == 0xFF) continue;
     // 0x01: zero tests only.  0x02 (GF(p)): zero tests and arithmetic -- the kernels treat it like 0 (the sinks test the
-    // raw input themselves); the one caller that cares is zkgpu_set_inputs_from_messages with a value wider than the limbs
-    mode = !src_other[h] ? 0x01 : (field.is_two ? 0xFF : 0x02);
+    // raw input themselves); the one caller that cares is zkgpu_set_inputs_from_messages with a value wider than the limbs.
+    // 0x03: and / xor read its bits (the kernels again read the raw input; a value wider than the limbs flags the lane).
+    mode = src_bits[h] ? 0x03 : !src_other[h] ? 0x01 : (field.is_two ? 0xFF : 0x02);
   }
 }
 
@@ -953,9 +978,9 @@ void StreamScheduler::Impl::emit_entries() {
             operand(y, &d.b0, &d.b1, 10);
           }
           break;
-        case TK_AND: case TK_XOR:
-          d.a0 = s.slot_of[x];
-          d.b0 = s.slot_of[y];
+        case TK_AND: case TK_XOR:   // (an operand that is a copy of an input: the input itself, bit_operand)
+          d.a0 = opnd_code[0][i - lo] ? (kOperandIsSource | opnd_code[0][i - lo]) : s.slot_of[x];
+          d.b0 = opnd_code[1][i - lo] ? (kOperandIsSource | opnd_code[1][i - lo]) : s.slot_of[y];
           break;
         case TK_ADDC: case TK_MULC:
           d.a0 = s.slot_of[x];
@@ -985,9 +1010,13 @@ void StreamScheduler::Impl::emit_entries() {
     d.dst = s.slot_of[i] == kNoWire ? 0 : s.slot_of[i];
     const uint32_t x = ra[i - lo], y = rb[i - lo];
     switch (kd) {
-      case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR:
+      case TK_ADD: case TK_MUL:
         d.a = s.slot_of[x];
         d.b = s.slot_of[y];
+        break;
+      case TK_AND: case TK_XOR:   // (an operand that is a copy of an input: the input itself, bit_operand)
+        d.a = opnd_code[0][i - lo] ? (kOperandIsSource | opnd_code[0][i - lo]) : s.slot_of[x];
+        d.b = opnd_code[1][i - lo] ? (kOperandIsSource | opnd_code[1][i - lo]) : s.slot_of[y];
         break;
       case TK_ADDC: case TK_MULC:
         d.a = s.slot_of[x];

@@ -13,6 +13,7 @@
 // (tape.hpp).  build_schedule() is the one-window case (the whole tape, everything but the pinned wires closed).
 #pragma once
 #include <stdint.h>
+#include <utility>
 #include <vector>
 
 #include "tape.hpp"
@@ -55,6 +56,7 @@ struct ScheduleOptions {
   bool pair = true;                 // one entry for the two same-level readers of a producer nobody else reads (never with retain_all)
   bool propagate_copies = true;     // readers use a copy's source; unobserved copies are not materialised (never with retain_all)
   std::vector<uint32_t> pinned;     // handles that must stay readable after the replay (Evaluator::get)
+  bool pinned_are_carried = false;  // ... because the next field segment takes them over from the wire table (capi.cpp)
   uint32_t threads = 0;             // worker threads for the per-level ordering (0 = min(8, hardware threads))
   bool bank_aware = true;           // GF(2): order the ops and number the slots so that one LDS instruction hits 32 banks
 };
@@ -74,6 +76,10 @@ struct Schedule {
   // operation / Evaluator::get): the GF(2) input packing flags a lane only for these (arithmetic entries carry the flag)
   std::vector<uint8_t> strict_instance, strict_witness;
   std::vector<uint8_t> strict_carry;       // the same per value carried in from the previous field segment (TK_CARRY)
+  // Wires alive at the end that are an input the relation has only copied: Evaluator::get returns the unreduced integer
+  // (evaluator.rs:750-752), so zkgpu_get_wire reads the input, not the wire table.  (tape handle, 2 + 4 * position + stream),
+  // sorted by handle.
+  std::vector<std::pair<uint32_t, uint32_t>> raw_source;
   std::vector<uint32_t> strand_level_ptr;  // level bounds of the strands (see Launch::level_ptr)
   std::vector<uint64_t> window_first_op;   // per window: index of its first program entry (+ a final end marker)
   uint32_t n_slots = 0;

@@ -177,7 +177,7 @@ uint32_t TapeBackend::bitwise(uint8_t kind, uint32_t a, uint32_t b) {
   need_field();
   // PlaintextBackend applies & ^ to the integers and then `% m`, and `not` is `is_zero ? 1 : 0`
   // (evaluator.rs:924-938); for p == 2 that is the bit-packed path, for an odd p the arithmetic kernels do the
-  // same on the canonical values (fp_bit_and / fp_bit_xor / fp_is_zero_indicator, device/fp_mont.hpp).
+  // same on the canonical values (bit_operation, device/replay_kernels.hpp; fp_is_zero_indicator, device/fp_mont.hpp).
   return push(kind, a, b);
 }
 
@@ -252,6 +252,14 @@ uint32_t TapeBackend::h_carry(uint32_t index) {
   need_field();
   if (index + 1 > tape_.n_carry) tape_.n_carry = index + 1;
   return push(TK_CARRY, index, 0);
+}
+
+uint32_t TapeBackend::h_input_at(uint8_t kind, uint32_t position) {
+  need_field();
+  if (kind != TK_INSTANCE && kind != TK_WITNESS) throw Error("GPU backend: h_input_at() names an input stream");
+  uint32_t& n = kind == TK_INSTANCE ? tape_.n_instance : tape_.n_witness;
+  if (position + 1 > n) n = position + 1;
+  return push(kind, position, 0);
 }
 
 uint32_t TapeBackend::h_witness(const FieldElement* val) {

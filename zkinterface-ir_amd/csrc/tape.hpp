@@ -74,6 +74,8 @@ struct Tape {
   uint32_t n_instance = 0, n_witness = 0;  // input positions referenced (max + 1)
   uint32_t n_carry = 0;                    // values carried in from the previous field segment
   uint64_t n_value_ops = 0;
+  uint32_t n_rebound = 0;                  // the first n_rebound entries re-bind the wires an earlier field segment left alive
+                                           // (carried values, inputs and constants read again): no backend calls
   // Dropped wires, in order: handle drop_handle[k] went out of the caller's reach when the tape held drop_pos[k]
   // entries -- no call recorded at or after that position can name it.  The reference's evaluator owns its wires
   // (`HashMap<WireId, B::Wire>`, temporaries in locals) and Rust drops them on `Free`, at scope exit and at the end
@@ -135,6 +137,11 @@ class TapeBackend {
     return e;
   }
   void set_field(const Value& modulus, uint32_t degree, bool is_boolean);
+  static FieldElement literal_bytes(const Value& bytes) {   // a constant as its little-endian bytes
+    TapeElement e;
+    e.bytes = bytes;
+    return e;
+  }
   FieldElement one() const { return literal(1); }
   FieldElement minus_one() const;
   FieldElement zero() const { return literal(0); }
@@ -172,7 +179,10 @@ class TapeBackend {
   uint32_t h_not(uint32_t x) { return bitwise(TK_NOT, x, 0); }
   uint32_t h_instance(FieldElement val);
   uint32_t h_witness(const FieldElement* val);
-  uint32_t h_carry(uint32_t index);   // a wire of the previous field segment, alive in the scope when the modulus changed
+  uint32_t h_carry(uint32_t index);
+  // a wire that holds instance / witness value `position` again, without advancing a stream: the integer a wire of the
+  // previous field segment still held when the field changed (capi.cpp switch_field)
+  uint32_t h_input_at(uint8_t kind, uint32_t position);   // a wire of the previous field segment, alive in the scope when the modulus changed
   void h_ladder(size_t first, uint32_t base, uint32_t result) {
     tape_.ladder_open = kNoWire;
     // with is_boolean the "multiplies" of the ladder are `and` gates and Fermat says nothing about them
@@ -223,6 +233,11 @@ class TapeBackend {
   void use_generic_field() {
     force_generic_ = true;
     if (field_set_) field_.init(modulus_, true);
+  }
+  // everything recorded so far re-binds wires of the previous field segment (capi.cpp switch_field)
+  void end_rebinding() {
+    tape_.n_rebound = (uint32_t)tape_.size();
+    tape_.n_value_ops = 0;
   }
   void set_assert_base(uint32_t n) { assert_base_ = n; }   // global sequence number of this segment's first assert
   uint32_t assert_base() const { return assert_base_; }
