@@ -119,7 +119,9 @@ int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]);
  * {dst, kind | a_expr << 8 | b_expr << 10 | second << 12, a0, a1, b0, b1, dst2, c0} (expr: 0 = the slot,
  * 1 = add(x0,x1), 2 = mul(x0,x1); second != 0: pair entry, also dst2 = add (1) / mul (2) of operand a and slot c0),
  * launches4 = {first,count,ops_per_wave,sequential} per launch, const_words = constant pool in device form,
- * slot_of[i] = wire-table slot of tape op i (0xFFFFFFFF for asserts).  Any pointer may be NULL. */
+ * slot_of[i] = wire-table slot of tape op i (0xFFFFFFFF for asserts).  An operand of and / xor over a field other than
+ * GF(2) may be 0x80000000 | (2 + 4 * position + stream) instead of a slot: the raw value of that input (stream 0 instance,
+ * 1 witness, 2 carried in), of which the operand is only a copy.  Any pointer may be NULL. */
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
                         uint32_t* slot_of);
 
@@ -143,16 +145,21 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
 
 /* Values >= the field characteristic.  The reference's PlaintextBackend keeps constants, instance and witness values
  * unreduced (rust/src/consumers/evaluator.rs:862-864,896-898,940-946): arithmetic gates reduce their result, but copy
- * clones the integer, assert_zero / not test it for zero, and / xor over an odd field work on its bits and
+ * clones the integer, assert_zero / not test it for zero, and / xor over a field other than GF(2) work on its bits and
  * Evaluator::get returns it.  After zkgpu_finalize, zkgpu_input_modes gives per input position (witness = 0: instance
  * stream, 1: witness stream; returns the number of positions, writes at most cap bytes) how a value >= p is treated:
  *   0x00  reduced on load: every use is arithmetic (over GF(2): and / xor, whose low bit only depends on low bits);
  *   0x01  read by assert_zero / not alone, through copies: those see "non-zero", as the reference does (a value >= p
  *         is never the integer 0) -- GF(p): the kernels test the raw input beside the wire; GF(2): packed as v != 0;
  *   0x02  GF(p): both of the above (the sinks still get the reference's answer);
- *   0xFF  it reaches and / xor over an odd field, Evaluator::get (a wire alive at the end) or, over GF(2), both a zero
- *         test and a gate: a lane holding a value >= p there is flagged ZKGPU_LANE_NONCANONICAL and counted as failed,
- *         with a violation text that says so.  Constants >= p in those places are refused by zkgpu_finalize.
+ *   0x03  not GF(2): its bits are read as they are -- by and / xor through copies (the entry reads the raw input instead
+ *         of the wire) or by zkgpu_get_wire for a wire alive at the end that is a copy of it (answered from the input
+ *         itself): the reference's answer again; only a value wider than the limbs of the field flags its lane;
+ *   0xFF  over GF(2) (bit-packed) it feeds both a zero test and a gate -- one bit cannot be `v & 1` and `v != 0` -- or it
+ *         was carried over two field changes without passing through a gate: a lane holding a value >= p there is
+ *         flagged ZKGPU_LANE_NONCANONICAL and counted as failed, with a violation text that says so.
+ * Constants >= p that reach and / xor over another field than GF(2), Evaluator::get, or (GF(2)) a zero test and a gate are
+ * refused by zkgpu_finalize.
  * The modes depend on the tape alone, not on options ("stream" windows included). */
 size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size_t cap);
 
