@@ -230,3 +230,88 @@ def test_the_verdict_does_not_depend_on_how_the_tape_was_cut_into_windows():
             seen[stream] = (expected_product_violations(ev, ff), flagged)
         assert seen['0'] == seen['16'], name
         assert seen['0'] == (ref.violations, False), name
+
+
+# ---- random relations with inputs at and above the characteristic -----------------------------------------------------
+FUZZ_FIELDS = [(P, True), (P, False), (2 ** 61 - 1, True), (2 ** 64 - 2, True), (2 ** 61 - 1, False), (6, True)]
+
+
+def _unreduced_rows(g, lanes, seed, p):
+    """instance / witness rows of 8-byte values: small ones, multiples of p, p + small, anything below 2^64"""
+    import random
+    r = random.Random(seed)
+
+    def val():
+        k = r.random()
+        if k < 0.25:
+            return r.randrange(0, 6)
+        if k < 0.5:
+            return min(2 ** 64 - 1, p * r.randrange(1, 4) + r.randrange(0, 3))
+        if k < 0.75:
+            return r.randrange(p)
+        return r.getrandbits(64)
+    return [[val() for _ in range(g.n_inst)] for _ in range(lanes)], [[val() for _ in range(g.n_wit)] for _ in range(lanes)]
+
+
+@pytest.mark.parametrize('seed', range(30))
+def test_random_relations_with_unreduced_inputs_against_oracle(seed):
+    """structured relations (functions, loops, switches) whose inputs are NOT canonical: arithmetic reduces them, zero tests
+    and bit operations see the integers -- the product's verdict is the oracle's for every lane, nobody is flagged"""
+    from random_circuits import Gen
+    p, boolean = FUZZ_FIELDS[seed % len(FUZZ_FIELDS)]
+    g = Gen(seed + 900, p, boolean)
+    rel, mod_le = g.relation()
+    rows_i, rows_w = _unreduced_rows(g, 4, seed, p)
+    ev = zk.Evaluator()
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    ev.ingest_message(rel)
+    if not ev.n_value_ops and ev.host_violations():
+        return
+    ev.finalize()
+    assert ev.elem_bytes == 8
+    ops, launches, consts, _ = ev.schedule_dump()
+    info = ev.schedule_info()
+    modes = (ev.input_modes(False), ev.input_modes(True))
+    assert 0xFF not in modes[0] + modes[1]
+    for lane in range(4):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32, trace=False)
+        _, ff, flagged = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, rows_i[lane], rows_w[lane],
+                                              shuffle_seed=seed, modes=modes)
+        assert not flagged and expected_product_violations(ev, ff) == ref.violations, (seed, lane)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(0, 30, 2))
+def test_random_relations_with_unreduced_inputs_on_gpu(seed):
+    from helpers import batch_arrays
+    from random_circuits import Gen
+    p, boolean = FUZZ_FIELDS[seed % len(FUZZ_FIELDS)]
+    g = Gen(seed + 900, p, boolean)
+    rel, mod_le = g.relation(n_top=14)
+    lanes = 70
+    rows_i, rows_w = _unreduced_rows(g, lanes, seed, p)
+    ev = zk.Evaluator()
+    ev.declare_inputs(g.n_inst, g.n_wit)
+    ev.ingest_message(rel)
+    if not ev.n_value_ops and ev.host_violations():
+        return
+    ev.finalize()
+    inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+    ev.set_inputs(inst if g.n_inst else None, wit if g.n_wit else None, lanes)
+    ev.replay()
+    ev.synchronize()
+    n_ok = 0
+    for lane in range(lanes):
+        ref = oracle_lane(mod_le, rows_i[lane], rows_w[lane], [rel], 32, trace=False)
+        assert ev.get_violations(lane) == ref.violations, (seed, lane)
+        n_ok += ref.violations == []
+    assert ev.counts() == (n_ok, lanes - n_ok) and not ev.lane_results(lanes)[1].any()
+    # Evaluator::get on the wires still alive at the end: the integers, reduced or not
+    ref = oracle_lane(mod_le, rows_i[0], rows_w[0], [rel], 32, trace=False)
+    if not ref.violations:
+        for wid in range(0, 60):
+            want = ref.get(wid)
+            got = ev.get(wid, lanes)
+            assert (want is None) == (got is None), (seed, wid)
+            if want is not None:
+                assert got[0] == want, (seed, wid)
