@@ -264,3 +264,58 @@ def test_session_between_gf2_and_another_field_on_gpu(order):
         assert ev.get_violations(k) == ref.violations, (order, k)
         n_ok += rows[k][2]
     assert ev.counts() == (n_ok, lanes - n_ok)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('p', [2 ** 89 - 2, 2 ** 607 - 1])
+def test_wide_levels_and_a_full_batch_on_gpu(p):
+    """1024 lanes (16 lane blocks: the XCD-aware grid, two streams) over levels of 48 gates, the verdict of every lane against
+    Python integers; the product of the last layer is pinned by an instance value per lane"""
+    rnd = random.Random(p % 1009)
+    W, D, lanes = 48, 3, 1024
+    gates = [('witness', k) for k in range(W)]
+    nid = W
+    prev = list(range(W))
+    layers = []
+    for _ in range(D):
+        cur, spec = [], []
+        for _ in range(W):
+            op, x, y = rnd.choice(['add', 'mul']), rnd.choice(prev), rnd.choice(prev)
+            gates.append((op, nid, x, y))
+            spec.append((op, prev.index(x), prev.index(y)))
+            cur.append(nid)
+            nid += 1
+        layers.append(spec)
+        prev = cur
+    acc = prev[0]
+    for w in prev[1:]:
+        gates.append(('add', nid, acc, w))
+        acc = nid
+        nid += 1
+    gates += [('instance', nid), ('mulc', nid + 1, nid, sw.int_to_le(p - 1)), ('add', nid + 2, acc, nid + 1), ('assert_zero', nid + 2),
+              ('free', 0, nid + 2)]
+    rel = sw.write_relation(sw.int_to_le(p), 'arithmetic', 'simple', [], gates)
+    rows_w = [[rnd.randrange(p) for _ in range(W)] for _ in range(lanes)]
+    rows_i = []
+    for lane, row in enumerate(rows_w):
+        vals = row
+        for spec in layers:
+            vals = [(vals[x] + vals[y]) % p if op == 'add' else (vals[x] * vals[y]) % p for op, x, y in spec]
+        rows_i.append([(sum(vals) + (1 if lane % 37 == 5 else 0)) % p])
+    ev = zk.Evaluator()
+    ev.declare_inputs(1, W)
+    ev.ingest_message(rel)
+    assert ev.host_violations() == [] and ev.field_representation(0) == 2
+    ev.finalize()
+    inst, wit = batch_arrays(rows_i, rows_w, ev.elem_bytes)
+    ev.set_inputs(inst, wit, lanes)
+    ev.replay()
+    ev.synchronize()
+    first, flags = ev.lane_results(lanes)
+    bad = [lane for lane in range(lanes) if lane % 37 == 5]
+    assert [lane for lane in range(lanes) if int(first[lane]) != zk.NO_FAIL] == bad and not flags.any()
+    assert ev.counts() == (lanes - len(bad), len(bad))
+    ev.set_lane_group(512)      # lane groups one after the other: the same verdicts
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (lanes - len(bad), len(bad))
