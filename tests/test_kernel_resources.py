@@ -82,3 +82,19 @@ def test_arithmetic_kernels_at_bn254_width():
         # (the input streams' descriptors sit behind one pointer, device/args.hpp InputAux: in the kernarg block they made
         # the cold kernels spill 28 SGPRs and the strands of a structured relation 13 % slower)
         assert k['scratch'] == 0 and k['vgpr_spill'] == 0 and k['sgpr_spill'] == 0, (name, k)
+
+
+def test_any_modulus_kernels_private_memory():
+    """the operands of the any-modulus kernels are thread-private arrays indexed at run time (device/generic_kernels.hpp):
+    one instantiation per capacity class, so that a 600-bit modulus does not pay for a 4096-bit one -- registers for the
+    small classes, scratch memory bounded by the class for the large ones"""
+    res = kernel_resources.resources('kernels_generic.hip')
+    caps = {}
+    for name, k in res.items():
+        m = re.search(r'replay_generic_kernel<(\d+)>', name)
+        if m:
+            caps[int(m.group(1))] = k
+    assert sorted(caps) == [16, 32, 64, 128]
+    for cap, k in caps.items():
+        assert k['vgprs'] + k['agprs'] <= 512 and k['occupancy'] >= 1, (cap, k)
+        assert k['scratch'] <= 40 * cap, (cap, k)     # 3.6 KB per lane at 4096 bits

@@ -67,6 +67,10 @@ def main():
     for name, k in resources('kernels_bool.hip', flags).items():
         print('  %-58s VGPRs=%-3d AGPRs=%-2d SGPRs=%-3d scratch=%-3d occupancy=%d LDS=%d' %
               (name, k['vgprs'], k['agprs'], k['sgprs'], k['scratch'], k['occupancy'], k['lds']))
+    print('== kernels_generic.hip')
+    for name, k in resources('kernels_generic.hip').items():
+        print('  %-58s VGPRs=%-3d AGPRs=%-2d SGPRs=%-3d scratch=%-4d occupancy=%d' %
+              (name, k['vgprs'], k['agprs'], k['sgprs'], k['scratch'], k['occupancy']))
 
 
 if __name__ == '__main__':
