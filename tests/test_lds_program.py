@@ -2,7 +2,7 @@
 host work -- it is built here for every block size the kernel is instantiated for and INTERPRETED in numpy, 32
 witnesses per word like the kernel: the verdicts must be the oracle's / the CPU checker's, and the structural
 promises the kernel's hand-counted waits rest on must hold (whole rows, a level never reads what it writes, the
-`a and-rows then xor-rows` field only on full blocks that are exactly that)."""
+rows of a level are and-rows, one split row, xor-rows)."""
 import numpy as np
 import pytest
 
@@ -68,10 +68,12 @@ def interpret(prog, consts, inst_bits, wit_bits):
                 desc, off = int(blocks[blk, 0]), int(blocks[blk, 1])
                 n = desc & 15
                 assert 1 <= n <= br and off % 12 == 0
-                kinds = [(desc >> (5 + r)) & 1 for r in range(n)]
-                a1 = (desc >> 17) & 31
-                if a1:
-                    assert n == br and kinds == [0] * (a1 - 1) + [1] * (n - a1 + 1), 'the kind-known path would run other gates'
+                # `n_and` and-rows, then the split row (its first `split` ops are `and`), then xor-rows (lds_layout.hpp)
+                n_and, split = (desc >> 5) & 15, (desc >> 9) & 2047
+                shape = (flags >> 11) & 15     # of the run: full blocks with that many and-rows, or 15 = anything
+                assert shape == 15 or (n == br and n_and == shape), 'the code of the run would execute other gates'
+                assert shape != 15 or n < br or n_and > 12
+                assert n_and <= n and split < ROW and (n_and < n or split == 0), 'a split behind the last row of the block'
                 assert (off // 2) + br * ROW * 3 <= len(rows), 'a block fetches block_rows rows: they must lie in the stream'
                 for r in range(n):
                     rec = rows[off // 2 + r * ROW * 3: off // 2 + (r + 1) * ROW * 3].reshape(ROW, 3).astype(np.int64)
@@ -89,7 +91,8 @@ def interpret(prog, consts, inst_bits, wit_bits):
                     assert not (level_writes & set(real_dst.tolist())), 'two rows of a level write one slot'
                     level_writes.update(real_dst.tolist())
                     x, y = T[a], T[b]                      # all reads of the row before its writes, like the kernel
-                    T[dst] = (x ^ y) if kinds[r] else (x & y)
+                    is_and = np.arange(ROW) < (ROW if r < n_and else split if r == n_and else 0)
+                    T[dst] = np.where(is_and, x & y, x ^ y)
                     T[real + 32] = 0
                     T[real + 33] = 0xFFFFFFFF              # (padding ops only ever write the 32 scratch slots)
                 if desc & 16:

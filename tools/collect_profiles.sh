@@ -67,6 +67,13 @@ elif [ $WHAT = pmc_c2 ]; then
   pmc c2h_f FETCH_SIZE -- $H
   pmc c2h_w WRITE_SIZE -- $H
   python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c2h_f.csv /tmp/pmc_c2h_w.csv $OUT/pmc_traffic_c2_hbm_variant.json 4000000 "$K" c2_hbm_variant > /dev/null
+elif [ $WHAT = pmc_c4 ]; then   # (the LDS / SQ passes of the GF(2) kernel alone: kernel experiments)
+  C4="--workload c4 --steps 2 --warmup 1 --timed-steps-only"
+  LDS="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU"
+  pmc c4_lds $LDS -- $C4
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_lds.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_lds_counters.json
+  pmc c4_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY -- $C4
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_sq.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_sq_counters.json
 elif [ $WHAT = pmc_c45 ]; then
   C4="--workload c4 --steps 2 --warmup 1 --timed-steps-only"
   pmc c4_f FETCH_SIZE -- $C4

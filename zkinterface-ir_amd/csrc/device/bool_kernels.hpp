@@ -191,9 +191,11 @@ __device__ __forceinline__ void lds_exec(const LdsOp op, u32* __restrict__ T, co
   T[op.dst] = r;
 }
 
-// The xor / and / not / copy ops of a level are stored as ROWS of 2048 ops of one kind -- and or xor: `not a` is stored
-// as a xor ONES, a copy as a xor ZERO (args.hpp) -- padded to whole rows with ops on scratch slots, without their kind:
-// three u16 per op, two ops = 12 bytes per thread and row -- {pair | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}.  The two
+// The and / xor / not / copy ops of a level are ONE sequence -- its `and` ops first, then the rest, which the rows know as
+// `xor`: `not a` is stored as a xor ONES, a copy as a xor ZERO (lds_layout.hpp) -- cut into ROWS of 2048 ops and padded
+// at its end only with ops on scratch slots: and-rows, at most one SPLIT row (its first ops `and`, its other ops `xor`),
+// xor-rows.  The ops are stored without their kind: three u16 per op, two ops = 12 bytes per thread and row --
+// {pair | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}.  The two
 // results of a thread go to the two halves of ONE 8-byte slot pair (slots 2 * pair and 2 * pair + 1: the scheduler
 // allocates the result slots of a row pair by pair), so a row step has one address shift and one ds_write_b64 for them.
 // Consecutive rows of a level form BLOCKS of at most BR rows (args.hpp: block header).
@@ -278,8 +280,16 @@ __device__ __forceinline__ void ldsp_wait_row() {
 #define ZKGPU_LDS_STEP_TEMPS [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2), [t3] "n"(kRegT + 3)
 
 // step R of a block of N rows: [reads of row R + kLdsAhead] -> wait for row R -> gates, writes -> refill
+// The split row (lds_layout.hpp): its ops at row positions below `split` are `and`, the others `xor`.  Thread t executes
+// the ops at positions 2 t and 2 t + 1 (`wpos`, `wpos + 1`: two VGPRs the kernel sets up once).
+struct LdsSplit {
+  u32 split;   // wave-uniform, 0 .. 2048
+  u32 wpos;    // 2 * threadIdx.x
+  u32 wpos1;   // 2 * threadIdx.x + 1
+};
+
 template <int BR, int N, int R, int KIND>
-__device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 voff) {
+__device__ __forceinline__ void ldsp_step(const LdsSplit& sp, const u32* src_next, u32 voff) {
   constexpr int S = kLdsAhead + 1;
   constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % S);
   constexpr int w = R < kLdsAhead ? R : kLdsAhead;                              // writes (one per row) behind the reads of row R
@@ -305,8 +315,9 @@ __device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 vof
                  : "memory");
   }
   // gates of row R, their writes, and the refill of the row's registers.  KIND 0 / 1: the row is known to be and / xor
-  // (a full block whose rows are `A` and-rows followed by xor-rows: one instantiation per A, no decision per row);
-  // KIND 2: by the row's bit of the block header (s_bitcmp1 + a branch inside the statement, which then clobbers scc).
+  // (a full block: `A` and-rows, the split row, xor-rows -- one instantiation per A, no decision per row); KIND 2: the
+  // split row -- every lane computes both gates and keeps the one of its side of the split: six more vector
+  // instructions in one row of a level, no branch (the statement clobbers vcc).
 #define ZKGPU_LDS_STEP_WRITE                                         \
   "ds_write_b64 v[%[t0]], v[%[t2]:%[t3]]\n\t"                        \
   "global_load_dwordx3 v[%[px]:%[pz]], %[voff], %[base]"
@@ -321,17 +332,18 @@ __device__ __forceinline__ void ldsp_step(u32 desc, const u32* src_next, u32 vof
   } else if constexpr (KIND == 1) {
     asm volatile(ZKGPU_LDS_STEP_GATES("v_xor_b32") ZKGPU_LDS_STEP_WRITE : : ZKGPU_LDS_STEP_TAIL_OPERANDS : "memory");
   } else {
-    asm volatile("s_bitcmp1_b32 %[desc], %[bit]\n\t"
-                 "s_cbranch_scc1 1f\n\t"
-                 ZKGPU_LDS_STEP_GATES("v_and_b32")
-                 "s_branch 2f\n"
-                 "1:\n\t"
-                 ZKGPU_LDS_STEP_GATES("v_xor_b32")
-                 "2:\n\t"
+    asm volatile("v_and_b32 v[%[t2]], v[%[v0]], v[%[v2]]\n\t"
+                 "v_xor_b32 v[%[t1]], v[%[v0]], v[%[v2]]\n\t"
+                 "v_cmp_gt_u32 vcc, %[split], %[wpos]\n\t"               // the even op is an `and`: 2 t < split
+                 "v_cndmask_b32 v[%[t2]], v[%[t1]], v[%[t2]], vcc\n\t"   // (vcc ? src1 : src0)
+                 "v_and_b32 v[%[t3]], v[%[v1]], v[%[v3]]\n\t"
+                 "v_xor_b32 v[%[t1]], v[%[v1]], v[%[v3]]\n\t"
+                 "v_cmp_gt_u32 vcc, %[split], %[wpos1]\n\t"
+                 "v_cndmask_b32 v[%[t3]], v[%[t1]], v[%[t3]], vcc\n\t"
                  ZKGPU_LDS_STEP_WRITE
                  :
-                 : [desc] "s"(desc), [bit] "n"(kLdsBlockKindShift + R), ZKGPU_LDS_STEP_TAIL_OPERANDS
-                 : "memory", "scc");
+                 : [split] "s"(sp.split), [wpos] "v"(sp.wpos), [wpos1] "v"(sp.wpos1), ZKGPU_LDS_STEP_TAIL_OPERANDS
+                 : "memory", "vcc");
   }
 }
 template <int R>   // this thread's 12 bytes of a row -> the registers of row R; voff = byte offset of (thread, row R) in a block
@@ -346,24 +358,36 @@ __device__ __forceinline__ void ldsp_gload_header(const u32* p, u32 vzero) {   /
   asm volatile("global_load_dwordx2 v[%2:%3], %0, %1" : : "v"(vzero), "s"(p), "n"(kRegH), "n"(kRegH + 1) : "memory");
 }
 
-// One block of N rows, straight-line (one instantiation per N: every wait is a constant).  A >= 0: the first A rows
-// are and-rows, the rest xor-rows; A < 0: every row decides by its header bit.
+// One block of N rows, straight-line (one instantiation per N: every wait is a constant).  A >= 0 (full blocks): the
+// first A rows are and-rows, row A is the split row, the rest xor-rows; A < 0: `ad` and-rows, known at run time -- every
+// row runs the split row's code with a split that puts all of it on one side (2048: all `and`; 0: all `xor`) unless it
+// is the split row itself.
 template <int BR, int N, int A, int R>
-__device__ __forceinline__ void ldsp_rows(u32 desc, const u32* src_next, const u32 (&voff)[BR]) {
+__device__ __forceinline__ void ldsp_rows(const LdsSplit& sp, u32 ad, const u32* src_next, const u32 (&voff)[BR]) {
   if constexpr (R < BR) {
-    if constexpr (R < N) ldsp_step<BR, N, R, (A < 0 ? 2 : (R < A ? 0 : 1))>(desc, src_next, voff[R]);
-    else ldsp_gload<R>(src_next, voff[R]);
-    ldsp_rows<BR, N, A, R + 1>(desc, src_next, voff);
+    if constexpr (R < N) {
+      if constexpr (A < 0) {
+        LdsSplit row = sp;
+        row.split = (u32)R < ad ? (u32)kLdsRowOps : ((u32)R == ad ? sp.split : 0u);
+        ldsp_step<BR, N, R, 2>(row, src_next, voff[R]);
+      } else {
+        ldsp_step<BR, N, R, (R < A ? 0 : (R == A ? 2 : 1))>(sp, src_next, voff[R]);
+      }
+    } else {
+      ldsp_gload<R>(src_next, voff[R]);
+    }
+    ldsp_rows<BR, N, A, R + 1>(sp, ad, src_next, voff);
   }
 }
 template <int BR, int N, int A>
-__device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 vzero, u32 desc, const u32* src_next, const u32 (&voff)[BR]) {
+__device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 vzero, const LdsSplit& sp, u32 ad, const u32* src_next,
+                                           const u32 (&voff)[BR]) {
   if constexpr (N <= BR && A <= N) {
     ldsp_read<BR, 0>();
     if constexpr (N > 1 && kLdsAhead > 1) ldsp_read<BR, 1>();
     if constexpr (N > 2 && kLdsAhead > 2) ldsp_read<BR, 2>();
     ldsp_gload_header(hdr_next3, vzero);
-    ldsp_rows<BR, N, A, 0>(desc, src_next, voff);
+    ldsp_rows<BR, N, A, 0>(sp, ad, src_next, voff);
   }
 }
 template <int BR, int R>
@@ -371,6 +395,51 @@ __device__ __forceinline__ void ldsp_gload_all(const u32* src, const u32 (&voff)
   if constexpr (R < BR) {
     ldsp_gload<R>(src, voff[R]);
     ldsp_gload_all<BR, R + 1>(src, voff);
+  }
+}
+
+// A run of `run` blocks starting with block `first`.  Header = {descriptor, BYTE offset of the block in ops6}.  A >= 0:
+// every block of the run is full and starts with A and-rows (lds_program.cpp starts a new run where that changes), so
+// nothing is decided per block; A < 0: blocks of any row count, and-rows read from the header.
+template <int BR, int A>
+__device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32 run, u32 vzero, LdsSplit sp, const u32 (&voff)[BR]) {
+  if constexpr (A <= BR) {
+    const u32* hdr = args.blocks + 2 * (size_t)first;
+    const u32 last = __builtin_amdgcn_readfirstlane(run - 1);
+    u32 d_cur = lds_sload(hdr, 0), f_cur = lds_sload(hdr, 1);
+    u32 d_nxt = lds_sload(hdr, 2 * min(1u, last)), f_nxt = lds_sload(hdr, 2 * min(1u, last) + 1);
+    const char* stream = reinterpret_cast<const char*>(args.ops6);
+    ldsp_gload_header(hdr + 2 * min(2u, last), vzero);
+    ldsp_gload_all<BR, 0>(reinterpret_cast<const u32*>(stream + f_cur), voff);
+    // the scalar loads above have to be over: none may be in flight below (naming the values orders the loads before)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d_cur), "+s"(f_cur), "+s"(d_nxt), "+s"(f_nxt) : : "memory");
+    for (u32 k = 0; k < run; ++k) {
+      // rows 0 .. kLdsAhead - 1 and the header of block k + 2 (issued a block ago) have arrived
+      ldsp_wait_row<BR>();
+      u32 d_n2, f_n2;
+      asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
+      const u32* hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
+      const u32* src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
+      sp.split = (d_cur >> kLdsBlockSplitShift) & 2047;
+      if constexpr (A >= 0) {
+        ldsp_block<BR, BR, A>(hdr_next3, vzero, sp, 0u, src_next, voff);
+      } else {
+        const u32 ad = (d_cur >> kLdsBlockAndShift) & 15;
+#define ZKGPU_LDS_ANY(N) case N: ldsp_block<BR, N, -1>(hdr_next3, vzero, sp, ad, src_next, voff); break;
+        switch (d_cur & 15) {
+          ZKGPU_LDS_ANY(1) ZKGPU_LDS_ANY(2) ZKGPU_LDS_ANY(3) ZKGPU_LDS_ANY(4) ZKGPU_LDS_ANY(5) ZKGPU_LDS_ANY(6)
+          ZKGPU_LDS_ANY(7) ZKGPU_LDS_ANY(8) ZKGPU_LDS_ANY(9) ZKGPU_LDS_ANY(10) ZKGPU_LDS_ANY(11)
+          default: ldsp_block<BR, 12, -1>(hdr_next3, vzero, sp, ad, src_next, voff); break;
+        }
+#undef ZKGPU_LDS_ANY
+      }
+      if ((d_cur >> 4) & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
+      d_cur = d_nxt;
+      f_cur = f_nxt;
+      d_nxt = d_n2;
+      f_nxt = f_n2;
+    }
+    (void)f_cur;
   }
 }
 
@@ -432,52 +501,19 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
       if ((flags >> 8) & 1) __syncthreads();
       continue;
     }
-    // A run of `run` blocks starting with block `first`.  Header = {descriptor, BYTE offset of the block in ops6}.
-    const u32* hdr = args.blocks + 2 * (size_t)first;
-    const u32 last = __builtin_amdgcn_readfirstlane(run - 1);
-    u32 d_cur = lds_sload(hdr, 0), f_cur = lds_sload(hdr, 1);
-    u32 d_nxt = lds_sload(hdr, 2 * min(1u, last)), f_nxt = lds_sload(hdr, 2 * min(1u, last) + 1);
-    const char* stream = reinterpret_cast<const char*>(args.ops6);
-    ldsp_gload_header(hdr + 2 * min(2u, last), vzero);
-    ldsp_gload_all<BR, 0>(reinterpret_cast<const u32*>(stream + f_cur), voff);
-    // the scalar loads above have to be over: none may be in flight below (naming the values orders the loads before)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d_cur), "+s"(f_cur), "+s"(d_nxt), "+s"(f_nxt) : : "memory");
-    for (u32 k = 0; k < run; ++k) {
-      const u32 n = d_cur & 15;
-      // rows 0 .. kLdsAhead - 1 and the header of block k + 2 (issued a block ago) have arrived
-      ldsp_wait_row<BR>();
-      u32 d_n2, f_n2;
-      asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
-      const u32* hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
-      const u32* src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
-      // The engine sizes the blocks to the program, so nearly all are full, and a level's rows come sorted by kind: a
-      // full block of `a` and-rows followed by xor-rows (header bits 17..21 = a + 1, 0 = some other order) runs code
-      // that knows every row's kind.
-      const u32 a1 = (d_cur >> kLdsBlockAndShift) & 31;
-      if (a1) {   // (set for full blocks only)
-#define ZKGPU_LDS_FULL(A) case A + 1: ldsp_block<BR, BR, A>(hdr_next3, vzero, d_cur, src_next, voff); break;
-        switch (a1) {
-          ZKGPU_LDS_FULL(0) ZKGPU_LDS_FULL(1) ZKGPU_LDS_FULL(2) ZKGPU_LDS_FULL(3) ZKGPU_LDS_FULL(4) ZKGPU_LDS_FULL(5) ZKGPU_LDS_FULL(6)
-          ZKGPU_LDS_FULL(7) ZKGPU_LDS_FULL(8) ZKGPU_LDS_FULL(9) ZKGPU_LDS_FULL(10) ZKGPU_LDS_FULL(11) ZKGPU_LDS_FULL(12)
-          default: break;
-        }
-#undef ZKGPU_LDS_FULL
-      } else {
-#define ZKGPU_LDS_ANY(N) case N: ldsp_block<BR, N, -1>(hdr_next3, vzero, d_cur, src_next, voff); break;
-        switch (n) {
-          ZKGPU_LDS_ANY(1) ZKGPU_LDS_ANY(2) ZKGPU_LDS_ANY(3) ZKGPU_LDS_ANY(4) ZKGPU_LDS_ANY(5) ZKGPU_LDS_ANY(6)
-          ZKGPU_LDS_ANY(7) ZKGPU_LDS_ANY(8) ZKGPU_LDS_ANY(9) ZKGPU_LDS_ANY(10) ZKGPU_LDS_ANY(11)
-          default: ldsp_block<BR, 12, -1>(hdr_next3, vzero, d_cur, src_next, voff); break;
-        }
-#undef ZKGPU_LDS_ANY
-      }
-      if ((d_cur >> 4) & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
-      d_cur = d_nxt;
-      f_cur = f_nxt;
-      d_nxt = d_n2;
-      f_nxt = f_n2;
+    // A run of `run` blocks starting with block `first`: all full blocks with the same number of and-rows (flags bits
+    // 11..14; the code of such a run knows every row's kind but the split row's), or blocks of any shape (15)
+#define ZKGPU_LDS_RUN(A) case A: ldsp_run<BR, A>(args, first, run, vzero, sp, voff); break;
+    LdsSplit sp;
+    sp.split = 0;
+    sp.wpos = 2 * tid;
+    sp.wpos1 = 2 * tid + 1;
+    switch ((flags >> kLdsChunkAndShift) & 15) {
+      ZKGPU_LDS_RUN(0) ZKGPU_LDS_RUN(1) ZKGPU_LDS_RUN(2) ZKGPU_LDS_RUN(3) ZKGPU_LDS_RUN(4) ZKGPU_LDS_RUN(5) ZKGPU_LDS_RUN(6)
+      ZKGPU_LDS_RUN(7) ZKGPU_LDS_RUN(8) ZKGPU_LDS_RUN(9) ZKGPU_LDS_RUN(10) ZKGPU_LDS_RUN(11) ZKGPU_LDS_RUN(12)
+      default: ldsp_run<BR, -1>(args, first, run, vzero, sp, voff); break;
     }
-    (void)f_cur;
+#undef ZKGPU_LDS_RUN
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }

@@ -522,18 +522,30 @@ void StreamScheduler::Impl::fuse_and_pair() {
 
 void StreamScheduler::Impl::order_by_level() {
   // ---- order ops by (level, kind): counting sort ------------------------
+  // GF(2): the kinds that run as ROWS of the LDS-resident kernel (and, xor, not, copy) come last in a level, and first
+  // then xor, not, copy -- for the kernel the last three are all `xor` (with ONES / ZERO as the second operand): the rows
+  // of a level are ONE sequence of ops whose first part is `and` and whose rest is `xor`, padded at its end only
+  // (lds_program.cpp; positions in that sequence: assign_slots).
   constexpr uint32_t kKinds = TK_CARRY + 1;
+  uint32_t rank[kKinds];
+  for (uint32_t k = 0; k < kKinds; ++k) rank[k] = k;
+  if (s.boolean_path) {
+    uint32_t next = 0;
+    for (uint32_t k = 0; k < kKinds; ++k)
+      if (k != TK_AND && k != TK_XOR && k != TK_NOT && k != TK_COPY) rank[k] = next++;
+    for (uint32_t k : {(uint32_t)TK_AND, (uint32_t)TK_XOR, (uint32_t)TK_NOT, (uint32_t)TK_COPY}) rank[k] = next++;
+  }
   std::vector<uint64_t> bucket((size_t)n_wlevels * kKinds + 1, 0);
   const std::vector<uint32_t>& level = s.level_of;
   size_t n_live = 0;
   for (uint32_t i = lo; i < hi; ++i)
-    if (st(i) == ST_ENTRY) { ++bucket[(size_t)(level[i] - base) * kKinds + kind[i - lo] + 1]; ++n_live; }
+    if (st(i) == ST_ENTRY) { ++bucket[(size_t)(level[i] - base) * kKinds + rank[kind[i - lo]] + 1]; ++n_live; }
   for (size_t k = 1; k < bucket.size(); ++k) bucket[k] += bucket[k - 1];
   order.assign(n_live, 0);
   {
     std::vector<uint64_t> cursor(bucket.begin(), bucket.end() - 1);
     for (uint32_t i = lo; i < hi; ++i)
-      if (st(i) == ST_ENTRY) order[cursor[(size_t)(level[i] - base) * kKinds + kind[i - lo]]++] = i;
+      if (st(i) == ST_ENTRY) order[cursor[(size_t)(level[i] - base) * kKinds + rank[kind[i - lo]]]++] = i;
   }
   level_start.assign(n_wlevels + 1, 0);
   for (uint32_t l = 0; l <= n_wlevels; ++l) level_start[l] = bucket[(size_t)l * kKinds];
@@ -659,12 +671,33 @@ void StreamScheduler::Impl::assign_slots() {
     const uint32_t d = slot / 2;
     if (--pair_live[d] == 0 && d != open_single) free_pairs[banked ? d % kPairBanks : 0].push_back(d);   // both halves are dead
   };
-  // Order the ops of one (level, kind) run [k0, k1) of `order` for the LDS kernel.  Thread t of the workgroup executes
-  // ops 2t and 2t + 1 of a 2048-op row, so one LDS instruction of a wave serves the even (or the odd) ops of a
-  // 128-op block, in two groups of 32 lanes: positions q and q' of the run conflict when q / 64 == q' / 64, q % 2 == q' % 2
-  // and their operands (or their results) share a bank.  Greedy: fill group after group, taking for each lane an op
-  // whose operand banks are still unused in the group; what cannot be placed conflict-free fills the holes.
-  auto bank_order = [&](uint64_t k0, uint64_t k1) {
+  // Order the ops of one (level, kind) run [k0, k1) of `order` for the LDS kernel.  The row ops of a level are ONE
+  // sequence (and, then xor, not, copy: order_by_level) and thread t of the workgroup executes ops 2t and 2t + 1 of a
+  // 2048-op row of it, so one LDS instruction of a wave serves the even (or the odd) ops of a 128-op block, in two groups
+  // of 32 lanes: positions q and q' of the SEQUENCE conflict when q / 64 == q' / 64, q % 2 == q' % 2 and their operands
+  // (or their results) share a bank.  `offset` = position of the run's first op in the sequence: the run's first and
+  // last 64-position blocks may be shared with its neighbours, whose banks in the shared block arrive in carry_a / carry_b
+  // (per parity) and are avoided.  Greedy: fill group after group, taking for each lane an op whose operand banks are still
+  // unused in the group; what cannot be placed conflict-free fills the holes.
+  uint32_t carry_a[2] = {0, 0}, carry_b[2] = {0, 0};
+  // after a run has its final order: the banks its ops use in the block the next run will share with it
+  auto note_run = [&](uint64_t k0, uint64_t k1, uint64_t offset) {
+    const uint64_t end = offset + (k1 - k0);
+    if (k1 == k0) return;
+    if (end % 64 == 0) {
+      carry_a[0] = carry_a[1] = carry_b[0] = carry_b[1] = 0;
+      return;
+    }
+    const uint64_t last_block = (end - 1) / 64;
+    if (offset / 64 != last_block || offset % 64 == 0) carry_a[0] = carry_a[1] = carry_b[0] = carry_b[1] = 0;   // (else: the run lies inside the shared block)
+    for (uint64_t q = std::max(offset, last_block * 64); q < end; ++q) {
+      const uint32_t i = order[k0 + (q - offset)];
+      const int ni = n_inputs(kind[i - lo]);
+      if (ni >= 1) carry_a[q % 2] |= 1u << (s.slot_of[ra[i - lo]] % kBanks);
+      if (ni == 2) carry_b[q % 2] |= 1u << (s.slot_of[rb[i - lo]] % kBanks);
+    }
+  };
+  auto bank_order = [&](uint64_t k0, uint64_t k1, uint64_t offset) {
     const size_t cnt = k1 - k0;
     if (cnt < 2 * kBanks) return;
     const bool two = n_inputs(kind[order[k0] - lo]) == 2;
@@ -680,10 +713,21 @@ void StreamScheduler::Impl::assign_slots() {
       by_a[s.slot_of[ra[i - lo]] % kBanks].push_back(i);
     }
     std::vector<uint32_t> out(cnt, kInf);
-    const size_t n_groups = (cnt + 2 * kBanks - 1) / (2 * kBanks) * 2;
-    // groups in run order: block g / 2, parity g % 2 -> positions (g / 2) * 64 + (g % 2) + 2 * lane
-    auto pos_of = [&](size_t g, uint32_t lane) { return (g / 2) * 64 + (g % 2) + 2 * (size_t)lane; };
+    const uint64_t block0 = offset / 64;
+    const size_t n_groups = (size_t)((offset + cnt - 1) / 64 - block0 + 1) * 2;
+    // groups in sequence order: block block0 + g / 2, parity g % 2 -> sequence positions block * 64 + (g % 2) + 2 * lane;
+    // the run holds the positions [offset, offset + cnt): index into `out` = position - offset, kInf outside
+    auto pos_of = [&](size_t g, uint32_t lane) -> size_t {
+      const uint64_t q = (block0 + g / 2) * 64 + (g % 2) + 2 * (uint64_t)lane;
+      return (q < offset || q >= offset + cnt) ? (size_t)kInf : (size_t)(q - offset);
+    };
     std::vector<uint32_t> used_a(n_groups, 0), used_b(n_groups, 0);
+    if (offset % 64) {
+      for (int par = 0; par < 2; ++par) {
+        used_a[par] = carry_a[par];
+        used_b[par] = carry_b[par];
+      }
+    }
     // ops left per operand-b bank: a lane prefers the candidate whose b bank has most ops left, so that the banks
     // are used up evenly and the last groups of the run still find 32 different ones
     uint32_t left_b[kBanks] = {0};
@@ -719,9 +763,10 @@ void StreamScheduler::Impl::assign_slots() {
     for (size_t g = 0; g < n_groups; ++g) {
       uint32_t holes[kBanks], n_holes = 0;
       for (uint32_t lane = 0; lane < kBanks; ++lane) {
-        if (pos_of(g, lane) >= cnt) continue;
+        if (pos_of(g, lane) == (size_t)kInf) continue;
         // the operand-a bank of this lane: rotate with the group so that no bank's bucket is always served last
-        const uint32_t i = take((lane + (uint32_t)g) % kBanks, used_b[g], 24);
+        const uint32_t bank = (lane + (uint32_t)g) % kBanks;
+        const uint32_t i = ((used_a[g] >> bank) & 1) ? kInf : take(bank, used_b[g], 24);
         if (i != kInf) put(g, lane, i);
         else holes[n_holes++] = lane;
       }
@@ -738,7 +783,7 @@ void StreamScheduler::Impl::assign_slots() {
     for (size_t g = 0; g < n_groups; ++g)
       for (uint32_t lane = 0; lane < kBanks; ++lane) {
         const size_t q = pos_of(g, lane);
-        if (q >= cnt || out[q] != kInf) continue;
+        if (q == (size_t)kInf || out[q] != kInf) continue;
         uint32_t pick_bank = kInf;
         for (uint32_t bank = 0; bank < kBanks && pick_bank == kInf; ++bank)
           if (!by_a[bank].empty() && !((used_a[g] >> bank) & 1)) pick_bank = bank;
@@ -755,7 +800,7 @@ void StreamScheduler::Impl::assign_slots() {
   // still unplaced (an op with operand banks (x, y) is the edge x--y and, the gates being commutative, also y--x with
   // its operands swapped).  Greedy choices run dry towards the end of a run; augmenting paths (Kuhn) do not, as long
   // as a matching exists.
-  auto bank_order_two = [&](uint64_t k0, uint64_t k1) {
+  auto bank_order_two = [&](uint64_t k0, uint64_t k1, uint64_t offset) {
     const size_t cnt = k1 - k0;
     constexpr uint32_t kFlip = 0x80000000u;
     std::vector<uint32_t> run(order.begin() + k0, order.begin() + k1);
@@ -771,8 +816,12 @@ void StreamScheduler::Impl::assign_slots() {
     for (uint32_t a = 0; a < kBanks; ++a)
       for (uint32_t b = 0; b < kBanks; ++b) left[a * kBanks + b] = (uint32_t)cell[a * kBanks + b].size();
     std::vector<uint32_t> out(cnt, kInf);
-    const size_t n_groups = (cnt + 2 * kBanks - 1) / (2 * kBanks) * 2;
-    auto pos_of = [&](size_t g, uint32_t lane) { return (g / 2) * 64 + (g % 2) + 2 * (size_t)lane; };
+    const uint64_t block0 = offset / 64;
+    const size_t n_groups = (size_t)((offset + cnt - 1) / 64 - block0 + 1) * 2;
+    auto pos_of = [&](size_t g, uint32_t lane) -> size_t {   // (as in bank_order)
+      const uint64_t q = (block0 + g / 2) * 64 + (g % 2) + 2 * (uint64_t)lane;
+      return (q < offset || q >= offset + cnt) ? (size_t)kInf : (size_t)(q - offset);
+    };
     int match_of_b[kBanks], match_of_a[kBanks];
     uint32_t visited = 0, taken_b = 0;
     // capacity of edge a--b for one more use in this group: the reverse edge b--a, if matched, draws on the same ops
@@ -799,7 +848,7 @@ void StreamScheduler::Impl::assign_slots() {
         }
         // otherwise push somebody else off a taken one (augmenting path)
         for (uint32_t b = 0; b < 32; ++b) {
-          if ((visited >> b) & 1 || !((taken_b >> b) & 1) || !capacity(a, b)) continue;
+          if ((visited >> b) & 1 || !((taken_b >> b) & 1) || match_of_b[b] < 0 || !capacity(a, b)) continue;   // (taken without a match: by the neighbouring run)
           visited |= 1u << b;
           const int other = match_of_b[b];
           match_of_a[other] = -1;
@@ -821,13 +870,17 @@ void StreamScheduler::Impl::assign_slots() {
     };
     for (size_t g = 0; g < n_groups; ++g) {
       uint32_t lanes = 0;
-      for (uint32_t lane = 0; lane < kBanks; ++lane) lanes += pos_of(g, lane) < cnt;
+      for (uint32_t lane = 0; lane < kBanks; ++lane) lanes += pos_of(g, lane) != (size_t)kInf;
       if (!lanes) continue;
       for (uint32_t b = 0; b < kBanks; ++b) match_of_b[b] = match_of_a[b] = -1;
-      taken_b = 0;
+      // the first block may be shared with the run before this one: its banks are taken
+      const bool shared = g < 2 && offset % 64 != 0;
+      const uint32_t blocked_a = shared ? carry_a[g % 2] : 0;
+      taken_b = shared ? carry_b[g % 2] : 0;
       uint32_t matched = 0;
       for (uint32_t t = 0; t < kBanks && matched < lanes; ++t) {
         const uint32_t a = (t + (uint32_t)g) % kBanks;
+        if ((blocked_a >> a) & 1) continue;
         visited = 0;
         if (Kuhn::augment(a, match_of_b, match_of_a, visited, taken_b, capacity_fn)) ++matched;
       }
@@ -843,7 +896,7 @@ void StreamScheduler::Impl::assign_slots() {
         if (a != b) --left[b * kBanks + a];
         const uint32_t i = run[r];
         if (e & kFlip) std::swap(ra[i - lo], rb[i - lo]);
-        while (lane < kBanks && (pos_of(g, lane) >= cnt || out[pos_of(g, lane)] != kInf)) ++lane;
+        while (lane < kBanks && (pos_of(g, lane) == (size_t)kInf || out[pos_of(g, lane)] != kInf)) ++lane;
         out[pos_of(g, lane)] = i;
       }
     }
@@ -875,27 +928,30 @@ void StreamScheduler::Impl::assign_slots() {
   auto row_class = [&](uint8_t k) { return k == TK_AND || k == TK_XOR || k == TK_NOT || k == TK_COPY; };
   for (uint32_t l = 0; l < n_wlevels; ++l) {
     if (!opt.retain_all && l > 0) release_level(l - 1);
-    uint64_t run0 = level_start[l];   // start of the current (level, kind) run
-    bool wide_run = false;            // long enough for whole groups of 32 lanes
     // GF(2): a level wide enough for a launch of its own runs as rows of the LDS-resident kernel (lds_program.cpp), two
-    // ops per thread in run order; a narrower one joins a sequential segment (emit_launches)
+    // ops per thread in the order of its row SEQUENCE -- the and, xor, not and copy ops of the level, in that order
+    // (order_by_level); a narrower one joins a sequential segment (emit_launches)
     const bool rows_level = s.boolean_path && level_start[l + 1] - level_start[l] >= opt.narrow_width;
+    uint64_t rows0 = level_start[l + 1];   // first op of the row sequence
+    for (uint64_t k = level_start[l]; k < level_start[l + 1] && rows0 == level_start[l + 1]; ++k)
+      if (row_class(kind[order[k] - lo])) rows0 = k;
+    const bool wide_rows = level_start[l + 1] - rows0 >= 2 * kBanks;   // long enough for whole groups of 32 lanes
+    carry_a[0] = carry_a[1] = carry_b[0] = carry_b[1] = 0;
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
-      if (s.boolean_path && (k == level_start[l] || kind[order[k] - lo] != kind[order[k - 1] - lo])) {
-        run0 = k;
+      if (s.boolean_path && k >= rows0 && (k == rows0 || kind[order[k] - lo] != kind[order[k - 1] - lo])) {
         uint64_t e = k;
         while (e < level_start[l + 1] && kind[order[e] - lo] == kind[order[k] - lo]) ++e;
-        wide_run = e - k >= 2 * kBanks;
-        if (banked && wide_run && kind[order[k] - lo] != TK_ASSERT) {
-          if (n_inputs(kind[order[k] - lo]) == 2) bank_order_two(k, e);
-          else if (n_inputs(kind[order[k] - lo]) == 1) bank_order(k, e);
+        if (banked && rows_level && e - k >= 2 * kBanks) {
+          if (n_inputs(kind[order[k] - lo]) == 2) bank_order_two(k, e, k - rows0);
+          else if (n_inputs(kind[order[k] - lo]) == 1) bank_order(k, e, k - rows0);
         }
+        note_run(k, e, k - rows0);
       }
       const uint32_t i = order[k];
       if (kind[i - lo] == TK_ASSERT || kind[i - lo] == TK_NOP) continue;
-      // position of the op in its run (the thread that executes it is position / 2), for the ops that run as rows
-      prefer_bank = wide_run;
-      place(i, (rows_level && row_class(kind[i - lo])) ? (uint32_t)(k - run0) : kInf);
+      // position of the op in the row sequence (the thread that executes it is position / 2), for the ops that run as rows
+      prefer_bank = wide_rows;
+      place(i, (rows_level && row_class(kind[i - lo])) ? (uint32_t)(k - rows0) : kInf);
       if (!pair_second.empty() && pair_second[i - lo] != kInf) place(pair_second[i - lo]);  // the second value of a pair entry
     }
   }
