@@ -244,20 +244,28 @@ static_assert((kRegT + 2) % 2 == 0, "the two results of a row step are the data 
 // workgroup fill them): a row step is two asm statements holding nothing but 7 VALU (five address shifts, two gates),
 // 5 LDS (four reads, one 64-bit write), 1 VMEM and the waits (vmcnt every other row, lgkmcnt every row).  What hipcc makes of a C++ if-chain over the
 // row kind is a dozen scalar instructions and up to five branches per row, and between statements it puts address adds.
-template <int BR, int R>   // issue the four operand reads of row R (block start: rows 0 .. kLdsAhead - 1)
-__device__ __forceinline__ void ldsp_read() {
-  constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
+template <int BR, int R>   // the LDS addresses of the four operands of row R, into the step temporaries
+__device__ __forceinline__ void ldsp_addr() {
+  constexpr int P = kRegP + 4 * R;
   asm volatile("v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[ax]]" ZKGPU_SDWA_HI
                "v_lshlrev_b32_sdwa v[%[t1]], %[two], v[%[az]]" ZKGPU_SDWA_LO
                "v_lshlrev_b32_sdwa v[%[t2]], %[two], v[%[ay]]" ZKGPU_SDWA_LO
                "v_lshlrev_b32_sdwa v[%[t3]], %[two], v[%[az]]" ZKGPU_SDWA_HI
-               "ds_read_b32 v[%[a0]], v[%[t0]]\n\t"
+               :
+               : [two] "s"(2u), [ax] "n"(P), [ay] "n"(P + 1), [az] "n"(P + 2), [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2),
+                 [t3] "n"(kRegT + 3)
+               : "memory");
+}
+template <int BR, int R>   // ... and the four reads (block start: rows 0 .. kLdsAhead - 1)
+__device__ __forceinline__ void ldsp_issue() {
+  constexpr int V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
+  asm volatile("ds_read_b32 v[%[a0]], v[%[t0]]\n\t"
                "ds_read_b32 v[%[a1]], v[%[t1]]\n\t"
                "ds_read_b32 v[%[a2]], v[%[t2]]\n\t"
                "ds_read_b32 v[%[a3]], v[%[t3]]"
                :
-               : [two] "s"(2u), [ax] "n"(P), [ay] "n"(P + 1), [az] "n"(P + 2), [a0] "n"(V), [a1] "n"(V + 1), [a2] "n"(V + 2),
-                 [a3] "n"(V + 3), [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2), [t3] "n"(kRegT + 3)
+               : [a0] "n"(V), [a1] "n"(V + 1), [a2] "n"(V + 2), [a3] "n"(V + 3), [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2),
+                 [t3] "n"(kRegT + 3)
                : "memory");
 }
 template <int BR>
@@ -383,9 +391,11 @@ template <int BR, int N, int A>
 __device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 vzero, const LdsSplit& sp, u32 ad, const u32* src_next,
                                            const u32 (&voff)[BR]) {
   if constexpr (N <= BR && A <= N) {
-    ldsp_read<BR, 0>();
-    if constexpr (N > 1 && kLdsAhead > 1) ldsp_read<BR, 1>();
-    if constexpr (N > 2 && kLdsAhead > 2) ldsp_read<BR, 2>();
+    ldsp_issue<BR, 0>();   // (the addresses of row 0 were computed in front of the barrier: ldsp_run)
+    if constexpr (N > 1 && kLdsAhead > 1) { ldsp_addr<BR, 1>(); ldsp_issue<BR, 1>(); }
+    if constexpr (N > 2 && kLdsAhead > 2) { ldsp_addr<BR, 2>(); ldsp_issue<BR, 2>(); }
+    // (the header load stays behind the barrier: issued in front of it, with the rest of the prologue, the replay of C4
+    // took 3 % longer -- profiles/r03_tuning_sweeps.txt)
     ldsp_gload_header(hdr_next3, vzero);
     ldsp_rows<BR, N, A, 0>(sp, ad, src_next, voff);
   }
@@ -413,14 +423,24 @@ __device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32
     ldsp_gload_all<BR, 0>(reinterpret_cast<const u32*>(stream + f_cur), voff);
     // the scalar loads above have to be over: none may be in flight below (naming the values orders the loads before)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d_cur), "+s"(f_cur), "+s"(d_nxt), "+s"(f_nxt) : : "memory");
-    for (u32 k = 0; k < run; ++k) {
-      // rows 0 .. kLdsAhead - 1 and the header of block k + 2 (issued a block ago) have arrived
+    // What a block needs before its first LDS read -- the header of the block after next out of its registers, the
+    // pointers of the loads it issues, its split, the addresses of row 0 -- does not depend on the wire table: it is
+    // done for block k + 1 BEHIND the last write of block k and IN FRONT of the barrier, where a wave waits for its
+    // writes anyway.  Behind the barrier every wave of the CU would execute it with nothing to overlap it with.
+    u32 d_n2, f_n2;
+    const u32* hdr_next3;
+    const u32* src_next;
+    auto prepare = [&](u32 k) {
+      // rows 0 .. kLdsAhead - 1 of block k and the header of block k + 2 (issued a block ago) have arrived
       ldsp_wait_row<BR>();
-      u32 d_n2, f_n2;
       asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
-      const u32* hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
-      const u32* src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
+      hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
+      src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
       sp.split = (d_cur >> kLdsBlockSplitShift) & 2047;
+      ldsp_addr<BR, 0>();
+    };
+    prepare(0);
+    for (u32 k = 0; k < run; ++k) {
       if constexpr (A >= 0) {
         ldsp_block<BR, BR, A>(hdr_next3, vzero, sp, 0u, src_next, voff);
       } else {
@@ -433,11 +453,13 @@ __device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32
         }
 #undef ZKGPU_LDS_ANY
       }
-      if ((d_cur >> 4) & 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
+      const u32 barrier = (d_cur >> 4) & 1;
       d_cur = d_nxt;
       f_cur = f_nxt;
       d_nxt = d_n2;
       f_nxt = f_n2;
+      if (k + 1 < run) prepare(k + 1);
+      if (barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
     }
     (void)f_cur;
   }
