@@ -270,6 +270,10 @@ def make_roofline(workload, kernel, launches, kernel_ms_per_step, algo_bytes_per
         res['issue'] = {'achieved': c['issue_ms_per_step'], 'peak': kernel_ms_per_step,
                         'unit': 'ms of instruction issue per step (counted instructions per wave x 4 waves per SIMD x 4 cycles at 2.4 GHz) over ms per step',
                         'frac': c['issue_ms_per_step'] / kernel_ms_per_step, 'insts_per_wave': c.get('insts_per_wave')}
+    if c.get('lds_array_ms_per_step') is not None:
+        res['lds_array'] = {'achieved': c['lds_array_ms_per_step'], 'peak': kernel_ms_per_step,
+                            'unit': 'ms the LDS array of a CU is busy per step (SQ_LDS_IDX_ACTIVE per workgroup at 2.4 GHz) over ms per step',
+                            'frac': c['lds_array_ms_per_step'] / kernel_ms_per_step}
     if not res:
         # no counters for this program: the algorithmic figure against HBM is all there is
         res['hbm_algorithmic'] = {'achieved': algo_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': algo_gbs / HBM_PEAK_GBS}
@@ -279,7 +283,7 @@ def make_roofline(workload, kernel, launches, kernel_ms_per_step, algo_bytes_per
     if bc:
         out['binding'] = bc.get('binding')
         out['counters'] = {k: v for k, v in c.items() if k not in ('traffic_bytes_per_launch', 'traffic_source', 'valu_pipe_ms_per_step',
-                                                                   'issue_ms_per_step', 'memory_side', 'traffic_launches_per_step')}
+                                                                   'issue_ms_per_step', 'lds_array_ms_per_step', 'memory_side', 'traffic_launches_per_step')}
         out['reading'] = bc.get('reading')
         out['sources'] = bc.get('sources')
     else:

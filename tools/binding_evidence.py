@@ -95,6 +95,8 @@ def main():
              'program_bytes_per_workgroup': 6.0 * cfg['backend_ops_per_witness'],   # rows: three u16 per op
              'workgroups': cfg.get('batch_per_gpu', 4096) // 32,
              'waves_parked_frac': lds.get('SQ_WAIT_ANY', 0) / max(lds.get('SQ_WAVE_CYCLES', 1), 1)}
+        # the second candidate: the CU's LDS array (SQ_LDS_IDX_ACTIVE = its busy cycles, summed over the CUs that run a workgroup)
+        c['lds_array_ms_per_step'] = lds.get('SQ_LDS_IDX_ACTIVE', 0) / max(c['workgroups'], 1) / 2.4e9 * 1e3
         sources = ['profiles/%s_pmc_c4_lds_counters.json' % tag]
         if tr4:
             c.update({'memory_side': 'fabric', 'traffic_bytes_per_launch': tr4['traffic_bytes_per_launch'], 'traffic_launches_per_step': 1,
@@ -116,8 +118,11 @@ def main():
             'reading': 'one workgroup = one CU walks the whole program with its 32-witness slice of the wire table in LDS (128 of 256 '
                        'CUs at batch 4096).  A SIMD hands out one issue slot every four cycles and the 16 waves of the workgroup '
                        '(4 per SIMD) fill them: issue = counted instructions per wave (waits, branches and barriers are not in these '
-                       'counters) x 4 waves x 4 cycles at 2.4 GHz; the rest of the kernel time is the drain -> barrier -> refill of '
-                       'the levels.  The wire traffic never leaves the LDS: the fabric bytes are the program, once per XCD, + inputs',
+                       'counters) x 4 waves x 4 cycles at 2.4 GHz -- the figure that has tracked every change of the kernel, up '
+                       'or down (profiles/*_tuning_sweeps.txt); the LDS array itself is busy for lds_array_ms_per_step (14 cycles '
+                       'per row and wave: four 2-cycle reads and the 6-cycle 8-byte store); the rest of the kernel time is the '
+                       'drain -> barrier -> refill of the levels.  The wire traffic never leaves the LDS: the fabric bytes are '
+                       'the program, once per XCD, + inputs',
             'sources': sources, 'collected': {'tag': tag, 'ms_per_step_at_collection': bench['ms_per_step']}})
     # ---- C5
     bench = load(d, '%s_bench_c5.json' % tag)
