@@ -440,7 +440,12 @@ __device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32
       ldsp_addr<BR, 0>();
     };
     prepare(0);
+    // The barrier behind block k stands at the TOP of iteration k + 1: hipcc puts the scalar book-keeping of the loop (the
+    // rotation of the header words, the loop test) at the latch, which is then in front of the barrier and not between
+    // the barrier and the first LDS reads of the next level.  (The last block's barrier is the one that ends the run.)
+    u32 barrier = 0;
     for (u32 k = 0; k < run; ++k) {
+      if (barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
       if constexpr (A >= 0) {
         ldsp_block<BR, BR, A>(hdr_next3, vzero, sp, 0u, src_next, voff);
       } else {
@@ -453,13 +458,12 @@ __device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32
         }
 #undef ZKGPU_LDS_ANY
       }
-      const u32 barrier = (d_cur >> 4) & 1;
+      barrier = (d_cur >> 4) & 1;
       d_cur = d_nxt;
       f_cur = f_nxt;
       d_nxt = d_n2;
       f_nxt = f_n2;
       if (k + 1 < run) prepare(k + 1);
-      if (barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
     }
     (void)f_cur;
   }
