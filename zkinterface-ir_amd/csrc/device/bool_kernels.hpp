@@ -235,6 +235,10 @@ constexpr int kLdsAhead = ZKGPU_LDS_AHEAD;
 constexpr int kRegP = 64, kRegH = 124, kRegT = kRegH - 4;   // kRegT .. + 3: address / result temporaries of a step
 template <int BR> constexpr int kRegV = kRegP + 4 * BR;   // value sets follow the BR rows of program words
 template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1) <= kRegT;
+// Four registers between the value sets and the step temporaries, where a block size leaves them: the LDS addresses of
+// the next block's row 0, computed in the middle of a block (ldsp_run)
+template <int BR> constexpr int kRegU = kRegV<BR> + 4 * (kLdsAhead + 1);
+template <int BR> constexpr bool kLdsEarly = kRegU<BR> + 4 <= kRegT;
 static_assert((kRegT + 2) % 2 == 0, "the two results of a row step are the data of one ds_write_b64: an aligned register pair");
 
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
@@ -244,7 +248,7 @@ static_assert((kRegT + 2) % 2 == 0, "the two results of a row step are the data 
 // workgroup fill them): a row step is two asm statements holding nothing but 7 VALU (five address shifts, two gates),
 // 5 LDS (four reads, one 64-bit write), 1 VMEM and the waits (vmcnt every other row, lgkmcnt every row).  What hipcc makes of a C++ if-chain over the
 // row kind is a dozen scalar instructions and up to five branches per row, and between statements it puts address adds.
-template <int BR, int R>   // the LDS addresses of the four operands of row R, into the step temporaries
+template <int BR, int R, int T0 = kRegT>   // the LDS addresses of the four operands of row R, into v[T0 .. T0 + 3]
 __device__ __forceinline__ void ldsp_addr() {
   constexpr int P = kRegP + 4 * R;
   asm volatile("v_lshlrev_b32_sdwa v[%[t0]], %[two], v[%[ax]]" ZKGPU_SDWA_HI
@@ -252,11 +256,11 @@ __device__ __forceinline__ void ldsp_addr() {
                "v_lshlrev_b32_sdwa v[%[t2]], %[two], v[%[ay]]" ZKGPU_SDWA_LO
                "v_lshlrev_b32_sdwa v[%[t3]], %[two], v[%[az]]" ZKGPU_SDWA_HI
                :
-               : [two] "s"(2u), [ax] "n"(P), [ay] "n"(P + 1), [az] "n"(P + 2), [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2),
-                 [t3] "n"(kRegT + 3)
+               : [two] "s"(2u), [ax] "n"(P), [ay] "n"(P + 1), [az] "n"(P + 2), [t0] "n"(T0), [t1] "n"(T0 + 1), [t2] "n"(T0 + 2),
+                 [t3] "n"(T0 + 3)
                : "memory");
 }
-template <int BR, int R>   // ... and the four reads (block start: rows 0 .. kLdsAhead - 1)
+template <int BR, int R, int T0 = kRegT>   // ... and the four reads (block start: rows 0 .. kLdsAhead - 1)
 __device__ __forceinline__ void ldsp_issue() {
   constexpr int V = kRegV<BR> + 4 * (R % (kLdsAhead + 1));
   asm volatile("ds_read_b32 v[%[a0]], v[%[t0]]\n\t"
@@ -264,8 +268,8 @@ __device__ __forceinline__ void ldsp_issue() {
                "ds_read_b32 v[%[a2]], v[%[t2]]\n\t"
                "ds_read_b32 v[%[a3]], v[%[t3]]"
                :
-               : [a0] "n"(V), [a1] "n"(V + 1), [a2] "n"(V + 2), [a3] "n"(V + 3), [t0] "n"(kRegT), [t1] "n"(kRegT + 1), [t2] "n"(kRegT + 2),
-                 [t3] "n"(kRegT + 3)
+               : [a0] "n"(V), [a1] "n"(V + 1), [a2] "n"(V + 2), [a3] "n"(V + 3), [t0] "n"(T0), [t1] "n"(T0 + 1), [t2] "n"(T0 + 2),
+                 [t3] "n"(T0 + 3)
                : "memory");
 }
 template <int BR>
@@ -370,8 +374,13 @@ __device__ __forceinline__ void ldsp_gload_header(const u32* p, u32 vzero) {   /
 // first A rows are and-rows, row A is the split row, the rest xor-rows; A < 0: `ad` and-rows, known at run time -- every
 // row runs the split row's code with a split that puts all of it on one side (2048: all `and`; 0: all `xor`) unless it
 // is the split row itself.
-template <int BR, int N, int A, int R>
-__device__ __forceinline__ void ldsp_rows(const LdsSplit& sp, u32 ad, const u32* src_next, const u32 (&voff)[BR]) {
+struct LdsNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// HOOK: called once, behind row N - 2 of a full block -- where ldsp_run prepares the NEXT block (its row 0 was fetched by
+// step 0, long ago by then), in the shadow of this block's last LDS waits
+template <int BR, int N, int A, int R, class Hook>
+__device__ __forceinline__ void ldsp_rows(const LdsSplit& sp, u32 ad, const u32* src_next, const u32 (&voff)[BR], Hook&& hook) {
   if constexpr (R < BR) {
     if constexpr (R < N) {
       if constexpr (A < 0) {
@@ -380,24 +389,25 @@ __device__ __forceinline__ void ldsp_rows(const LdsSplit& sp, u32 ad, const u32*
         ldsp_step<BR, N, R, 2>(row, src_next, voff[R]);
       } else {
         ldsp_step<BR, N, R, (R < A ? 0 : (R == A ? 2 : 1))>(sp, src_next, voff[R]);
+        if constexpr (R == N - 2) hook();
       }
     } else {
       ldsp_gload<R>(src_next, voff[R]);
     }
-    ldsp_rows<BR, N, A, R + 1>(sp, ad, src_next, voff);
+    ldsp_rows<BR, N, A, R + 1>(sp, ad, src_next, voff, hook);
   }
 }
-template <int BR, int N, int A>
+template <int BR, int N, int A, int T0 = kRegT, class Hook = LdsNoHook>
 __device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 vzero, const LdsSplit& sp, u32 ad, const u32* src_next,
-                                           const u32 (&voff)[BR]) {
+                                           const u32 (&voff)[BR], Hook&& hook = Hook()) {
   if constexpr (N <= BR && A <= N) {
-    ldsp_issue<BR, 0>();   // (the addresses of row 0 were computed in front of the barrier: ldsp_run)
+    ldsp_issue<BR, 0, T0>();   // (the addresses of row 0 were computed in front of the barrier: ldsp_run)
     if constexpr (N > 1 && kLdsAhead > 1) { ldsp_addr<BR, 1>(); ldsp_issue<BR, 1>(); }
     if constexpr (N > 2 && kLdsAhead > 2) { ldsp_addr<BR, 2>(); ldsp_issue<BR, 2>(); }
     // (the header load stays behind the barrier: issued in front of it, with the rest of the prologue, the replay of C4
     // took 3 % longer -- profiles/r03_tuning_sweeps.txt)
     ldsp_gload_header(hdr_next3, vzero);
-    ldsp_rows<BR, N, A, 0>(sp, ad, src_next, voff);
+    ldsp_rows<BR, N, A, 0>(sp, ad, src_next, voff, hook);
   }
 }
 template <int BR, int R>
@@ -424,46 +434,89 @@ __device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32
     // the scalar loads above have to be over: none may be in flight below (naming the values orders the loads before)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(d_cur), "+s"(f_cur), "+s"(d_nxt), "+s"(f_nxt) : : "memory");
     // What a block needs before its first LDS read -- the header of the block after next out of its registers, the
-    // pointers of the loads it issues, its split, the addresses of row 0 -- does not depend on the wire table: it is
-    // done for block k + 1 BEHIND the last write of block k and IN FRONT of the barrier, where a wave waits for its
-    // writes anyway.  Behind the barrier every wave of the CU would execute it with nothing to overlap it with.
+    // pointers of the loads it issues, its split, the addresses of row 0 -- does not depend on the wire table, and behind
+    // the barrier every wave of the CU would execute it with nothing to overlap it with.
     u32 d_n2, f_n2;
     const u32* hdr_next3;
     const u32* src_next;
-    auto prepare = [&](u32 k) {
-      // rows 0 .. kLdsAhead - 1 of block k and the header of block k + 2 (issued a block ago) have arrived
+    u32 barrier = 0;
+    if constexpr (A >= 0 && kLdsEarly<BR>) {
+      // Full blocks with four spare registers: block k + 1 is prepared in the MIDDLE of block k (behind its row BR - 2, in
+      // the shadow of the LDS waits of its last rows), into variables of its own that take over when block k ends; the
+      // addresses of its row 0 wait in the spare registers.  Nothing but the rotation is left between the last write of a
+      // block and the barrier -- what stands there delays the wave's arrival at the barrier, i.e. the whole CU.
+      constexpr int U = kRegU<BR>;
+      u32 d_n3 = 0, f_n3 = 0, split_n = 0;
+      const u32* hdr_n = hdr;
+      const u32* src_n = reinterpret_cast<const u32*>(stream);
       ldsp_wait_row<BR>();
       asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
-      hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
-      src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
+      hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(3u, last));
+      src_next = reinterpret_cast<const u32*>(stream + f_nxt);
       sp.split = (d_cur >> kLdsBlockSplitShift) & 2047;
-      ldsp_addr<BR, 0>();
-    };
-    prepare(0);
-    // The barrier behind block k stands at the TOP of iteration k + 1: hipcc puts the scalar book-keeping of the loop (the
-    // rotation of the header words, the loop test) at the latch, which is then in front of the barrier and not between
-    // the barrier and the first LDS reads of the next level.  (The last block's barrier is the one that ends the run.)
-    u32 barrier = 0;
-    for (u32 k = 0; k < run; ++k) {
-      if (barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
-      if constexpr (A >= 0) {
-        ldsp_block<BR, BR, A>(hdr_next3, vzero, sp, 0u, src_next, voff);
-      } else {
-        const u32 ad = (d_cur >> kLdsBlockAndShift) & 15;
-#define ZKGPU_LDS_ANY(N) case N: ldsp_block<BR, N, -1>(hdr_next3, vzero, sp, ad, src_next, voff); break;
-        switch (d_cur & 15) {
-          ZKGPU_LDS_ANY(1) ZKGPU_LDS_ANY(2) ZKGPU_LDS_ANY(3) ZKGPU_LDS_ANY(4) ZKGPU_LDS_ANY(5) ZKGPU_LDS_ANY(6)
-          ZKGPU_LDS_ANY(7) ZKGPU_LDS_ANY(8) ZKGPU_LDS_ANY(9) ZKGPU_LDS_ANY(10) ZKGPU_LDS_ANY(11)
-          default: ldsp_block<BR, 12, -1>(hdr_next3, vzero, sp, ad, src_next, voff); break;
-        }
-#undef ZKGPU_LDS_ANY
+      ldsp_addr<BR, 0, U>();
+      for (u32 k = 0; k < run; ++k) {
+        if (barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
+        ldsp_block<BR, BR, A, U>(hdr_next3, vzero, sp, 0u, src_next, voff, [&]() {
+          // block k + 1 (past the last block: the clamped header / offsets of the last one again -- never used).  The
+          // header of block k + 3 (issued at the start of this block) and row 0 of block k + 1 (fetched by step 0) are
+          // older than the BR - 2 youngest loads in flight.
+          asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - 2) : "memory");
+          asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n3), "=s"(f_n3) : "n"(kRegH), "n"(kRegH + 1));
+          hdr_n = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 4, last));
+          src_n = reinterpret_cast<const u32*>(stream + f_n2);
+          split_n = (d_nxt >> kLdsBlockSplitShift) & 2047;
+          ldsp_addr<BR, 0, U>();
+        });
+        barrier = (d_cur >> 4) & 1;
+        d_cur = d_nxt;
+        f_cur = f_nxt;
+        d_nxt = d_n2;
+        f_nxt = f_n2;
+        d_n2 = d_n3;
+        f_n2 = f_n3;
+        hdr_next3 = hdr_n;
+        src_next = src_n;
+        sp.split = split_n;
       }
-      barrier = (d_cur >> 4) & 1;
-      d_cur = d_nxt;
-      f_cur = f_nxt;
-      d_nxt = d_n2;
-      f_nxt = f_n2;
-      if (k + 1 < run) prepare(k + 1);
+    } else {
+      // Otherwise it is done for block k + 1 BEHIND the last write of block k and IN FRONT of the barrier, where a wave
+      // waits for its writes anyway.
+      auto prepare = [&](u32 k) {
+        // rows 0 .. kLdsAhead - 1 of block k and the header of block k + 2 (issued a block ago) have arrived
+        ldsp_wait_row<BR>();
+        asm volatile("v_readfirstlane_b32 %0, v[%2]\n\tv_readfirstlane_b32 %1, v[%3]" : "=s"(d_n2), "=s"(f_n2) : "n"(kRegH), "n"(kRegH + 1));
+        hdr_next3 = hdr + 2 * (size_t)(u32)__builtin_amdgcn_readfirstlane(min(k + 3, last));
+        src_next = reinterpret_cast<const u32*>(stream + f_nxt);   // past the last block: re-reads it (never used)
+        sp.split = (d_cur >> kLdsBlockSplitShift) & 2047;
+        ldsp_addr<BR, 0>();
+      };
+      prepare(0);
+      // The barrier behind block k stands at the TOP of iteration k + 1: hipcc puts the scalar book-keeping of the loop
+      // (the rotation of the header words, the loop test) at the latch, which is then in front of the barrier and not
+      // between the barrier and the first LDS reads of the next level.  (The last block's barrier is the one that ends
+      // the run.)
+      for (u32 k = 0; k < run; ++k) {
+        if (barrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
+        if constexpr (A >= 0) {
+          ldsp_block<BR, BR, A>(hdr_next3, vzero, sp, 0u, src_next, voff);
+        } else {
+          const u32 ad = (d_cur >> kLdsBlockAndShift) & 15;
+#define ZKGPU_LDS_ANY(N) case N: ldsp_block<BR, N, -1>(hdr_next3, vzero, sp, ad, src_next, voff); break;
+          switch (d_cur & 15) {
+            ZKGPU_LDS_ANY(1) ZKGPU_LDS_ANY(2) ZKGPU_LDS_ANY(3) ZKGPU_LDS_ANY(4) ZKGPU_LDS_ANY(5) ZKGPU_LDS_ANY(6)
+            ZKGPU_LDS_ANY(7) ZKGPU_LDS_ANY(8) ZKGPU_LDS_ANY(9) ZKGPU_LDS_ANY(10) ZKGPU_LDS_ANY(11)
+            default: ldsp_block<BR, 12, -1>(hdr_next3, vzero, sp, ad, src_next, voff); break;
+          }
+#undef ZKGPU_LDS_ANY
+        }
+        barrier = (d_cur >> 4) & 1;
+        d_cur = d_nxt;
+        f_cur = f_nxt;
+        d_nxt = d_n2;
+        f_nxt = f_n2;
+        if (k + 1 < run) prepare(k + 1);
+      }
     }
     (void)f_cur;
   }
