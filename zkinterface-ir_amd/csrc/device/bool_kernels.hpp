@@ -217,11 +217,19 @@ __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
 // r of block k + 1 into the registers row r just left, for all BR rows (the kernel's template parameter) whatever the
 // blocks hold -- so "the rows this step reads are there" is always the same vmcnt: one block of program words in flight.
 //
+// A level ends with a barrier, and what stands next to it is the critical path of the whole CU: what a wave executes
+// between its last write and the barrier delays everybody's release, what it executes between the barrier and its first
+// LDS reads runs with an idle LDS.  So the code of a run of blocks is picked once per run (ldsp_run<BR, A>), a block is
+// prepared -- header words, pointers, split, the addresses of its row 0 -- in the middle of the block before it (or, for
+// the block sizes without spare registers, behind that block's last write), and the barrier stands at the top of the
+// loop, behind the loop's own scalar book-keeping (profiles/r03_tuning_sweeps.txt has each of these measured).
+//
 // hipcc cannot be told that a register is waiting for a load: it is free to copy it (at a branch join, say) before the
 // data is there.  So everything that is in flight lives in registers the compiler does not own -- the kernel is
 // compiled for kLdsCompilerVgprs registers (amdgpu_num_vgpr) and the registers above are named in the asm text:
 //   v[kRegP + 4 r .. + 2]  program words of row r: {pair | a0 << 16, b0 | dst1 << 16, a1 | b1 << 16}
 //   v[kRegV + 4 s .. + 3]  operand values a0, a1, b0, b1 of the row in value set s (row r uses set r mod (kLdsAhead + 1))
+//   v[kRegU .. + 3]        (block sizes <= 10) LDS addresses of the operands of the next block's row 0
 //   v[kRegT .. + 3]        address / result temporaries of a row step
 //   v[kRegH .. + 1]        block header in flight
 // No scalar load may be in flight inside a run (they share lgkmcnt with the LDS and return out of order): block headers
