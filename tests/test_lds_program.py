@@ -150,6 +150,33 @@ def test_lds_program_interpreted_matches_the_cpu_checker(block_rows):
     assert got.tolist() == want.tolist()
 
 
+@pytest.mark.parametrize('mix', [(100, 0), (0, 100), (0, 0), (97, 3), (3, 90), (50, 50)])
+def test_row_sequence_of_every_gate_mix(mix):
+    """the row ops of a level are one sequence, its `and` ops first: all `and` (the split at the end of the last row, the
+    padding ops behind it xor-padded), no `and` at all (split 0), nothing but `not`, and mixes whose split falls anywhere"""
+    wl = workloads.BoolLayered(W=5000, D=4, n_instance0=32, n_out=24, seed=0x317 + mix[0], mix=mix)
+    batch = 17
+    inst, wit = wl.inputs(batch)
+    outs = cpu_checkers.bool_layered_outputs(wl, inst, wit)
+    inst = inst.copy()
+    wl.set_expected_outputs(inst, outs, corrupt_every=0)
+    want = np.full(batch, NO_FAIL, dtype=np.uint64)
+    for lane in range(0, batch, 3):
+        inst[lane, wl.n_instance0 + lane % wl.n_out, 0] ^= 1
+        want[lane] = lane % wl.n_out
+    ev = session(wl.relation_messages(), wl.n_instance, wl.n_witness)
+    _, _, consts, _ = ev.schedule_dump()
+    splits = set()
+    for block_rows in (4, 8, 12):
+        prog = ev.lds_program(block_rows)
+        assert interpret(prog, consts, inst[:, :, 0], wit[:, :, 0]).tolist() == want.tolist(), (mix, block_rows)
+        splits |= {(int(d) >> 9) & 2047 for d in prog['blocks'][:, 0]}
+    if mix[0] in (0,):
+        assert splits == {0}
+    if mix == (50, 50):
+        assert len(splits) > 2      # the boundary moves from level to level
+
+
 @pytest.mark.parametrize('name', ['bool_correct', 'bool_incorrect'])
 def test_lds_program_of_the_reference_examples(name):
     """the reference's Boolean example (functions, a for loop, a switch): mostly sequential segments and short rows"""

@@ -28,7 +28,8 @@ for case in range(n_cases):
         os.environ['ZKGPU_LDS_BLOCK_ROWS'] = str(br)
     else:
         os.environ.pop('ZKGPU_LDS_BLOCK_ROWS', None)
-    wl = workloads.BoolLayered(W=W, D=D, n_instance0=n_inst0, n_out=n_out, seed=int(rng.integers(1, 1 << 30)))
+    mix = [(45, 45), (45, 45), (100, 0), (0, 100), (0, 0), (97, 3), (3, 90), (50, 50)][int(rng.integers(0, 8))]
+    wl = workloads.BoolLayered(W=W, D=D, n_instance0=n_inst0, n_out=n_out, seed=int(rng.integers(1, 1 << 30)), mix=mix)
     inst, wit = wl.inputs(batch)
     outs = cpu_checkers.bool_layered_outputs(wl, inst, wit)
     inst = inst.copy()

@@ -172,7 +172,7 @@ class BoolLayered:
     (45 / 45 / 10 %), n_instance0 instance + (W - n_instance0) witness bits, n_out outputs compared by
     {Instance, Xor, AssertZero}.  One byte per input value."""
 
-    def __init__(self, W=16384, D=640, n_instance0=1024, n_out=64, seed=0xB001C4, wiring='random'):
+    def __init__(self, W=16384, D=640, n_instance0=1024, n_out=64, seed=0xB001C4, wiring='random', mix=(45, 45)):
         self.W, self.D, self.n_instance0, self.n_out, self.seed, self.p = W, D, n_instance0, n_out, seed, 2
         self.mod_le = bytes([2])
         self.width = 1
@@ -185,7 +185,9 @@ class BoolLayered:
             h = splitmix64(np.uint64(seed) ^ ((layer << np.uint64(32)) + j))
             h2 = splitmix64(h)
         r = (h >> np.uint64(8)) % np.uint64(100)
-        self.kind = np.where(r < 45, 8, np.where(r < 90, 9, 10)).astype(np.uint8)  # and / xor / not
+        # and / xor / not: `mix` = per cent of and, of xor (the C4 definition: 45 / 45 / 10; other mixes for the tests of the
+        # row layout -- all `and`, no `and`, ...)
+        self.kind = np.where(r < mix[0], 8, np.where(r < mix[0] + mix[1], 9, 10)).astype(np.uint8)
         self.src_a = (h2 % np.uint64(W)).astype(np.uint32)
         self.src_b = ((h2 >> np.uint64(32)) % np.uint64(W)).astype(np.uint32)
         if wiring == 'identity':  # experiment only: gate j reads wires j and j+1 of the previous layer
