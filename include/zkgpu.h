@@ -121,7 +121,9 @@ int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]);
  * launches4 = {first,count,ops_per_wave,sequential} per launch, const_words = constant pool in device form,
  * slot_of[i] = wire-table slot of tape op i (0xFFFFFFFF for asserts).  An operand of and / xor over a field other than
  * GF(2) may be 0x80000000 | (2 + 4 * position + stream) instead of a slot: the raw value of that input (stream 0 instance,
- * 1 witness, 2 carried in), of which the operand is only a copy.  Any pointer may be NULL. */
+ * 1 witness, 2 carried in), of which the operand is only a copy, or (stream 3) of a constant >= the characteristic, which
+ * const_words holds as a plain integer behind the zkgpu_n_constants device-form entries, `position` counting from there.
+ * Any pointer may be NULL. */
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
                         uint32_t* slot_of);
 
@@ -158,8 +160,9 @@ int zkgpu_set_lane_group(zkgpu_session* s, uint32_t lanes);
  *   0xFF  over GF(2) (bit-packed) it feeds both a zero test and a gate -- one bit cannot be `v & 1` and `v != 0` -- or it
  *         was carried over two field changes without passing through a gate: a lane holding a value >= p there is
  *         flagged ZKGPU_LANE_NONCANONICAL and counted as failed, with a violation text that says so.
- * Constants >= p that reach and / xor over another field than GF(2), Evaluator::get, or (GF(2)) a zero test and a gate are
- * refused by zkgpu_finalize.
+ * Constants >= p get the reference's answer the same way (kept in the pool as the integers they are where their bits
+ * are read); zkgpu_finalize refuses one that is wider than the limbs there, and over GF(2) one that feeds a zero test and
+ * a gate.
  * The modes depend on the tape alone, not on options ("stream" windows included). */
 size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size_t cap);
 

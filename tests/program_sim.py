@@ -16,7 +16,7 @@ def is_canonical_field(p):
 
 
 def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances, witnesses, shuffle_seed=None, modes=None,
-             carries=(), canonical=None):
+             carries=(), canonical=None, n_raw_consts=0):
     """Run one lane.  instances / witnesses: python ints.  Returns (slots, first_fail_seq, noncanonical).
     modes = (instance modes, witness modes) as zkgpu_input_modes gives them (how a value >= p is treated per position:
     0xFF flags the lane; GF(2): 0x01 packs `v != 0`); None = every position 0.
@@ -42,7 +42,8 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
     mode_lists = list(modes) if modes is not None else []
     while len(mode_lists) < 3:
         mode_lists.append([])
-    streams = (instances, witnesses, carries)
+    # stream 3 of the source codes: the last n_raw_consts entries of the pool are constants >= p kept as plain integers
+    streams = (instances, witnesses, carries, consts[len(consts) - n_raw_consts:] if n_raw_consts else [])
 
     def mode_of(stream, position):
         m = mode_lists[stream]

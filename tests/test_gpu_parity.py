@@ -266,6 +266,30 @@ def test_unreduced_inputs_get_the_reference_verdict():
     assert ev.get(0, 3) == [5, 106, 2 ** 32 - 1] and ev.get(1, 3) == [5, 106, 2 ** 32 - 1]
     assert ev.get(2, 3) == [25, 25, ((2 ** 32 - 1) ** 2) % 101]
     assert ev.counts() == (3, 0)
+    # a constant >= p: its bits in and / xor (the entry reads it from the pool as the integer it is), Evaluator::get of a copy
+    for p in (101, 2 ** 64 - 2):
+        c = p + 6 if p == 101 else 2 ** 64 - 1
+        neg = sw.int_to_le(p - 1)
+        gates = [('constant', 0, sw.int_to_le(c)), ('witness', 1), ('and', 2, 0, 1), ('copy', 3, 0), ('xor', 4, 3, 1), ('witness', 5), ('witness', 6),
+                 ('mulc', 7, 5, neg), ('add', 8, 2, 7), ('assert_zero', 8), ('mulc', 9, 6, neg), ('add', 10, 4, 9), ('assert_zero', 10),
+                 ('free', 0, 2), ('free', 4, 10)]
+        rel6 = sw.write_relation(sw.int_to_le(p), 'arithmetic,boolean', 'simple', [], gates)
+        ws = [5, 100, p + 9 if p == 101 else 2 ** 63 + 12345, 255, 0]
+        rows_w = [[w, (c & w) % p, (c ^ w) % p] for w in ws] + [[7, (c & 7) % p, ((c ^ 7) + 1) % p]]
+        for retain in (False, True):
+            ev = zk.Evaluator()
+            ev.declare_inputs(0, 3)
+            ev.ingest_message(rel6)
+            ev.finalize(retain_all=retain)
+            _, wit = batch_arrays([[]] * len(rows_w), rows_w, ev.elem_bytes)
+            ev.set_inputs(None, wit, len(rows_w))
+            ev.replay()
+            ev.synchronize()
+            for lane, row in enumerate(rows_w):
+                ref = oracle_lane(sw.int_to_le(p), [], row, [rel6], 8, trace=False)
+                assert ev.get_violations(lane) == ref.violations, (p, retain, lane)
+            assert ev.counts() == (len(rows_w) - 1, 1)
+            assert ev.get(3, len(rows_w)) == [c] * len(rows_w)      # wire 3, a copy of the constant, is alive at the end
     # GF(2): a position only zero tests read is packed as `v != 0` (both kernels)
     rel4 = sw.write_relation(bytes([2]), 'boolean', 'simple', [],
                              [('witness', 0), ('not', 1, 0), ('assert_zero', 1), ('witness', 2), ('copy', 3, 2), ('assert_zero', 3)]

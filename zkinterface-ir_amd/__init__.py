@@ -316,6 +316,12 @@ class Evaluator:
         self._ck(self.L.zkgpu_tape_assert_wires(self.h, out.ctypes.data, n))
         return out[:n]
 
+    @property
+    def n_constants(self):
+        """constants of the (inspected) tape; the pool schedule_dump returns holds, behind their device forms, the raw
+        integers of those whose unreduced bits are read (include/zkgpu.h zkgpu_schedule_dump)"""
+        return int(self.L.zkgpu_n_constants(self.h))
+
     def constants(self):
         out = []
         for i in range(self.L.zkgpu_n_constants(self.h)):

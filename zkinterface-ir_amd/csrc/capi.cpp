@@ -1553,7 +1553,15 @@ int zkgpu_get_wire(zkgpu_session* s, uint64_t wire_id, uint8_t* out) {
       // the wire is an input the relation has only copied: Evaluator::get returns the integer the witness holds, reduced
       // or not (evaluator.rs:750-752, 940-946) -- read it where the caller put it
       const uint32_t q = it->second - 2;
-      if (s->peers.empty()) {
+      if ((q & 3) == 3) {   // a constant >= p: the integer the relation wrote, for every lane
+        const Value& c = s->backend.tape().consts[s->sched.raw_const_of[q >> 2]];
+        size_t n = c.size();
+        while (n > 0 && c[n - 1] == 0) --n;
+        ws = session_elem_bytes(s);
+        if (n > ws) throw std::runtime_error("zkgpu_get_wire: the wire holds a constant wider than zkgpu_elem_bytes");
+        tmp.assign((size_t)s->batch * ws, 0);
+        for (uint32_t lane = 0; lane < s->batch; ++lane) memcpy(&tmp[(size_t)lane * ws], c.data(), n);
+      } else if (s->peers.empty()) {
         s->engine->read_input(q & 3, q >> 2, &tmp, &ws);
       } else {
         std::vector<Engine*> eng = all_engines(s);

@@ -88,7 +88,8 @@ struct InputAux {
   const u32* carry;             // [lane][n_carry][carry_words]: canonical values of the wires carried over from the previous
   u32 n_carry, carry_words;     // field segment (carry_words = that field's N)
   u32 in_stride_words;          // 32-bit words per input value in inst / wit (N, or more in a session of several fields)
-  u32 pad;
+  u32 raw_const_base;           // stream 3 of the source codes: constants >= p whose bits are read, kept as plain integers in
+                                // the constant pool from this entry on (Schedule::raw_const_of)
 };
 
 struct ReplayArgs {

@@ -172,6 +172,11 @@ __device__ __forceinline__ bool g_stream_load(u32 stream, u32 position, const Re
   typedef const InputAux __attribute__((address_space(4))) AuxS;
   AuxS* aux = (AuxS*)(unsigned long long)args.aux;
   for (u32 i = 0; i < n; ++i) out[i] = 0;
+  if (stream == 3) {   // a constant kept as the integer it is (replay_kernels.hpp stream_load)
+    const u32* c = args.consts + (size_t)(aux->raw_const_base + position) * n;
+    for (u32 i = 0; i < n; ++i) out[i] = c[i];
+    return false;
+  }
   if (!valid) return false;
   const u32* base;
   u32 n_vals, stride;

@@ -114,11 +114,19 @@ __device__ __forceinline__ Fp<N> input_load(const void* __restrict__ base, u32 l
   return r;
 }
 
-// the raw value of input stream 0 (instance), 1 (witness) or 2 (carry) at `position`
+// the raw value of input stream 0 (instance), 1 (witness) or 2 (carry) at `position`, or of raw constant `position` (3)
 typedef const InputAux __attribute__((address_space(4))) InputAuxS;   // (scalar loads)
 template <int N, class Args>
 __device__ __forceinline__ Fp<N> stream_load(u32 stream, u32 position, const Args& args, u32 lane_g, bool lane_valid, bool& too_wide) {
   InputAuxS* aux = (InputAuxS*)(unsigned long long)args.aux;
+  if (stream == 3) {   // a constant kept as the integer it is (the same for every lane)
+    Fp<N> r;
+    const u32* c = args.consts + (size_t)(aux->raw_const_base + position) * N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.w[i] = c[i];
+    too_wide = false;
+    return r;
+  }
   if (stream == 2) return input_load<N>(aux->carry, lane_g, aux->n_carry, position, lane_valid, aux->carry_words, too_wide);
   return input_load<N>(stream ? args.wit : args.inst, lane_g, stream ? args.n_wit : args.n_inst, position, lane_valid,
                        aux->in_stride_words, too_wide);

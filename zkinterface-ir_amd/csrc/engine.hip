@@ -199,7 +199,8 @@ void Engine::free_batch() {
 // or input position out of range must be an exception here, never a memory fault on the GPU.
 void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n_witness, uint32_t n_carry) {
   const uint32_t wpc = s.words_per_const ? s.words_per_const : 1;
-  const uint64_t n_consts = s.const_words.size() / wpc;
+  // (arithmetic fields: the pool ends with the raw constants of Schedule::raw_const_of, which only source codes name)
+  const uint64_t n_consts = s.const_words.size() / wpc - (s.boolean_path ? 0 : std::min<uint64_t>(s.raw_const_of.size(), s.const_words.size() / wpc));
   auto fail = [](size_t i, const char* what) {
     throw std::runtime_error("Engine: program entry " + std::to_string(i) + " has " + what + " out of range");
   };
@@ -210,7 +211,8 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
   auto source = [&](size_t i, uint32_t code) {
     if (code < 2) return;
     const uint32_t q = code - 2, stream = q & 3;
-    if (stream > 2 || (q >> 2) >= (stream == 0 ? n_instance : stream == 1 ? n_witness : n_carry)) fail(i, "the input position of its unreduced source");
+    if ((q >> 2) >= (stream == 0 ? n_instance : stream == 1 ? n_witness : stream == 2 ? n_carry : (uint32_t)s.raw_const_of.size()))
+      fail(i, "the input position of its unreduced source");
   };
   auto check = [&](size_t i, uint32_t kind, uint32_t dst, uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t ea,
                    uint32_t eb, uint32_t second, uint32_t dst2, uint32_t c0, uint32_t src) {
@@ -476,6 +478,8 @@ void Engine::set_batch(uint32_t batch) {
     aux.n_carry = n_carry_;
     aux.carry_words = carry_words_;
     aux.in_stride_words = in_stride_ / 4;
+    // (the pool: the tape's constants in device form, then the raw ones)
+    aux.raw_const_base = (uint32_t)(sched_.const_words.size() / std::max<uint32_t>(sched_.words_per_const, 1) - sched_.raw_const_of.size());
     if (!d_input_aux_) HIP_OK(hipMalloc(&d_input_aux_, sizeof aux));
     HIP_OK(hipMemcpy(d_input_aux_, &aux, sizeof aux, hipMemcpyHostToDevice));
   }

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -160,7 +161,8 @@ struct StreamScheduler::Impl {
   // copy, kInf for everything an arithmetic gate has produced -- and what the source is
   std::vector<uint32_t> src_root;
   std::vector<uint8_t> src_kind;         // per handle: TK_CONST / TK_INSTANCE / TK_WITNESS for sources, 0 otherwise
-  std::vector<uint32_t> src_pos;         // per source handle: input position, or 1 for a constant >= p (0: canonical)
+  std::vector<uint32_t> src_pos;         // per source handle: input position; a constant: 0 canonical, 1 + its pool index if >= p
+  std::map<uint32_t, uint32_t> raw_const_index;   // constant pool index -> position in Schedule::raw_const_of
   std::vector<uint8_t> src_zero_test, src_other;   // per source handle: read by assert_zero / not through copies; by anything else
   std::vector<uint8_t> src_bits;         // per source handle: its raw bits are an operand of and / xor (through copies)
   std::vector<uint32_t> opnd_code[2];    // window: per and / xor op and operand, the input it is a copy of (sink_code's codes), or 0
@@ -236,6 +238,15 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
   opnd_code[0].assign(n, 0);
   opnd_code[1].assign(n, 0);
   auto code_of = [&](uint32_t r) {
+    if (src_kind[r] == TK_CONST) {   // a constant >= p whose bits are read: stream 3, its raw entry in the pool
+      const uint32_t c = src_pos[r] - 1;
+      auto it = raw_const_index.find(c);
+      if (it == raw_const_index.end()) {
+        it = raw_const_index.emplace(c, (uint32_t)s.raw_const_of.size()).first;
+        s.raw_const_of.push_back(c);
+      }
+      return 2u + 4u * it->second + 3u;
+    }
     return 2u + 4u * src_pos[r] + (src_kind[r] == TK_INSTANCE ? 0u : src_kind[r] == TK_WITNESS ? 1u : 2u);
   };
   for (uint32_t i = lo; i < hi; ++i) {
@@ -244,7 +255,7 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
     if (k == TK_CONST || k == TK_INSTANCE || k == TK_WITNESS || k == TK_CARRY) {
       src_root[i] = i;
       src_kind[i] = k;
-      src_pos[i] = k == TK_CONST ? (b != 0 ? 1u : 0u) : a;   // tape: b != 0 marks a constant that is not canonical
+      src_pos[i] = k == TK_CONST ? (b != 0 ? 1u + a : 0u) : a;   // tape: b != 0 marks a constant that is not canonical
       continue;
     }
     if (k == TK_COPY) {
@@ -259,13 +270,12 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
       if (k == TK_ASSERT || k == TK_NOT) {
         src_zero_test[r] = 1;
         sink_code[i - lo] = src_kind[r] == TK_CONST ? (src_pos[r] ? 1u : 0u) : code_of(r);
-      } else if (bit_op && src_kind[r] != TK_CONST) {
-        // the entry reads the raw input instead of the wire (device/replay_kernels.hpp bit_operand)
+      } else if (bit_op && (src_kind[r] != TK_CONST || src_pos[r])) {
+        // the entry reads the raw input (or the raw constant) instead of the wire (device/replay_kernels.hpp bit_operand)
         src_bits[r] = 1;
         opnd_code[q][i - lo] = code_of(r);
       } else {
         src_other[r] = 1;
-        if (bit_op) refuse_unreduced(r, "and / xor");
       }
     }
   }
@@ -273,13 +283,13 @@ void StreamScheduler::Impl::track_unreduced_values(const TapeWindow& w) {
     for (uint32_t h : *w.pinned) {
       if (h >= hi || src_root[h] == kInf) continue;
       const uint32_t r = src_root[h];
-      if (opt.pinned_are_carried || src_kind[r] == TK_CONST) {
+      if (src_kind[r] == TK_CONST && !src_pos[r]) continue;   // a canonical constant: the wire table holds it as it is
+      if (opt.pinned_are_carried) {
         // The next field segment takes the value from the wire table, which holds the residue (capi.cpp switch_field
         // re-reads inputs and constants under the new field itself: what is left here is a value carried in and only
-        // copied); a constant alive at the end: Evaluator::get would return the integer as it is.
+        // copied).
         src_other[r] = 1;
-        refuse_unreduced(r, opt.pinned_are_carried ? "the next field segment (carried over twice without passing through a gate)"
-                                                   : "Evaluator::get (a wire alive at the end)");
+        refuse_unreduced(r, "the next field segment (carried over twice without passing through a gate)");
       } else {
         // Evaluator::get returns the integer as it is (evaluator.rs:750-752): zkgpu_get_wire reads the input itself
         src_bits[r] = 1;
@@ -1274,6 +1284,19 @@ Schedule StreamScheduler::finish(const std::vector<Value>& consts) {
       m.field.reduce(consts[i], r);
       m.field.to_mont(r, mont);
       memcpy(&s.const_words[(size_t)i * m.field.nwords], mont, 4 * m.field.nwords);
+    }
+    // the constants whose unreduced bits are read, as the integers they are (Schedule::raw_const_of)
+    for (uint32_t c : s.raw_const_of) {
+      const Value& v = consts[c];
+      size_t n = v.size();
+      while (n > 0 && v[n - 1] == 0) --n;
+      if (n > 4 * (size_t)m.field.nwords)
+        throw Error("GPU backend: a constant wider than the field's limbs reaches and / xor or Evaluator::get without passing "
+                    "through an arithmetic gate; the reference works on the unreduced integer there (evaluator.rs:750-752,924-933) "
+                    "and this path cannot hold it");
+      std::vector<uint32_t> wds(m.field.nwords, 0);
+      for (size_t b = 0; b < n; ++b) wds[b / 4] |= (uint32_t)v[b] << (8 * (b % 4));
+      s.const_words.insert(s.const_words.end(), wds.begin(), wds.end());
     }
   }
   return std::move(s);

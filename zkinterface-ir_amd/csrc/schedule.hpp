@@ -80,6 +80,11 @@ struct Schedule {
   // (evaluator.rs:750-752), so zkgpu_get_wire reads the input, not the wire table.  (tape handle, 2 + 4 * position + stream),
   // sorted by handle.
   std::vector<std::pair<uint32_t, uint32_t>> raw_source;
+  // Constants >= p whose unreduced bits are read (and / xor over a field other than GF(2), Evaluator::get): the tape's
+  // constant indices, in the order of the RAW entries the constant pool holds behind its device-form entries
+  // (const_words: n_consts device-form constants, then these as plain little-endian integers of words_per_const words);
+  // stream 3 of the source codes names them by their position here.
+  std::vector<uint32_t> raw_const_of;
   std::vector<uint32_t> strand_level_ptr;  // level bounds of the strands (see Launch::level_ptr)
   std::vector<uint64_t> window_first_op;   // per window: index of its first program entry (+ a final end marker)
   uint32_t n_slots = 0;
