@@ -310,6 +310,24 @@ def test_unreduced_inputs_get_the_reference_verdict():
             ref = oracle_lane(bytes([2]), [], row, [rel4], 1, trace=False)
             assert ev.get_violations(lane) == ref.violations, (path, lane)
         assert ev.counts() == (3, 2)
+    # GF(2), Evaluator::get: a wire alive at the end that is a copy of an input returns the byte the witness holds, and a
+    # constant 2 alive at the end the integer 2 (the table itself holds one bit per witness)
+    rel7 = sw.write_relation(bytes([2]), 'boolean', 'simple', [],
+                             [('witness', 0), ('copy', 1, 0), ('witness', 2), ('xor', 3, 0, 2), ('constant', 4, bytes([2])), ('copy', 5, 4)])
+    for path in ('hbm', 'lds'):
+        ev = zk.Evaluator()
+        ev.set_option('bool_path', path)
+        ev.declare_inputs(0, 2)
+        ev.ingest_message(rel7)
+        ev.finalize()
+        _, wit = batch_arrays([[]] * 4, [[1, 0], [3, 1], [0, 0], [254, 1]], 1)
+        ev.set_inputs(None, wit, 4)
+        ev.replay()
+        ev.synchronize()
+        assert ev.get(1, 4) == [1, 3, 0, 254] and ev.get(0, 4) == [1, 3, 0, 254], path
+        assert ev.get(3, 4) == [1, 0, 0, 1], path          # (w0 ^ w2) % 2 on the integers: the low bits
+        assert ev.get(5, 4) == [2, 2, 2, 2], path
+        assert ev.counts() == (4, 0)
 
 
 def _layered_session(wl, batch, lane_group=0):
