@@ -73,10 +73,6 @@ def interpret(prog, consts, inst_bits, wit_bits):
                 shape = (flags >> 11) & 15     # of the run: full blocks with that many and-rows, or 15 = anything
                 assert shape == 15 or (n == br and n_and == shape), 'the code of the run would execute other gates'
                 assert shape != 15 or n < br or n_and > 12
-                if flags & (1 << 15):   # a run without headers: whole-level full blocks that follow each other in the stream
-                    assert n == br and desc & 16 and shape != 15
-                    if blk > first_w:
-                        assert off == int(blocks[blk - 1, 1]) + br * ROW * 6, 'the blocks of a header-less run are not contiguous'
                 assert n_and <= n and split < ROW and (n_and < n or split == 0), 'a split behind the last row of the block'
                 assert (off // 2) + br * ROW * 3 <= len(rows), 'a block fetches block_rows rows: they must lie in the stream'
                 for r in range(n):
@@ -85,9 +81,6 @@ def interpret(prog, consts, inst_bits, wit_bits):
                     # the even op of a thread names the slot PAIR (dst / 2): the thread stores its two results with one
                     # ds_write_b64, so the odd op's slot must be the other half of that pair
                     dst[0::2] *= 2
-                    if r == n_and:     # the split row: its odd ops carry the split in their dst field (lds_layout.hpp)
-                        assert (dst[1::2] == split).all(), 'the split row does not carry its split'
-                        dst[1::2] = dst[0::2] + 1
                     assert np.array_equal(dst[1::2], dst[0::2] + 1), 'the two results of a thread are not one aligned slot pair'
                     assert dst.max() < real + 32 and a.max() < words and b.max() < words
                     assert real % 2 == 0, 'the scratch slots start at an even slot'

@@ -308,11 +308,8 @@ struct LdsSplit {
   u32 wpos1;   // 2 * threadIdx.x + 1
 };
 
-// NOHDR: a run without header loads (ldsp_run_whole_levels) -- one load less is in flight between the rows of a block and
-// the rows of the next, so the same rows have arrived one count earlier
-template <int BR, int N, int R, int KIND, bool NOHDR = false>
+template <int BR, int N, int R, int KIND>
 __device__ __forceinline__ void ldsp_step(const LdsSplit& sp, const u32* src_next, u32 voff) {
-  static_assert(NOHDR == (KIND == 3) || KIND < 2, "the split row of a run without headers carries its split");
   constexpr int S = kLdsAhead + 1;
   constexpr int P = kRegP + 4 * R, V = kRegV<BR> + 4 * (R % S);
   constexpr int w = R < kLdsAhead ? R : kLdsAhead;                              // writes (one per row) behind the reads of row R
@@ -321,7 +318,7 @@ __device__ __forceinline__ void ldsp_step(const LdsSplit& sp, const u32* src_nex
   if constexpr (R + kLdsAhead < N) {
     constexpr int A = R + kLdsAhead, PA = kRegP + 4 * A, VA = kRegV<BR> + 4 * (A % S);
     // program words of rows A and A + 1 have arrived: one vmcnt wait per two rows
-    constexpr int vm = BR - kLdsAhead - 1 - (NOHDR ? 1 : 0);
+    constexpr int vm = BR - kLdsAhead - 1;
 #define ZKGPU_LDS_STEP_AHEAD_OPERANDS                                                                                      \
   :                                                                                                                        \
   : [two] "s"(2u), [three] "s"(3u), [vm] "n"(vm), [lg] "n"(lg), [ax] "n"(PA), [ay] "n"(PA + 1), [az] "n"(PA + 2), [a0] "n"(VA),              \
@@ -354,21 +351,6 @@ __device__ __forceinline__ void ldsp_step(const LdsSplit& sp, const u32* src_nex
     asm volatile(ZKGPU_LDS_STEP_GATES("v_and_b32") ZKGPU_LDS_STEP_WRITE : : ZKGPU_LDS_STEP_TAIL_OPERANDS : "memory");
   } else if constexpr (KIND == 1) {
     asm volatile(ZKGPU_LDS_STEP_GATES("v_xor_b32") ZKGPU_LDS_STEP_WRITE : : ZKGPU_LDS_STEP_TAIL_OPERANDS : "memory");
-  } else if constexpr (KIND == 3) {
-    // the split row of a run without headers: the split sits in the dst field of the row's odd ops (lds_layout.hpp),
-    // the upper half of the second program word -- compared as it is (SDWA)
-    asm volatile("v_and_b32 v[%[t2]], v[%[v0]], v[%[v2]]\n\t"
-                 "v_xor_b32 v[%[t1]], v[%[v0]], v[%[v2]]\n\t"
-                 "v_cmp_gt_u32_sdwa vcc, v[%[py]], %[wpos] src0_sel:WORD_1 src1_sel:DWORD\n\t"
-                 "v_cndmask_b32 v[%[t2]], v[%[t1]], v[%[t2]], vcc\n\t"
-                 "v_and_b32 v[%[t3]], v[%[v1]], v[%[v3]]\n\t"
-                 "v_xor_b32 v[%[t1]], v[%[v1]], v[%[v3]]\n\t"
-                 "v_cmp_gt_u32_sdwa vcc, v[%[py]], %[wpos1] src0_sel:WORD_1 src1_sel:DWORD\n\t"
-                 "v_cndmask_b32 v[%[t3]], v[%[t1]], v[%[t3]], vcc\n\t"
-                 ZKGPU_LDS_STEP_WRITE
-                 :
-                 : [py] "n"(P + 1), [wpos] "v"(sp.wpos), [wpos1] "v"(sp.wpos1), ZKGPU_LDS_STEP_TAIL_OPERANDS
-                 : "memory", "vcc");
   } else {
     asm volatile("v_and_b32 v[%[t2]], v[%[v0]], v[%[v2]]\n\t"
                  "v_xor_b32 v[%[t1]], v[%[v0]], v[%[v2]]\n\t"
@@ -405,7 +387,7 @@ struct LdsNoHook {
 };
 // HOOK: called once, behind row N - 2 of a full block -- where ldsp_run prepares the NEXT block (its row 0 was fetched by
 // step 0, long ago by then), in the shadow of this block's last LDS waits
-template <int BR, int N, int A, int R, class Hook, bool NOHDR = false>
+template <int BR, int N, int A, int R, class Hook>
 __device__ __forceinline__ void ldsp_rows(const LdsSplit& sp, u32 ad, const u32* src_next, const u32 (&voff)[BR], Hook&& hook) {
   if constexpr (R < BR) {
     if constexpr (R < N) {
@@ -414,13 +396,13 @@ __device__ __forceinline__ void ldsp_rows(const LdsSplit& sp, u32 ad, const u32*
         row.split = (u32)R < ad ? (u32)kLdsRowOps : ((u32)R == ad ? sp.split : 0u);
         ldsp_step<BR, N, R, 2>(row, src_next, voff[R]);
       } else {
-        ldsp_step<BR, N, R, (R < A ? 0 : (R == A ? (NOHDR ? 3 : 2) : 1)), NOHDR>(sp, src_next, voff[R]);
+        ldsp_step<BR, N, R, (R < A ? 0 : (R == A ? 2 : 1))>(sp, src_next, voff[R]);
         if constexpr (R == N - 2) hook();
       }
     } else {
       ldsp_gload<R>(src_next, voff[R]);
     }
-    ldsp_rows<BR, N, A, R + 1, Hook, NOHDR>(sp, ad, src_next, voff, hook);
+    ldsp_rows<BR, N, A, R + 1>(sp, ad, src_next, voff, hook);
   }
 }
 template <int BR, int N, int A, int T0 = kRegT, class Hook = LdsNoHook>
@@ -548,37 +530,6 @@ __device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32
   }
 }
 
-// A run of full blocks that are whole levels each, with A and-rows every one (chunk flag kLdsChunkNoHeaders; block sizes
-// with spare registers): nothing about a block has to be looked up -- the blocks follow each other in the stream, the
-// barrier stands behind every one, the split row carries its split -- so there is no header load, no header word in
-// scalar registers, no rotation: per block one pointer addition, and the addresses of the next block's row 0 in the
-// middle of the block as in ldsp_run.
-template <int BR, int A>
-__device__ __forceinline__ void ldsp_run_whole_levels(const BoolLdsArgs& args, u32 first, u32 run, const LdsSplit& sp, const u32 (&voff)[BR]) {
-  if constexpr (A <= BR && kLdsEarly<BR>) {
-    constexpr int U = kRegU<BR>;
-    const u32* hdr = args.blocks + 2 * (size_t)first;
-    u32 f_cur = lds_sload(hdr, 1);
-    const char* stream = reinterpret_cast<const char*>(args.ops6);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(f_cur) : : "memory");   // (no scalar load may be in flight below)
-    const char* src = stream + f_cur;
-    ldsp_gload_all<BR, 0>(reinterpret_cast<const u32*>(src), voff);
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - 1) : "memory");    // row 0 has arrived
-    ldsp_addr<BR, 0, U>();
-    for (u32 k = 0; k < run; ++k) {
-      if (k) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // does not drain vmcnt
-      src += (size_t)BR * kLdsRowOps * 6;   // the rows the steps fetch: the next block's (behind the last block: whatever
-                                            // follows in the stream, at worst the slack rows at its end -- never used)
-      ldsp_issue<BR, 0, U>();
-      auto hook = [&]() {
-        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(BR - 2) : "memory");   // row 0 of the next block (fetched by step 0)
-        ldsp_addr<BR, 0, U>();
-      };
-      ldsp_rows<BR, BR, A, 0, decltype(hook)&, true>(sp, 0u, reinterpret_cast<const u32*>(src), voff, hook);
-    }
-  }
-}
-
 // BR: rows every block fetches (the host picks the instantiation that fetches least for the program at hand)
 template <int BR>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVgprs))) void bool_lds_kernel(const BoolLdsArgs args) {
@@ -644,20 +595,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
     sp.split = 0;
     sp.wpos = 2 * tid;
     sp.wpos1 = 2 * tid + 1;
-    if constexpr (kLdsEarly<BR>) {
-      if (flags & kLdsChunkNoHeaders) {
-#define ZKGPU_LDS_WHOLE(A) case A: ldsp_run_whole_levels<BR, A>(args, first, run, sp, voff); break;
-        switch ((flags >> kLdsChunkAndShift) & 15) {
-          ZKGPU_LDS_WHOLE(0) ZKGPU_LDS_WHOLE(1) ZKGPU_LDS_WHOLE(2) ZKGPU_LDS_WHOLE(3) ZKGPU_LDS_WHOLE(4) ZKGPU_LDS_WHOLE(5) ZKGPU_LDS_WHOLE(6)
-          ZKGPU_LDS_WHOLE(7) ZKGPU_LDS_WHOLE(8) ZKGPU_LDS_WHOLE(9) ZKGPU_LDS_WHOLE(10)
-          default: break;
-        }
-#undef ZKGPU_LDS_WHOLE
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-        continue;
-      }
-    }
     switch ((flags >> kLdsChunkAndShift) & 15) {
       ZKGPU_LDS_RUN(0) ZKGPU_LDS_RUN(1) ZKGPU_LDS_RUN(2) ZKGPU_LDS_RUN(3) ZKGPU_LDS_RUN(4) ZKGPU_LDS_RUN(5) ZKGPU_LDS_RUN(6)
       ZKGPU_LDS_RUN(7) ZKGPU_LDS_RUN(8) ZKGPU_LDS_RUN(9) ZKGPU_LDS_RUN(10) ZKGPU_LDS_RUN(11) ZKGPU_LDS_RUN(12)

@@ -25,14 +25,12 @@ struct LdsOp {  // 8-byte program entry of a generic chunk; wide fields are spli
 // `and`, its other ops `xor` (thread t of the workgroup executes ops 2 t and 2 t + 1 of a row), and the rows behind it are
 // xor-rows.  A run of blocks (one chunk) holds either full blocks with one and the same A -- chunk flags bits
 // kLdsChunkAndShift.. = A, the kernel's code for the run knows every row's kind but the split row's -- or blocks of any
-// shape (15).  The ODD ops of a split row hold the split in their dst field (the kernel never reads an odd op's dst: its
-// result is the other half of the even op's pair), and the blocks of a run follow each other in ops6: a run of full
-// blocks that are whole levels each (kLdsChunkNoHeaders: a barrier behind every block) is replayed without its headers.
+// shape (15).
 constexpr int kLdsRowOps = 2048;
 constexpr int kLdsMaxBlockRows = 12;   // block_rows: 4, 6, 8, 9, 10 or 12 (one kernel instantiation each)
 constexpr int kLdsBlockAndShift = 5, kLdsBlockSplitShift = 9;   // 4 and 11 bits
 constexpr int kLdsChunkAndShift = 11;                            // 4 bits of the chunk's flags word
 constexpr uint32_t kLdsScratchSlots = 32, kLdsZeroSlot = 32, kLdsOnesSlot = 33, kLdsExtraSlots = 34;   // offsets past the real slots
-constexpr uint32_t kLdsChunkBarrier = 1u << 8, kLdsChunkSequential = 1u << 9, kLdsChunkBlocks = 1u << 10, kLdsChunkNoHeaders = 1u << 15;
+constexpr uint32_t kLdsChunkBarrier = 1u << 8, kLdsChunkSequential = 1u << 9, kLdsChunkBlocks = 1u << 10;
 
 }  // namespace zkgpu

@@ -105,11 +105,7 @@ LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& blo
       blocks.push_back((uint32_t)byte_offset);
       // consecutive blocks of one shape form one run (one chunk): full blocks with the same number of and-rows, whose
       // code the kernel picks once per run, or anything else
-      // ... and where each of those blocks is a whole level (a barrier behind every one) the kernel needs no headers at all
-      // (kLdsChunkNoHeaders: the blocks of a run follow each other in the stream, the split travels in the split row)
-      const bool whole_level = n == block_rows && rows == block_rows;
-      const uint32_t flags = zkgpu::kLdsChunkBlocks | ((n == block_rows ? a : 15u) << zkgpu::kLdsChunkAndShift) |
-                             (whole_level ? zkgpu::kLdsChunkNoHeaders : 0u);
+      const uint32_t flags = zkgpu::kLdsChunkBlocks | ((n == block_rows ? a : 15u) << zkgpu::kLdsChunkAndShift);
       if (ln.size() >= 4 && ln[ln.size() - 2] == flags && ln[ln.size() - 4] + ln[ln.size() - 1] == id)
         ++ln[ln.size() - 1];
       else
@@ -179,14 +175,6 @@ LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& blo
       if ((d0 & 1) || d1 != d0 + 1)
         throw std::runtime_error("Engine: the results of a row are not allocated as aligned slot pairs (scheduler / LDS program mismatch)");
       d0 = (unsigned short)(d0 >> 1);
-    }
-    // The split row carries its split itself: in the dst field of its ODD ops, which the kernel does not read (the odd
-    // op's result is the other half of the even op's pair).  A run of whole-level blocks is replayed without headers.
-    {
-      const size_t split_row = n_and / zkgpu::kLdsRowOps, split = n_and % zkgpu::kLdsRowOps;
-      if (split_row < n / zkgpu::kLdsRowOps)
-        for (size_t q = split_row * zkgpu::kLdsRowOps + 1; q < (split_row + 1) * zkgpu::kLdsRowOps; q += 2)
-          lo6[seq_start + 3 * q] = (unsigned short)split;
     }
     emit_blocks(first_record, (uint32_t)(n / zkgpu::kLdsRowOps), n_and);
   }
