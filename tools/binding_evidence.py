@@ -118,10 +118,13 @@ def main():
             'reading': 'one workgroup = one CU walks the whole program with its 32-witness slice of the wire table in LDS (128 of 256 '
                        'CUs at batch 4096).  A SIMD hands out one issue slot every four cycles and the 16 waves of the workgroup '
                        '(4 per SIMD) fill them: issue = counted instructions per wave (waits, branches and barriers are not in these '
-                       'counters) x 4 waves x 4 cycles at 2.4 GHz -- the figure that has tracked every change of the kernel, up '
-                       'or down (profiles/*_tuning_sweeps.txt); the LDS array itself is busy for lds_array_ms_per_step (14 cycles '
-                       'per row and wave: four 2-cycle reads and the 6-cycle 8-byte store); the rest of the kernel time is the '
-                       'drain -> barrier -> refill of the levels.  The wire traffic never leaves the LDS: the fabric bytes are '
+                       'counters) x 4 waves x 4 cycles at 2.4 GHz -- the figure that tracked the changes of rows per level and of '
+                       'the code next to the barrier (profiles/*_tuning_sweeps.txt); the LDS array itself is busy for '
+                       'lds_array_ms_per_step (14 cycles per row and wave: four 2-cycle reads and the 6-cycle 8-byte store).  The '
+                       'two are not independent: taking about 14 instructions per level out of the MIDDLE of the blocks (runs '
+                       'without headers, r03_tuning_sweeps.txt) changed nothing -- there the waves wait for the LDS, which in '
+                       'the steady state of a level is about 85 % busy -- while instructions next to a level\'s barrier cost their '
+                       'full issue time: the rest of the kernel time is the drain -> barrier -> refill of the levels.  The wire traffic never leaves the LDS: the fabric bytes are '
                        'the program, once per XCD, + inputs',
             'sources': sources, 'collected': {'tag': tag, 'ms_per_step_at_collection': bench['ms_per_step']}})
     # ---- C5
