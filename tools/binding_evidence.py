@@ -120,12 +120,13 @@ def main():
                        '(4 per SIMD) fill them: issue = counted instructions per wave (waits, branches and barriers are not in these '
                        'counters) x 4 waves x 4 cycles at 2.4 GHz -- the figure that tracked the changes of rows per level and of '
                        'the code next to the barrier (profiles/*_tuning_sweeps.txt); the LDS array itself is busy for '
-                       'lds_array_ms_per_step (14 cycles per row and wave: four 2-cycle reads and the 6-cycle 8-byte store).  The '
+                       'lds_array_ms_per_step (14 cycles per row and wave: four 2-cycle reads and the 6-cycle 8-byte store).  '
                        'At the margin neither moves the time any more (r03_tuning_sweeps.txt): about 14 instructions per level less in the '
                        'MIDDLE of the blocks (runs without headers) changed nothing, and neither did 5 % fewer LDS array cycles (the '
                        'leftover ops of a run spread over the banks: conflicts 13 % -> 9 % of the cycles).  What is left is '
                        'latency: a row\'s operand reads must be back before its gates (one row ahead; two measured slower), and '
-                       'around a level\'s barrier instructions cost their 'full issue time: the rest of the kernel time is the drain -> barrier -> refill of the levels.  The wire traffic never leaves the LDS: the fabric bytes are '
+                       'around a level\'s barrier instructions cost their full issue time: the rest of the kernel time is the drain -> '
+                       'barrier -> refill of the levels.  The wire traffic never leaves the LDS: the fabric bytes are '
                        'the program, once per XCD, + inputs',
             'sources': sources, 'collected': {'tag': tag, 'ms_per_step_at_collection': bench['ms_per_step']}})
     # ---- C5
