@@ -123,10 +123,10 @@ def main():
                        'lds_array_ms_per_step (14 cycles per row and wave: four 2-cycle reads and the 6-cycle 8-byte store).  '
                        'At the margin neither moves the time any more (r03_tuning_sweeps.txt): about 14 instructions per level less in the '
                        'MIDDLE of the blocks (runs without headers) changed nothing, and neither did 5 % fewer LDS array cycles (the '
-                       'leftover ops of a run spread over the banks: conflicts 13 % -> 9 % of the cycles).  What is left is '
-                       'latency: a row\'s operand reads must be back before its gates (one row ahead; two measured slower), and '
-                       'around a level\'s barrier instructions cost their full issue time: the rest of the kernel time is the drain -> '
-                       'barrier -> refill of the levels.  The wire traffic never leaves the LDS: the fabric bytes are '
+                       'leftover ops of a run spread over the banks: conflicts 13 % -> 9 % of the cycles); timing-only variants without '
+                       'the LDS write, with half the reads or a third of the program bytes take the same time.  Against the '
+                       'width of a level: 0.39 us per level (drain -> barrier -> ramp) + 0.096 us per row (the dependent chain of a '
+                       'row step, four waves per SIMD).  The wire traffic never leaves the LDS: the fabric bytes are '
                        'the program, once per XCD, + inputs',
             'sources': sources, 'collected': {'tag': tag, 'ms_per_step_at_collection': bench['ms_per_step']}})
     # ---- C5
