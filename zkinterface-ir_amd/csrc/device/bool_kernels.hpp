@@ -246,7 +246,9 @@ template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1)
 // Four registers between the value sets and the step temporaries, where a block size leaves them: the LDS addresses of
 // the next block's row 0, computed in the middle of a block (ldsp_run)
 template <int BR> constexpr int kRegU = kRegV<BR> + 4 * (kLdsAhead + 1);
-template <int BR> constexpr bool kLdsEarly = kRegU<BR> + 4 <= kRegT;
+// (one row of reads ahead only: with more, a block's start also needs the program words of its later rows, which the
+// wait in the middle of the block before it does not cover)
+template <int BR> constexpr bool kLdsEarly = kLdsAhead == 1 && kRegU<BR> + 4 <= kRegT;
 static_assert((kRegT + 2) % 2 == 0, "the two results of a row step are the data of one ds_write_b64: an aligned register pair");
 
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
