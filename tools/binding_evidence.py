@@ -12,6 +12,10 @@ import json
 import os
 import sys
 
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
 # sustained issue rates on this chip, T lane-ops/s (profiles/r01_valu_rates.txt, tools/valu_rates.hip)
 RATE_MAD, RATE_ADDC, RATE_OTHER = 26.6, 67.9, 35.0
 
@@ -24,12 +28,15 @@ def load(d, name):
 
 
 def dump(d, name, obj):
+    # the kernel / scheduler sources the counters were collected on: run this script on the tree that was profiled
+    # (tools/collect_profiles.sh does, on the GPU box, right behind the --pmc passes)
+    obj['device_source_digest'] = entry.device_source_digest()
     json.dump(obj, open(os.path.join(d, name), 'w'), indent=1)
 
 
 def main():
     d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles')
-    tag = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+    tag = sys.argv[2] if len(sys.argv) > 2 else 'r04'
     # ---- C2 (headline batch: the wire table sits in the Infinity Cache) and its 4096-lane variant (HBM)
     bench = load(d, '%s_bench_c2.json' % tag)
     tr = load(d, 'pmc_traffic_latest.json')
@@ -96,7 +103,7 @@ def main():
              'workgroups': cfg.get('batch_per_gpu', 4096) // 32,
              'waves_parked_frac': lds.get('SQ_WAIT_ANY', 0) / max(lds.get('SQ_WAVE_CYCLES', 1), 1)}
         # the second candidate: the CU's LDS array (SQ_LDS_IDX_ACTIVE = its busy cycles, summed over the CUs that run a workgroup)
-        c['lds_array_ms_per_step'] = lds.get('SQ_LDS_IDX_ACTIVE', 0) / max(c['workgroups'], 1) / 2.4e9 * 1e3
+        c['lds_array_cycles_per_step'] = lds.get('SQ_LDS_IDX_ACTIVE', 0)   # all LDS-array cycles of one replay, summed over the CUs
         sources = ['profiles/%s_pmc_c4_lds_counters.json' % tag]
         if tr4:
             c.update({'memory_side': 'fabric', 'traffic_bytes_per_launch': tr4['traffic_bytes_per_launch'], 'traffic_launches_per_step': 1,
@@ -107,27 +114,19 @@ def main():
             per_wave = sum(sq4.get(k, 0) for k in keys) / sq4['SQ_WAVES']
             c['insts_per_wave'] = per_wave
             c['instructions_per_wave'] = {k: sq4.get(k, 0) / sq4['SQ_WAVES'] for k in keys}
-            c['issue_ms_per_step'] = per_wave * 4 * 4 / 2.4e9 * 1e3   # 4 waves per SIMD, one slot per SIMD every 4 cycles, 2.4 GHz
             sources.append('profiles/%s_pmc_c4_sq_counters.json' % tag)
         if lds0:
             c['lds_bank_conflict_ratio_before_the_bank_aware_schedule'] = ratio(lds0)
         dump(d, 'binding_c4.json', {
-            'workload': 'c4', 'kernel': 'bool_lds_kernel', 'binding': 'instruction issue (one slot per SIMD every four cycles)',
+            'workload': 'c4', 'kernel': 'bool_lds_kernel', 'binding': 'lds_array',
             'program': {'entries': cfg['program_entries'], 'launches': cfg['launches_per_step'], 'batch': cfg.get('batch_per_gpu', 4096)},
             'constants': c,
-            'reading': 'one workgroup = one CU walks the whole program with its 32-witness slice of the wire table in LDS (128 of 256 '
-                       'CUs at batch 4096).  A SIMD hands out one issue slot every four cycles and the 16 waves of the workgroup '
-                       '(4 per SIMD) fill them: issue = counted instructions per wave (waits, branches and barriers are not in these '
-                       'counters) x 4 waves x 4 cycles at 2.4 GHz -- the figure that tracked the changes of rows per level and of '
-                       'the code next to the barrier (profiles/*_tuning_sweeps.txt); the LDS array itself is busy for '
-                       'lds_array_ms_per_step (14 cycles per row and wave: four 2-cycle reads and the 6-cycle 8-byte store).  '
-                       'At the margin neither moves the time any more (r03_tuning_sweeps.txt): about 14 instructions per level less in the '
-                       'MIDDLE of the blocks (runs without headers) changed nothing, and neither did 5 % fewer LDS array cycles (the '
-                       'leftover ops of a run spread over the banks: conflicts 13 % -> 9 % of the cycles); timing-only variants without '
-                       'the LDS write, with half the reads or a third of the program bytes take the same time.  Against the '
-                       'width of a level: 0.39 us per level (drain -> barrier -> ramp) + 0.096 us per row (the dependent chain of a '
-                       'row step, four waves per SIMD).  The wire traffic never leaves the LDS: the fabric bytes are '
-                       'the program, once per XCD, + inputs',
+            'reading': 'one workgroup = one CU walks the whole program with its 32-witness slice of the wire table in LDS (batch / 32 of '
+                       'the 256 CUs).  No single resource is saturated (profiles/r03_tuning_sweeps.txt, "C4 decomposition": without '
+                       'the LDS write, with half the reads or a third of the program bytes the replay takes the same time): the '
+                       'hardware figure reported is the LDS array -- SQ_LDS_IDX_ACTIVE cycles against 256 CUs x 2.4 GHz -- and the '
+                       'CUs the batch occupies.  The wire traffic never leaves the LDS: the fabric bytes are the program, once per '
+                       'XCD, + inputs',
             'sources': sources, 'collected': {'tag': tag, 'ms_per_step_at_collection': bench['ms_per_step']}})
     # ---- C5
     bench = load(d, '%s_bench_c5.json' % tag)

@@ -7,7 +7,7 @@
 # tools/pmc_traffic.py applies the gfx950 corrections of MI355X_MICROARCH.md, tools/binding_evidence.py writes
 # profiles/binding_<workload>.json from the summaries.  Copy gpurun_out/<tag>/* into profiles/ afterwards.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 WHAT=${2:-bench}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
@@ -28,11 +28,14 @@ pmc() {  # pmc <name> <counters...> -- <bench args...>
 if [ $WHAT = bench ]; then
   # the driver's command: the C2 headline line with the c4 / c5 / structured lines under `secondary`
   echo "[collect] bench (default invocation)"
-  timeout -k 10 600 $B --steps 20 --warmup 3 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+  # (the line is the compact one the driver records; everything else is in the detail file the run writes)
+  ZKI_BENCH_DETAIL=gpurun_out/$TAG/${TAG}_bench_detail.json timeout -k 10 900 $B --steps 20 --warmup 3 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
   python3 - $OUT $TAG <<'PY'
 import json, sys
 out, tag = sys.argv[1], sys.argv[2]
-d = json.load(open('%s/%s_bench_default.json' % (out, tag)))
+line = open('%s/%s_bench_default.json' % (out, tag)).read()
+print('[collect] bench line: %d characters' % len(line))
+d = json.load(open('%s/%s_bench_detail.json' % (out, tag)))
 sec = d.pop('secondary', {})
 json.dump(d, open('%s/%s_bench_c2.json' % (out, tag), 'w'))
 for k, v in sec.items():
@@ -90,7 +93,7 @@ elif [ $WHAT = pmc_c45 ]; then
   python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c4_lds_unbanked.csv bool_lds_kernel 1000 > $OUT/${TAG}_pmc_c4_lds_counters_bank_unaware.json
   # the same relation shape with gate j reading wires j and j+1 of the previous layer: conflict-free by construction,
   # same program size -- what is left is the program stream and the barriers
-  ZKI_C4_WIRING=identity $B --workload c4 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_c4_identity_wiring.json 2> $OUT/bench_c4_identity.err || true
+  ZKI_C4_WIRING=identity ZKI_BENCH_DETAIL=gpurun_out/$TAG/${TAG}_bench_c4_identity_detail.json $B --workload c4 --steps 10 --warmup 2 --no-cpu-baseline --no-first-verdict > $OUT/${TAG}_bench_c4_identity_wiring.json 2> $OUT/bench_c4_identity.err
   C5="--workload c5 --steps 2 --warmup 1 --timed-steps-only"
   K5='r1cs_row_kernel<8, false>'
   pmc c5_f FETCH_SIZE -- $C5

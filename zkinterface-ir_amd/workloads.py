@@ -80,6 +80,7 @@ class ArithLayered:
     def __init__(self, W=4096, D=256, n_instance0=256, n_out=64, seed=0x5EED0001, p=BN254_R, mul_percent=None):
         assert n_instance0 <= W and n_out <= W
         self.W, self.D, self.n_instance0, self.n_out, self.seed, self.p = W, D, n_instance0, n_out, seed, p
+        self.default_mix = mul_percent is None
         self.mod_le = int_to_le(p)
         self.width = 8 * ((p.bit_length() + 63) // 64)
         self.n_instance = n_instance0 + n_out
@@ -174,6 +175,7 @@ class BoolLayered:
 
     def __init__(self, W=16384, D=640, n_instance0=1024, n_out=64, seed=0xB001C4, wiring='random', mix=(45, 45)):
         self.W, self.D, self.n_instance0, self.n_out, self.seed, self.p = W, D, n_instance0, n_out, seed, 2
+        self.wiring = wiring
         self.mod_le = bytes([2])
         self.width = 1
         self.n_instance = n_instance0 + n_out
