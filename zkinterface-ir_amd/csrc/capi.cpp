@@ -1,4 +1,5 @@
 // extern "C" surface declared in include/zkgpu.h.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -990,6 +991,9 @@ int zkgpu_field_segment_carried(const zkgpu_session* s, uint32_t k, uint32_t* sl
 int zkgpu_finalize(zkgpu_session* s, int retain_all) {
   return guarded(s, [&] {
     if (!s->backend.field_set()) throw std::runtime_error("no Relation ingested: the field is not set");
+    static const bool profile = getenv("ZKI_SCHED_PROFILE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count() * 1e3; };
     ScheduleOptions opt = schedule_options(s, retain_all != 0);
     s->ev.values().for_each([&](WireId, const TapeWire& w) { opt.pinned.push_back(w.h); });
     s->n_pinned = opt.pinned.size();
@@ -1039,8 +1043,11 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     s->value_op_index.clear();  // built on first use (need_value_index): only trace dumps and the R1CS entry points read it
     s->engine_loaded = false;
     // host check of every index the kernels use
+    const auto t_validate = std::chrono::steady_clock::now();
+    const double schedule_ms = since(t_begin);
     for (size_t k = 0; k < n_segments(s); ++k)
       Engine::validate_program(seg_sched(s, k), lane_inputs(s, true), lane_inputs(s, false), seg_backend(s, k).tape().n_carry);
+    if (profile) fprintf(stderr, "[finalize] schedule %.1f validate %.1f ms\n", schedule_ms, since(t_validate));
     s->finalized = true;
     s->results_fresh = false;
   });

@@ -6,11 +6,15 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <functional>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace zki {
@@ -84,27 +88,96 @@ void locality_order(uint32_t* ops, size_t cnt, Gathered&& gathered) {
   for (size_t p = 0; p < cnt; ++p) ops[p] = out[p];
 }
 
-// run f(l) for l in [0, n) on up to `threads` threads
-template <class F>
-void parallel_levels(uint32_t n, uint32_t threads, F&& f) {
-  if (threads <= 1 || n <= 1) {
-    for (uint32_t l = 0; l < n; ++l) f(l);
-    return;
+// A few worker threads that stay parked between parallel sections: the scheduler has hundreds of short ones per window
+// (the runs of every GF(2) level, the levels of an arithmetic window) and starting threads for each would cost more than
+// some of them take.  run(n, f): f(0) .. f(n - 1), claimed in index order by the workers and the calling thread; returns
+// when all are done.  A task may wait for a task with a SMALLER index (that one has been claimed before it).
+class TaskPool {
+ public:
+  explicit TaskPool(uint32_t workers) {
+    for (uint32_t t = 0; t < workers; ++t) threads_.emplace_back([this] { work(); });
   }
-  std::atomic<uint32_t> next(0);
-  auto work = [&] {
-    for (;;) {
-      const uint32_t l = next.fetch_add(1);
-      if (l >= n) return;
-      f(l);
+  ~TaskPool() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      quit_.store(true);
     }
-  };
-  std::vector<std::thread> pool;
-  const uint32_t extra = std::min(threads, n) - 1;
-  for (uint32_t t = 0; t < extra; ++t) pool.emplace_back(work);
-  work();
-  for (auto& th : pool) th.join();
-}
+    cv_.notify_all();
+    for (auto& th : threads_) th.join();
+  }
+  uint32_t workers() const { return (uint32_t)threads_.size(); }
+  void run(uint32_t n, const std::function<void(uint32_t)>& f) {
+    if (n == 0) return;
+    if (n == 1 || threads_.empty()) {
+      for (uint32_t i = 0; i < n; ++i) f(i);
+      return;
+    }
+    f_ = &f;
+    n_ = n;
+    pending_.store(n, std::memory_order_relaxed);
+    const uint64_t gen = (ticket_.load(std::memory_order_relaxed) >> 32) + 1;
+    ticket_.store(gen << 32, std::memory_order_release);   // publishes f_, n_, pending_: section `gen`, next task 0
+    if (sleepers_.load() != 0) {
+      std::lock_guard<std::mutex> g(mu_);
+      cv_.notify_all();
+    }
+    drain(gen);
+    // the section ends when every task has FINISHED (not just been claimed); sections are short: spin
+    while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+  }
+
+ private:
+  // Claim and run tasks of section `gen`.  {section, next task} are ONE word: a claim (the compare-exchange) succeeds only
+  // while the section is still current and has an unclaimed task -- and as long as it has one, run() has not returned, so
+  // f_ and n_ read between the load and the exchange are that section's.
+  void drain(uint64_t gen) {
+    for (;;) {
+      uint64_t t = ticket_.load(std::memory_order_acquire);
+      if ((t >> 32) != gen) return;
+      const std::function<void(uint32_t)>* f = f_;
+      const uint32_t n = n_;
+      const uint32_t i = (uint32_t)t;
+      if (i >= n) return;
+      if (!ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+      (*f)(i);
+      pending_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  void work() {
+    uint64_t seen = 0;
+    auto current = [&] { return ticket_.load(std::memory_order_acquire) >> 32; };
+    for (;;) {
+      // Sections follow each other within a fraction of a millisecond while a window is scheduled: poll for a while
+      // before going to sleep (waking a parked thread costs tens of microseconds on metal and milliseconds on some VMs --
+      // more than a section takes)
+      const auto t0 = std::chrono::steady_clock::now();
+      uint32_t polls = 0;
+      while (current() == seen && !quit_.load(std::memory_order_relaxed)) {
+        if ((++polls & 63) == 0) {
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) break;
+          std::this_thread::yield();
+        }
+      }
+      if (current() == seen && !quit_.load()) {
+        std::unique_lock<std::mutex> lk(mu_);
+        sleepers_.fetch_add(1);
+        cv_.wait(lk, [&] { return quit_.load() || current() != seen; });
+        sleepers_.fetch_sub(1);
+      }
+      if (quit_.load()) return;
+      seen = current();
+      drain(seen);
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  const std::function<void(uint32_t)>* f_ = nullptr;
+  uint32_t n_ = 0;
+  std::atomic<uint64_t> ticket_{0};   // section << 32 | next unclaimed task
+  std::atomic<uint32_t> pending_{0}, sleepers_{0};
+  std::atomic<bool> quit_{false};
+};
 
 enum : uint8_t {  // per-op state inside a window
   ST_ENTRY = 0,        // own program entry
@@ -122,6 +195,23 @@ struct StreamScheduler::Impl {
   ScheduleOptions opt;
   Schedule s;
   uint32_t threads = 1;
+  std::unique_ptr<TaskPool> pool_;   // threads - 1 workers, started by the first parallel section
+  TaskPool& pool() {
+    if (!pool_) pool_.reset(new TaskPool(threads > 1 ? threads - 1 : 0));
+    return *pool_;
+  }
+  // f(i) for i in [0, n) on the pool; f(lo, hi) over [0, n) cut into contiguous slices
+  template <class F>
+  void parallel_levels(uint32_t n, F&& f) {
+    const std::function<void(uint32_t)> fn = f;
+    pool().run(n, fn);
+  }
+  template <class F>
+  void parallel_slices(size_t n, size_t min_slice, F&& f) {
+    const uint32_t parts = (uint32_t)std::max<size_t>(1, std::min<size_t>(threads, n / std::max<size_t>(min_slice, 1)));
+    const std::function<void(uint32_t)> fn = [&](uint32_t p) { f(n * p / parts, n * (p + 1) / parts); };
+    pool().run(parts, fn);
+  }
   int prime = -1;  // primality of the characteristic: -1 not tested yet
 
   // per handle, over the whole tape seen so far
@@ -140,6 +230,8 @@ struct StreamScheduler::Impl {
   uint32_t row_pair = kInf;                         // the pair of the even op just placed (its odd neighbour takes the other half)
   uint32_t n_slots = 0;
   uint32_t n_windows = 0;
+  std::atomic<uint64_t> dbg_run_ns[4] = {};
+  double t_bank_order = 0;   // (ZKI_SCHED_PROFILE) seconds spent ordering GF(2) runs for the LDS banks
 
   // the window being scheduled (arrays indexed by handle - lo)
   uint32_t lo = 0, hi = 0, base = 0;
@@ -431,39 +523,39 @@ void StreamScheduler::Impl::levelise() {
   std::vector<uint32_t>& level = s.level_of;
   auto lvl = [&](uint32_t h) -> int64_t { return h < lo ? (int64_t)base - 1 : (int64_t)level[h]; };
   const uint32_t n = hi - lo;
-  std::vector<uint32_t> first_use(n, kInf);
-  std::vector<uint8_t> used(n, 0);
+  // One pass in tape order (operands come before their readers): the level of every op that has operands, and for its
+  // operands the last reader known so far and -- sources only -- the first one.  Then the sources: constant / instance /
+  // witness values are produced as late as possible, one level before their first reader in the window, so that they do
+  // not occupy a slot early.  A value nobody reads lives for its own level.
+  std::vector<uint32_t> first_use;   // per source of the window: level of its first reader (allocated when a source shows up)
+  std::vector<uint32_t> sources;
+  uint32_t top = base;
+  auto note_reader = [&](uint32_t x, uint32_t lv) {
+    if (last_use[x] < lv) last_use[x] = lv;
+    if (x >= lo && n_inputs(kind[x - lo]) == 0 && first_use[x - lo] > lv) first_use[x - lo] = lv;
+  };
   for (uint32_t i = lo; i < hi; ++i) {
     if (st(i) == ST_ELIDED) continue;
     const int ni = n_inputs(kind[i - lo]);
-    int64_t lv = base;  // sources: provisional, moved below
-    if (ni >= 1) lv = lvl(ra[i - lo]) + 1;
+    if (ni == 0) {
+      if (first_use.empty()) first_use.assign(n, kInf);
+      sources.push_back(i);
+      level[i] = base;   // provisional (what its readers are levelled against): moved below
+      continue;
+    }
+    int64_t lv = lvl(ra[i - lo]) + 1;
     if (ni == 2) lv = std::max(lv, lvl(rb[i - lo]) + 1);
     level[i] = (uint32_t)lv;
+    if (last_use[i] < (uint32_t)lv) last_use[i] = (uint32_t)lv;
+    note_reader(ra[i - lo], (uint32_t)lv);
+    if (ni == 2) note_reader(rb[i - lo], (uint32_t)lv);
+    top = std::max(top, (uint32_t)lv + 1);
   }
-  // sources (constant / instance / witness) are produced as late as possible: one level before their first
-  // reader in the window, so they do not occupy a slot early
-  for (uint32_t i = lo; i < hi; ++i) {
-    if (st(i) == ST_ELIDED) continue;
-    const int ni = n_inputs(kind[i - lo]);
-    const uint32_t x = ra[i - lo], y = rb[i - lo];
-    if (ni >= 1 && x >= lo) first_use[x - lo] = std::min(first_use[x - lo], level[i]);
-    if (ni == 2 && y >= lo) first_use[y - lo] = std::min(first_use[y - lo], level[i]);
-  }
-  for (uint32_t i = lo; i < hi; ++i)
-    if (st(i) != ST_ELIDED && n_inputs(kind[i - lo]) == 0)
-      level[i] = first_use[i - lo] == kInf ? base : first_use[i - lo] - 1;
-  uint32_t top = base;
-  for (uint32_t i = lo; i < hi; ++i) {
-    if (st(i) == ST_ELIDED) continue;
-    const int ni = n_inputs(kind[i - lo]);
-    const uint32_t x = ra[i - lo], y = rb[i - lo];
-    if (ni >= 1) { last_use[x] = std::max(last_use[x], level[i]); if (x >= lo) used[x - lo] = 1; }
-    if (ni == 2) { last_use[y] = std::max(last_use[y], level[i]); if (y >= lo) used[y - lo] = 1; }
+  for (uint32_t i : sources) {
+    level[i] = first_use[i - lo] == kInf ? base : first_use[i - lo] - 1;
+    if (last_use[i] < level[i]) last_use[i] = level[i];
     top = std::max(top, level[i] + 1);
   }
-  for (uint32_t i = lo; i < hi; ++i)
-    if (!used[i - lo]) last_use[i] = std::max(last_use[i], level[i]);
   n_wlevels = top - base;
 }
 
@@ -689,25 +781,33 @@ void StreamScheduler::Impl::assign_slots() {
   // last 64-position blocks may be shared with its neighbours, whose banks in the shared block arrive in carry_a / carry_b
   // (per parity) and are avoided.  Greedy: fill group after group, taking for each lane an op whose operand banks are still
   // unused in the group; what cannot be placed conflict-free fills the holes.
-  uint32_t carry_a[2] = {0, 0}, carry_b[2] = {0, 0};
-  // after a run has its final order: the banks its ops use in the block the next run will share with it
-  auto note_run = [&](uint64_t k0, uint64_t k1, uint64_t offset) {
+  // The runs of a level are ordered CONCURRENTLY (they are independent but for the 64-position block two neighbours may
+  // share): a run first orders the groups of the blocks it owns alone, then waits for its predecessor's banks in the shared
+  // block (`Carry`, per parity) and orders its own part of that block last.
+  struct Carry {
+    uint32_t a[2] = {0, 0}, b[2] = {0, 0};
+  };
+  // after a run has its final order: the banks its ops use in the block the next run will share with it (`c` holds the
+  // carry the run itself started from)
+  auto note_run = [&](uint64_t k0, uint64_t k1, uint64_t offset, Carry& c) {
     const uint64_t end = offset + (k1 - k0);
     if (k1 == k0) return;
     if (end % 64 == 0) {
-      carry_a[0] = carry_a[1] = carry_b[0] = carry_b[1] = 0;
+      c = Carry();
       return;
     }
     const uint64_t last_block = (end - 1) / 64;
-    if (offset / 64 != last_block || offset % 64 == 0) carry_a[0] = carry_a[1] = carry_b[0] = carry_b[1] = 0;   // (else: the run lies inside the shared block)
+    if (offset / 64 != last_block || offset % 64 == 0) c = Carry();   // (else: the run lies inside the shared block)
     for (uint64_t q = std::max(offset, last_block * 64); q < end; ++q) {
       const uint32_t i = order[k0 + (q - offset)];
       const int ni = n_inputs(kind[i - lo]);
-      if (ni >= 1) carry_a[q % 2] |= 1u << (s.slot_of[ra[i - lo]] % kBanks);
-      if (ni == 2) carry_b[q % 2] |= 1u << (s.slot_of[rb[i - lo]] % kBanks);
+      if (ni >= 1) c.a[q % 2] |= 1u << (s.slot_of[ra[i - lo]] % kBanks);
+      if (ni == 2) c.b[q % 2] |= 1u << (s.slot_of[rb[i - lo]] % kBanks);
     }
   };
-  auto bank_order = [&](uint64_t k0, uint64_t k1, uint64_t offset) {
+  // group order of a run: the groups of its first block last when that block is shared with the run before it
+  auto group_at = [](size_t gi, size_t n_groups, bool shared_first) { return !shared_first ? gi : (gi + 2 < n_groups ? gi + 2 : gi + 2 - n_groups); };
+  auto bank_order = [&](uint64_t k0, uint64_t k1, uint64_t offset, const std::function<const Carry&()>& wait_carry) {
     const size_t cnt = k1 - k0;
     if (cnt < 2 * kBanks) return;
     const bool two = n_inputs(kind[order[k0] - lo]) == 2;
@@ -732,12 +832,7 @@ void StreamScheduler::Impl::assign_slots() {
       return (q < offset || q >= offset + cnt) ? (size_t)kInf : (size_t)(q - offset);
     };
     std::vector<uint32_t> used_a(n_groups, 0), used_b(n_groups, 0);
-    if (offset % 64) {
-      for (int par = 0; par < 2; ++par) {
-        used_a[par] = carry_a[par];
-        used_b[par] = carry_b[par];
-      }
-    }
+    const bool shared_first = offset % 64 != 0;
     // ops left per operand-b bank: a lane prefers the candidate whose b bank has most ops left, so that the banks
     // are used up evenly and the last groups of the run still find 32 different ones
     uint32_t left_b[kBanks] = {0};
@@ -770,7 +865,15 @@ void StreamScheduler::Impl::assign_slots() {
       used_a[g] |= 1u << (s.slot_of[ra[i - lo]] % kBanks);
       if (two) used_b[g] |= 1u << (s.slot_of[rb[i - lo]] % kBanks);
     };
-    for (size_t g = 0; g < n_groups; ++g) {
+    for (size_t gi = 0; gi < n_groups; ++gi) {
+      const size_t g = group_at(gi, n_groups, shared_first);
+      if (shared_first && g == 0) {   // the banks the run before this one uses in the block the two share
+        const Carry& c = wait_carry();
+        for (int par = 0; par < 2; ++par) {
+          used_a[par] = c.a[par];
+          used_b[par] = c.b[par];
+        }
+      }
       uint32_t holes[kBanks], n_holes = 0;
       for (uint32_t lane = 0; lane < kBanks; ++lane) {
         if (pos_of(g, lane) == (size_t)kInf) continue;
@@ -814,21 +917,32 @@ void StreamScheduler::Impl::assign_slots() {
   // still unplaced (an op with operand banks (x, y) is the edge x--y and, the gates being commutative, also y--x with
   // its operands swapped).  Greedy choices run dry towards the end of a run; augmenting paths (Kuhn) do not, as long
   // as a matching exists.
-  auto bank_order_two = [&](uint64_t k0, uint64_t k1, uint64_t offset) {
+  auto bank_order_two = [&](uint64_t k0, uint64_t k1, uint64_t offset, const std::function<const Carry&()>& wait_carry) {
     const size_t cnt = k1 - k0;
     constexpr uint32_t kFlip = 0x80000000u;
     std::vector<uint32_t> run(order.begin() + k0, order.begin() + k1);
-    std::vector<std::vector<uint32_t>> cell(kBanks * kBanks);   // (a bank, b bank) -> positions in `run` (| kFlip: operands swapped)
+    // (a bank, b bank) -> positions in `run` (| kFlip: operands swapped), as one array cut by cell_end: the entries of cell
+    // c are cell_item[cell_begin[c] .. cell_end[c]), consumed from the back (two counting passes instead of a thousand
+    // small vectors per run)
+    std::vector<uint32_t> cell_begin(kBanks * kBanks + 1, 0), cell_end(kBanks * kBanks, 0), cell_item(2 * cnt);
+    std::vector<uint16_t> bank_xy(cnt);
     for (size_t r = 0; r < cnt; ++r) {
       const uint32_t i = run[r], x = s.slot_of[ra[i - lo]] % kBanks, y = s.slot_of[rb[i - lo]] % kBanks;
-      cell[x * kBanks + y].push_back((uint32_t)r);
-      if (x != y) cell[y * kBanks + x].push_back((uint32_t)r | kFlip);
+      bank_xy[r] = (uint16_t)(x * kBanks + y);
+      ++cell_begin[x * kBanks + y + 1];
+      if (x != y) ++cell_begin[y * kBanks + x + 1];
+    }
+    for (uint32_t c = 0; c < kBanks * kBanks; ++c) cell_begin[c + 1] += cell_begin[c];
+    for (uint32_t c = 0; c < kBanks * kBanks; ++c) cell_end[c] = cell_begin[c];
+    for (size_t r = 0; r < cnt; ++r) {
+      const uint32_t x = bank_xy[r] / kBanks, y = bank_xy[r] % kBanks;
+      cell_item[cell_end[x * kBanks + y]++] = (uint32_t)r;
+      if (x != y) cell_item[cell_end[y * kBanks + x]++] = (uint32_t)r | kFlip;
     }
     std::vector<uint8_t> used(cnt, 0);
     // unplaced ops per edge (symmetric: x--y and y--x are the same ops)
     std::vector<uint32_t> left(kBanks * kBanks, 0);
-    for (uint32_t a = 0; a < kBanks; ++a)
-      for (uint32_t b = 0; b < kBanks; ++b) left[a * kBanks + b] = (uint32_t)cell[a * kBanks + b].size();
+    for (uint32_t c = 0; c < kBanks * kBanks; ++c) left[c] = cell_end[c] - cell_begin[c];
     std::vector<uint32_t> out(cnt, kInf);
     const uint64_t block0 = offset / 64;
     const size_t n_groups = (size_t)((offset + cnt - 1) / 64 - block0 + 1) * 2;
@@ -836,37 +950,54 @@ void StreamScheduler::Impl::assign_slots() {
       const uint64_t q = (block0 + g / 2) * 64 + (g % 2) + 2 * (uint64_t)lane;
       return (q < offset || q >= offset + cnt) ? (size_t)kInf : (size_t)(q - offset);
     };
-    int match_of_b[kBanks], match_of_a[kBanks];
-    uint32_t visited = 0, taken_b = 0;
-    // capacity of edge a--b for one more use in this group: the reverse edge b--a, if matched, draws on the same ops
-    auto capacity = [&](uint32_t a, uint32_t b) {
-      const uint32_t n = left[a * kBanks + b];
-      return (a != b && match_of_a[b] == (int)a) ? (n > 1 ? n - 1 : 0) : n;
-    };
-    struct Kuhn {
-      static bool augment(uint32_t a, int* match_of_b, int* match_of_a, uint32_t& visited, uint32_t& taken_b,
-                          const std::function<uint32_t(uint32_t, uint32_t)>& capacity) {
+    // One group's matching state.  `avail[a]`: the b banks with ops left on edge a--b, as a bit mask -- the scan for a free
+    // b bank only visits those (this loop is the scheduler's hot spot: 330,000 groups of 32 lanes for the C4 relation).
+    struct Matcher {
+      int match_of_b[kBanks], match_of_a[kBanks];
+      uint32_t visited = 0, taken_b = 0;
+      uint32_t choices = 0, rotation = 0;   // choices: 0 = look at every free b bank
+      const uint32_t* left;
+      const uint32_t* avail;
+      // capacity of edge a--b for one more use in this group: the reverse edge b--a, if matched, draws on the same ops
+      inline uint32_t capacity(uint32_t a, uint32_t b) const {
+        const uint32_t n = left[a * kBanks + b];
+        return (a != b && match_of_a[b] == (int)a) ? (n > 1 ? n - 1 : 0) : n;
+      }
+      bool augment(uint32_t a) {
         // a free b bank if there is one: the edge with most ops left, so that the edges are used up evenly and the graph
         // stays dense to the end of the run
-        uint32_t best = 32, best_n = 0;
-        for (uint32_t b = 0; b < 32; ++b) {
-          if ((taken_b >> b) & 1) continue;
-          const uint32_t n = capacity(a, b);
-          if (n > best_n) { best_n = n; best = b; }
+        uint32_t best = kBanks, best_n = 0;
+        const uint32_t free_b = avail[a] & ~taken_b;
+        if (choices && free_b) {
+          // a few candidates, starting at a bank that rotates with the group and with a: the one with most ops left
+          const uint32_t rot = (rotation + 7 * a) & 31;
+          uint32_t cand = (free_b >> rot) | (rot ? free_b << (32 - rot) : 0);
+          for (uint32_t c = 0; c < choices && cand; ++c, cand &= cand - 1) {
+            const uint32_t b = ((uint32_t)__builtin_ctz(cand) + rot) & 31;
+            const uint32_t n = capacity(a, b);
+            if (n > best_n) { best_n = n; best = b; }
+          }
         }
-        if (best < 32) {
+        if (best == kBanks)
+          for (uint32_t cand = free_b; cand; cand &= cand - 1) {
+            const uint32_t b = (uint32_t)__builtin_ctz(cand);
+            const uint32_t n = capacity(a, b);
+            if (n > best_n) { best_n = n; best = b; }
+          }
+        if (best < kBanks) {
           match_of_b[best] = (int)a;
           match_of_a[a] = (int)best;
           taken_b |= 1u << best;
           return true;
         }
-        // otherwise push somebody else off a taken one (augmenting path)
-        for (uint32_t b = 0; b < 32; ++b) {
-          if ((visited >> b) & 1 || !((taken_b >> b) & 1) || match_of_b[b] < 0 || !capacity(a, b)) continue;   // (taken without a match: by the neighbouring run)
+        // otherwise push somebody else off a taken one (augmenting path); (taken without a match: by the neighbouring run)
+        for (uint32_t cand = avail[a] & taken_b & ~visited; cand; cand &= cand - 1) {
+          const uint32_t b = (uint32_t)__builtin_ctz(cand);
+          if ((visited >> b) & 1 || match_of_b[b] < 0 || !capacity(a, b)) continue;
           visited |= 1u << b;
           const int other = match_of_b[b];
           match_of_a[other] = -1;
-          if (augment((uint32_t)other, match_of_b, match_of_a, visited, taken_b, capacity)) {
+          if (augment((uint32_t)other)) {
             match_of_b[b] = (int)a;
             match_of_a[a] = (int)b;
             return true;
@@ -875,39 +1006,52 @@ void StreamScheduler::Impl::assign_slots() {
         }
         return false;
       }
-    };
-    const std::function<uint32_t(uint32_t, uint32_t)> capacity_fn = capacity;
+    } M;
+    std::vector<uint32_t> avail(kBanks, 0);
+    for (uint32_t a = 0; a < kBanks; ++a)
+      for (uint32_t b = 0; b < kBanks; ++b)
+        if (left[a * kBanks + b]) avail[a] |= 1u << b;
+    M.left = left.data();
+    M.avail = avail.data();
+    { const char* e = getenv("ZKI_MATCH_CHOICES"); M.choices = e ? (uint32_t)atoi(e) : 1; }
+    int* const match_of_b = M.match_of_b;
+    int* const match_of_a = M.match_of_a;
     auto alive = [&](uint32_t a, uint32_t b) {   // lazy deletion of the placed ops at the back of the edge's list
-      std::vector<uint32_t>& c = cell[a * kBanks + b];
-      while (!c.empty() && used[c.back() & ~kFlip]) c.pop_back();
-      return !c.empty();
+      const uint32_t c = a * kBanks + b;
+      while (cell_end[c] > cell_begin[c] && used[cell_item[cell_end[c] - 1] & ~kFlip]) --cell_end[c];
+      return cell_end[c] > cell_begin[c];
     };
-    for (size_t g = 0; g < n_groups; ++g) {
+    const bool shared_first = offset % 64 != 0;
+    Carry carry;
+    for (size_t gi = 0; gi < n_groups; ++gi) {
+      const size_t g = group_at(gi, n_groups, shared_first);
+      if (shared_first && g == 0) carry = wait_carry();   // the banks the run before this one uses in the block the two share
       uint32_t lanes = 0;
       for (uint32_t lane = 0; lane < kBanks; ++lane) lanes += pos_of(g, lane) != (size_t)kInf;
       if (!lanes) continue;
       for (uint32_t b = 0; b < kBanks; ++b) match_of_b[b] = match_of_a[b] = -1;
       // the first block may be shared with the run before this one: its banks are taken
-      const bool shared = g < 2 && offset % 64 != 0;
-      const uint32_t blocked_a = shared ? carry_a[g % 2] : 0;
-      taken_b = shared ? carry_b[g % 2] : 0;
+      const bool shared = g < 2 && shared_first;
+      const uint32_t blocked_a = shared ? carry.a[g % 2] : 0;
+      M.taken_b = shared ? carry.b[g % 2] : 0;
+      M.rotation = (uint32_t)(g * 11);
       uint32_t matched = 0;
       for (uint32_t t = 0; t < kBanks && matched < lanes; ++t) {
         const uint32_t a = (t + (uint32_t)g) % kBanks;
-        if ((blocked_a >> a) & 1) continue;
-        visited = 0;
-        if (Kuhn::augment(a, match_of_b, match_of_a, visited, taken_b, capacity_fn)) ++matched;
+        if ((blocked_a >> a) & 1 || !avail[a]) continue;
+        M.visited = 0;
+        if (M.augment(a)) ++matched;
       }
       uint32_t lane = 0;
       for (uint32_t a = 0; a < kBanks; ++a) {
         if (match_of_a[a] < 0) continue;
         const uint32_t b = (uint32_t)match_of_a[a];
         if (!alive(a, b)) continue;   // (cannot happen while `left` is exact; a hole is harmless)
-        const uint32_t e = cell[a * kBanks + b].back();
+        const uint32_t e = cell_item[cell_end[a * kBanks + b] - 1];
         const uint32_t r = e & ~kFlip;
         used[r] = 1;
-        --left[a * kBanks + b];
-        if (a != b) --left[b * kBanks + a];
+        if (--left[a * kBanks + b] == 0) avail[a] &= ~(1u << b);
+        if (a != b && --left[b * kBanks + a] == 0) avail[b] &= ~(1u << a);
         const uint32_t i = run[r];
         if (e & kFlip) std::swap(ra[i - lo], rb[i - lo]);
         while (lane < kBanks && (pos_of(g, lane) == (size_t)kInf || out[pos_of(g, lane)] != kInf)) ++lane;
@@ -920,15 +1064,16 @@ void StreamScheduler::Impl::assign_slots() {
     std::vector<uint32_t> left_ops;
     for (size_t r = 0; r < cnt; ++r)
       if (!used[r]) left_ops.push_back((uint32_t)r);
+    if (getenv("ZKI_MATCH_DEBUG")) fprintf(stderr, "[match] run of %zu ops at offset %llu: %zu left over\n", cnt, (unsigned long long)offset, left_ops.size());
     if (!left_ops.empty()) {
       std::vector<uint8_t> cnt_a(n_groups * kBanks, 0), cnt_b(n_groups * kBanks, 0);
       auto bank_a = [&](uint32_t i) { return s.slot_of[ra[i - lo]] % kBanks; };
       auto bank_b = [&](uint32_t i) { return s.slot_of[rb[i - lo]] % kBanks; };
       for (size_t g = 0; g < n_groups; ++g) {
-        if (g < 2 && offset % 64 != 0)
+        if (g < 2 && shared_first)
           for (uint32_t bk = 0; bk < kBanks; ++bk) {
-            cnt_a[g * kBanks + bk] = (carry_a[g % 2] >> bk) & 1;
-            cnt_b[g * kBanks + bk] = (carry_b[g % 2] >> bk) & 1;
+            cnt_a[g * kBanks + bk] = (carry.a[g % 2] >> bk) & 1;
+            cnt_b[g * kBanks + bk] = (carry.b[g % 2] >> bk) & 1;
           }
         for (uint32_t lane = 0; lane < kBanks; ++lane) {
           const size_t q = pos_of(g, lane);
@@ -992,17 +1137,60 @@ void StreamScheduler::Impl::assign_slots() {
     for (uint64_t k = level_start[l]; k < level_start[l + 1] && rows0 == level_start[l + 1]; ++k)
       if (row_class(kind[order[k] - lo])) rows0 = k;
     const bool wide_rows = level_start[l + 1] - rows0 >= 2 * kBanks;   // long enough for whole groups of 32 lanes
-    carry_a[0] = carry_a[1] = carry_b[0] = carry_b[1] = 0;
-    for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
-      if (s.boolean_path && k >= rows0 && (k == rows0 || kind[order[k] - lo] != kind[order[k - 1] - lo])) {
+    if (s.boolean_path && rows0 < level_start[l + 1]) {
+      // the (level, kind) runs of the row sequence, ordered for the LDS banks before any of their ops gets a slot (the order
+      // only looks at operands, i.e. at earlier levels) -- concurrently, each run waiting for its predecessor's final order
+      // only to fill its part of the 64-position block the two share
+      struct Run {
+        uint64_t k0, k1;
+        bool ordered;
+        Carry carry;                 // in: what the runs before left in the shared block; out (note_run): what this one leaves
+        std::atomic<bool> done{false};
+      };
+      std::deque<Run> runs;
+      for (uint64_t k = rows0; k < level_start[l + 1];) {
         uint64_t e = k;
         while (e < level_start[l + 1] && kind[order[e] - lo] == kind[order[k] - lo]) ++e;
-        if (banked && rows_level && e - k >= 2 * kBanks) {
-          if (n_inputs(kind[order[k] - lo]) == 2) bank_order_two(k, e, k - rows0);
-          else if (n_inputs(kind[order[k] - lo]) == 1) bank_order(k, e, k - rows0);
-        }
-        note_run(k, e, k - rows0);
+        runs.emplace_back();
+        runs.back().k0 = k;
+        runs.back().k1 = e;
+        runs.back().ordered = banked && rows_level && e - k >= 2 * kBanks && n_inputs(kind[order[k] - lo]) >= 1;
+        k = e;
       }
+      const auto tq = std::chrono::steady_clock::now();
+      auto do_run = [&](size_t r) {
+        Run& R = runs[r];
+        // the carry a run starts from: its predecessor's, final once that run is done
+        auto wait_carry = [&]() -> const Carry& {
+          if (r > 0) {
+            while (!runs[r - 1].done.load(std::memory_order_acquire)) std::this_thread::yield();
+            R.carry = runs[r - 1].carry;
+          }
+          return R.carry;
+        };
+        const std::function<const Carry&()> wc = wait_carry;
+        const auto tr = std::chrono::steady_clock::now();
+        if (R.ordered) {
+          if (n_inputs(kind[order[R.k0] - lo]) == 2) bank_order_two(R.k0, R.k1, R.k0 - rows0, wc);
+          else bank_order(R.k0, R.k1, R.k0 - rows0, wc);
+        }
+        dbg_run_ns[std::min<size_t>(r, 3)] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tr).count();
+        wait_carry();
+        note_run(R.k0, R.k1, R.k0 - rows0, R.carry);
+        R.done.store(true, std::memory_order_release);
+      };
+      size_t n_ordered = 0;
+      for (const Run& R : runs) n_ordered += R.ordered;
+      if (n_ordered >= 2 && threads > 1) {
+        // (tasks are claimed in run order, so the run a task waits for is always under way)
+        const std::function<void(uint32_t)> fn = [&](uint32_t r) { do_run(r); };
+        pool().run((uint32_t)runs.size(), fn);
+      } else {
+        for (size_t r = 0; r < runs.size(); ++r) do_run(r);
+      }
+      t_bank_order += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count();
+    }
+    for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {
       const uint32_t i = order[k];
       if (kind[i - lo] == TK_ASSERT || kind[i - lo] == TK_NOP) continue;
       // position of the op in the row sequence (the thread that executes it is position / 2), for the ops that run as rows
@@ -1021,7 +1209,7 @@ void StreamScheduler::Impl::order_levels() {
   // GF(2): the order inside a run is final when the slots are assigned -- the two results of a thread (run positions 2t,
   // 2t + 1) are the halves of one slot pair, and a bank-aware schedule has ordered the run for the LDS banks by then
   if (s.boolean_path) return;
-  parallel_levels(n_wlevels, threads, [&](uint32_t l) {
+  parallel_levels(n_wlevels, [&](uint32_t l) {
     // inside a (level, kind) run, order the ops by the slot of their first operand: gates that read
     // the same wire become neighbours (same workgroup), so the repeat read is an L1/L2 hit
     uint64_t k = level_start[l];
@@ -1057,7 +1245,8 @@ void StreamScheduler::Impl::emit_entries() {
   if (s.fused) {
     const size_t at = s.ops2.size();
     s.ops2.resize(at + n_live);
-    for (size_t k = 0; k < n_live; ++k) {
+    parallel_slices(n_live, 1 << 16, [&](size_t k_lo, size_t k_hi) {
+    for (size_t k = k_lo; k < k_hi; ++k) {
       const uint32_t i = order[k];
       const uint8_t kd = kind[i - lo];
       DevOp2 d{0, kd, 0, 0, 0, 0, 0, 0};
@@ -1111,11 +1300,13 @@ void StreamScheduler::Impl::emit_entries() {
       }
       s.ops2[at + k] = d;
     }
+    });
     return;
   }
   const size_t at = s.ops.size();
   s.ops.resize(at + n_live);
-  for (size_t k = 0; k < n_live; ++k) {
+  parallel_slices(n_live, 1 << 16, [&](size_t k_lo, size_t k_hi) {
+  for (size_t k = k_lo; k < k_hi; ++k) {
     const uint32_t i = order[k];
     const uint8_t kd = kind[i - lo];
     DevOp d{0, 0, 0, kd};
@@ -1150,6 +1341,7 @@ void StreamScheduler::Impl::emit_entries() {
     }
     s.ops[at + k] = d;
   }
+  });
 }
 
 void StreamScheduler::Impl::emit_launches() {
@@ -1228,27 +1420,35 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     for (uint32_t h : *w.pinned)
       if (h < w.hi) m.flags[h] = (uint8_t)((m.flags[h] | FL_PINNED) & ~FL_DROPPED);
   const uint32_t n = w.hi - w.lo;
-  m.track_unreduced_values(w);   // (also for an empty final window: the wires alive at the end are known only now)
-  m.n_wlevels = 0;
-  m.order.clear();
   static const bool profile = getenv("ZKI_SCHED_PROFILE") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto t0 = now();
-  double stage[8] = {0};
+  double stage[10] = {0};
   int si = 0;
   auto lap = [&] { auto t1 = now(); stage[si++] = std::chrono::duration<double>(t1 - t0).count(); t0 = t1; };
+  m.track_unreduced_values(w);   // (also for an empty final window: the wires alive at the end are known only now)
+  lap();
+  m.n_wlevels = 0;
+  m.order.clear();
   if (n) {
-    m.kind.assign(w.kind, w.kind + n);
-    m.state.assign(n, ST_ENTRY);
-    m.ra.assign(w.a, w.a + n);
-    m.rb.assign(w.b, w.b + n);
-    if (m.field.is_two) {
+    // the window's own copy of the ops (operands get resolved through copy chains, kinds rewritten), written slice by slice
+    m.kind.resize(n);
+    m.state.resize(n);
+    m.ra.resize(n);
+    m.rb.resize(n);
+    m.parallel_slices(n, 1 << 18, [&](size_t i0, size_t i1) {
+      memcpy(m.kind.data() + i0, w.kind + i0, i1 - i0);
+      memset(m.state.data() + i0, ST_ENTRY, i1 - i0);
+      memcpy(m.ra.data() + i0, w.a + i0, (i1 - i0) * 4);
+      memcpy(m.rb.data() + i0, w.b + i0, (i1 - i0) * 4);
+      if (!m.field.is_two) return;
       // Arithmetic mod 2 on {0, 1}, lowered here and not when the pool is converted: (a + b) % 2 = xor, (a * b) % 2 = and,
       // a + c = not / copy and a * c = copy / 0 by the parity of c.  The (level, kind) runs the slots are allocated for
       // are then the runs the LDS-resident kernel's program is cut into (lds_program.cpp): its threads store their two
       // results as one aligned pair.
-      for (uint32_t i = 0; i < n; ++i) {
+      for (size_t i = i0; i < i1; ++i) {
         uint8_t& k = m.kind[i];
+        if (k != TK_ADD && k != TK_MUL && k != TK_ADDC && k != TK_MULC) continue;
         const bool odd_const = (k == TK_ADDC || k == TK_MULC) && w.consts && m.rb[i] < w.consts->size() &&
                                !(*w.consts)[m.rb[i]].empty() && ((*w.consts)[m.rb[i]][0] & 1);
         if (k == TK_ADD) k = TK_XOR;
@@ -1259,7 +1459,7 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
           else { k = TK_CONST; m.ra[i] = kSyntheticZero; m.rb[i] = 0; }
         }
       }
-    }
+    });
     m.rewrite_ladders(w);
     m.propagate_copies();
     lap();
@@ -1285,9 +1485,10 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     lap();
     m.s.n_levels = m.base + m.n_wlevels;
     if (profile)
-      fprintf(stderr, "[schedule] window %u: %u ops, %u levels | copies %.1f levelise %.1f fuse %.1f sort %.1f slots %.1f order %.1f emit %.1f ms\n",
+      fprintf(stderr, "[schedule] window %u: %u ops, %u levels | grow+sources %.1f copies %.1f levelise %.1f fuse %.1f sort %.1f slots %.1f order %.1f emit %.1f ms\n",
               m.n_windows, n, m.n_wlevels, stage[0] * 1e3, stage[1] * 1e3, stage[2] * 1e3, stage[3] * 1e3, stage[4] * 1e3,
-              stage[5] * 1e3, stage[6] * 1e3);
+              stage[5] * 1e3, stage[6] * 1e3, stage[7] * 1e3);
+    if (profile && m.t_bank_order > 0) fprintf(stderr, "[schedule]   of slots: %.1f ms ordering runs for the LDS banks (runs 0..3: %.1f %.1f %.1f %.1f ms)\n", m.t_bank_order * 1e3, m.dbg_run_ns[0] / 1e6, m.dbg_run_ns[1] / 1e6, m.dbg_run_ns[2] / 1e6, m.dbg_run_ns[3] / 1e6);
   }
   ++m.n_windows;
   m.s.n_slots = std::max<uint32_t>(m.n_slots, 1);
