@@ -109,6 +109,7 @@ struct zkgpu_session {
   uint32_t strand_width = 0;   // 0 = the scheduler's default
   std::unique_ptr<StreamState> stream;
   double stream_busy_s = 0;
+  double parse_s = 0, record_s = 0;   // seconds spent decoding messages / recording Relation messages (ZKI_SCHED_PROFILE prints them)
   uint32_t stream_windows = 0;
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
@@ -576,8 +577,10 @@ void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
     if (s->ev.has_error() && !side_consumers) return;
     // peek the message type: Instance / Witness messages become lane 0's streams
     Message msg;
+    const auto t_parse = std::chrono::steady_clock::now();
     try {
       msg = read_message(data + m.first, m.second);
+      s->parse_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_parse).count();
     } catch (const std::exception& e) {
       // `let msg = msg?;` ends valid-eval-metrics before any report (cli.rs:345-346)
       if (side_consumers) throw;
@@ -607,7 +610,9 @@ void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
         }
         if (differs) switch_field(s, msg.relation.header, mask::contains_feature(msg.relation.gate_mask, mask::BOOL));
       }
+      const auto t_rec = std::chrono::steady_clock::now();
       s->ev.ingest_message(msg, s->backend);
+      s->record_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rec).count();
     }
   }
 }
@@ -1047,7 +1052,9 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     const double schedule_ms = since(t_begin);
     for (size_t k = 0; k < n_segments(s); ++k)
       Engine::validate_program(seg_sched(s, k), lane_inputs(s, true), lane_inputs(s, false), seg_backend(s, k).tape().n_carry);
-    if (profile) fprintf(stderr, "[finalize] schedule %.1f validate %.1f ms\n", schedule_ms, since(t_validate));
+    if (profile)
+      fprintf(stderr, "[finalize] schedule %.1f validate %.1f ms | ingest so far: decode %.1f record %.1f ms\n", schedule_ms, since(t_validate),
+              s->parse_s * 1e3, s->record_s * 1e3);
     s->finalized = true;
     s->results_fresh = false;
   });

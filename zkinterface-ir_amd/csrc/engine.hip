@@ -326,7 +326,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   dfree(d_consts_);
   dfree(d_lds_ops_);
   dfree(d_launches_);
-  sched_ = s;
+  sched_ = s.without_entries();
   boolean_ = s.boolean_path;
   nwords_ = f.nwords;
   elem_bytes_ = boolean_ ? 1 : 4 * f.nwords;
@@ -371,7 +371,12 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
     throw std::runtime_error("Engine: the field characteristic is wider than the Montgomery kernels");
   }
   validate_program(s, n_instance, n_witness, n_carry);
-  {
+  // GF(2): the LDS-resident kernel runs a program of its own (built below from the schedule): the 16-byte entries of the
+  // HBM-table kernel are not uploaded for it
+  const bool lds_wanted = s.boolean_path && bool_path_ != 1 && lds_program_fits(s);
+  if (lds_wanted) {
+    free_windows();
+  } else {
     // program entries window by window; windows a streamed ingest has already sent stay where they are
     const size_t eb = s.fused ? sizeof(DevOp2) : sizeof(DevOp);
     const uint8_t* host = s.fused ? (const uint8_t*)s.ops2.data() : (const uint8_t*)s.ops.data();
@@ -410,7 +415,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
   constexpr uint32_t kLdsBytes = 160 * 1024;
   lds_path_ = false;
   if (boolean_ && bool_path_ != 1) {
-    if (lds_program_fits(s)) {
+    if (lds_wanted) {
       // the program of the LDS kernel is host work (lds_program.cpp); here it is only uploaded
       std::vector<uint32_t> sizes;
       for (uint32_t br = 1; br <= (uint32_t)zkgpu::kLdsMaxBlockRows; ++br)

@@ -917,7 +917,12 @@ void StreamScheduler::Impl::assign_slots() {
   // still unplaced (an op with operand banks (x, y) is the edge x--y and, the gates being commutative, also y--x with
   // its operands swapped).  Greedy choices run dry towards the end of a run; augmenting paths (Kuhn) do not, as long
   // as a matching exists.
-  auto bank_order_two = [&](uint64_t k0, uint64_t k1, uint64_t offset, const std::function<const Carry&()>& wait_carry) {
+  // `out` holds positions in `run` and operand swaps are only NOTED (bank_xy swapped, the op listed in `flips`): the runs of
+  // a level are ordered concurrently and their ops lie interleaved in ra / rb -- writing those from several threads makes
+  // the cache lines bounce (measured: every run took twice as long).  The caller swaps the listed ops' operands afterwards.
+  // carry_out: the banks the run uses in its last 64-position block (note_run, from the run's own bank table).
+  auto bank_order_two = [&](uint64_t k0, uint64_t k1, uint64_t offset, const std::function<const Carry&()>& wait_carry,
+                            std::vector<uint32_t>& flips, Carry& carry_out) {
     const size_t cnt = k1 - k0;
     constexpr uint32_t kFlip = 0x80000000u;
     std::vector<uint32_t> run(order.begin() + k0, order.begin() + k1);
@@ -1052,10 +1057,12 @@ void StreamScheduler::Impl::assign_slots() {
         used[r] = 1;
         if (--left[a * kBanks + b] == 0) avail[a] &= ~(1u << b);
         if (a != b && --left[b * kBanks + a] == 0) avail[b] &= ~(1u << a);
-        const uint32_t i = run[r];
-        if (e & kFlip) std::swap(ra[i - lo], rb[i - lo]);
+        if (e & kFlip) {
+          flips.push_back(run[r]);
+          bank_xy[r] = (uint16_t)((bank_xy[r] % kBanks) * kBanks + bank_xy[r] / kBanks);
+        }
         while (lane < kBanks && (pos_of(g, lane) == (size_t)kInf || out[pos_of(g, lane)] != kInf)) ++lane;
-        out[pos_of(g, lane)] = i;
+        out[pos_of(g, lane)] = r;
       }
     }
     // What no matching could take (the last tenth of a run): a group that cannot be conflict-free should at least spread
@@ -1067,8 +1074,8 @@ void StreamScheduler::Impl::assign_slots() {
     if (getenv("ZKI_MATCH_DEBUG")) fprintf(stderr, "[match] run of %zu ops at offset %llu: %zu left over\n", cnt, (unsigned long long)offset, left_ops.size());
     if (!left_ops.empty()) {
       std::vector<uint8_t> cnt_a(n_groups * kBanks, 0), cnt_b(n_groups * kBanks, 0);
-      auto bank_a = [&](uint32_t i) { return s.slot_of[ra[i - lo]] % kBanks; };
-      auto bank_b = [&](uint32_t i) { return s.slot_of[rb[i - lo]] % kBanks; };
+      auto bank_a = [&](uint32_t r) { return (uint32_t)bank_xy[r] / kBanks; };   // (of the op at run position r, as it stands now)
+      auto bank_b = [&](uint32_t r) { return (uint32_t)bank_xy[r] % kBanks; };
       for (size_t g = 0; g < n_groups; ++g) {
         if (g < 2 && shared_first)
           for (uint32_t bk = 0; bk < kBanks; ++bk) {
@@ -1090,7 +1097,7 @@ void StreamScheduler::Impl::assign_slots() {
           uint32_t best_cost = ~0u;
           bool best_flip = false;
           for (size_t c = 0; c < left_ops.size() && best_cost; ++c) {
-            const uint32_t i = run[left_ops[c]], x = bank_a(i), y = bank_b(i);
+            const uint32_t x = bank_a(left_ops[c]), y = bank_b(left_ops[c]);
             // (multiplicity the op would see on its two banks: the heavier one counts most)
             auto cost = [&](uint32_t a, uint32_t b) {
               const uint32_t ca = cnt_a[g * kBanks + a], cb = cnt_b[g * kBanks + b];
@@ -1100,16 +1107,32 @@ void StreamScheduler::Impl::assign_slots() {
             if (straight < best_cost) { best_cost = straight; best = c; best_flip = false; }
             if (flipped < best_cost) { best_cost = flipped; best = c; best_flip = true; }
           }
-          const uint32_t i = run[left_ops[best]];
+          const uint32_t r = left_ops[best];
           left_ops[best] = left_ops.back();
           left_ops.pop_back();
-          if (best_flip) std::swap(ra[i - lo], rb[i - lo]);
-          out[q] = i;
-          ++cnt_a[g * kBanks + bank_a(i)];
-          ++cnt_b[g * kBanks + bank_b(i)];
+          if (best_flip) {
+            flips.push_back(run[r]);
+            bank_xy[r] = (uint16_t)((bank_xy[r] % kBanks) * kBanks + bank_xy[r] / kBanks);
+          }
+          out[q] = r;
+          ++cnt_a[g * kBanks + bank_a(r)];
+          ++cnt_b[g * kBanks + bank_b(r)];
         }
     }
-    for (size_t q = 0; q < cnt; ++q) order[k0 + q] = out[q];
+    for (size_t q = 0; q < cnt; ++q) order[k0 + q] = run[out[q]];
+    // the banks the run uses in the block its successor will share with it (what note_run computes from ra / rb)
+    const uint64_t end = offset + cnt;
+    if (end % 64 == 0) {
+      carry_out = Carry();
+    } else {
+      const uint64_t last_block = (end - 1) / 64;
+      carry_out = (offset / 64 != last_block || offset % 64 == 0) ? Carry() : carry;   // (else: the run lies inside the shared block)
+      for (uint64_t q = std::max(offset, last_block * 64); q < end; ++q) {
+        const uint32_t r = out[q - offset];
+        carry_out.a[q % 2] |= 1u << (bank_xy[r] / kBanks);
+        carry_out.b[q % 2] |= 1u << (bank_xy[r] % kBanks);
+      }
+    }
   };
   auto place = [&](uint32_t i, uint32_t bank = kInf) {
     s.slot_of[i] = take_slot(bank);
@@ -1145,6 +1168,7 @@ void StreamScheduler::Impl::assign_slots() {
         uint64_t k0, k1;
         bool ordered;
         Carry carry;                 // in: what the runs before left in the shared block; out (note_run): what this one leaves
+        std::vector<uint32_t> flips; // ops whose operands are to be swapped (applied behind the parallel section)
         std::atomic<bool> done{false};
       };
       std::deque<Run> runs;
@@ -1170,10 +1194,16 @@ void StreamScheduler::Impl::assign_slots() {
         };
         const std::function<const Carry&()> wc = wait_carry;
         const auto tr = std::chrono::steady_clock::now();
-        if (R.ordered) {
-          if (n_inputs(kind[order[R.k0] - lo]) == 2) bank_order_two(R.k0, R.k1, R.k0 - rows0, wc);
-          else bank_order(R.k0, R.k1, R.k0 - rows0, wc);
+        if (R.ordered && n_inputs(kind[order[R.k0] - lo]) == 2) {
+          Carry out;
+          bank_order_two(R.k0, R.k1, R.k0 - rows0, wc, R.flips, out);
+          wait_carry();   // (a run that does not start inside a shared block never asked)
+          R.carry = out;
+          R.done.store(true, std::memory_order_release);
+          dbg_run_ns[std::min<size_t>(r, 3)] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tr).count();
+          return;
         }
+        if (R.ordered) bank_order(R.k0, R.k1, R.k0 - rows0, wc);
         dbg_run_ns[std::min<size_t>(r, 3)] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tr).count();
         wait_carry();
         note_run(R.k0, R.k1, R.k0 - rows0, R.carry);
@@ -1188,6 +1218,8 @@ void StreamScheduler::Impl::assign_slots() {
       } else {
         for (size_t r = 0; r < runs.size(); ++r) do_run(r);
       }
+      for (const Run& R : runs)
+        for (uint32_t i : R.flips) std::swap(ra[i - lo], rb[i - lo]);
       t_bank_order += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count();
     }
     for (uint64_t k = level_start[l]; k < level_start[l + 1]; ++k) {

@@ -97,6 +97,34 @@ struct Schedule {
   // boolean = one u32 (0/1) per constant
   std::vector<uint32_t> const_words;
   uint32_t words_per_const = 0;
+
+  // everything but the per-entry and per-handle arrays (ops, ops2, slot_of, level_of): what the engine keeps once the
+  // program is on the device (a 10 M-gate program is a quarter of a gigabyte of those)
+  Schedule without_entries() const {
+    Schedule c;
+    c.fused = fused;
+    c.n_absorbed = n_absorbed;
+    c.n_copies_elided = n_copies_elided;
+    c.n_ladders = n_ladders;
+    c.n_paired = n_paired;
+    c.launches = launches;
+    c.strict_instance = strict_instance;
+    c.strict_witness = strict_witness;
+    c.strict_carry = strict_carry;
+    c.raw_source = raw_source;
+    c.raw_const_of = raw_const_of;
+    c.strand_level_ptr = strand_level_ptr;
+    c.window_first_op = window_first_op;
+    c.n_slots = n_slots;
+    c.n_levels = n_levels;
+    c.max_level_width = max_level_width;
+    c.retain_all = retain_all;
+    c.boolean_path = boolean_path;
+    c.has_bitops = has_bitops;
+    c.const_words = const_words;
+    c.words_per_const = words_per_const;
+    return c;
+  }
 };
 
 // Ops [lo, hi) of a tape.  Arrays are indexed by (tape index - lo); operands are tape indices and may lie below lo.
