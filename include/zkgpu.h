@@ -198,11 +198,15 @@ size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size
  * communicator of one rank -- and an RCCL failure is an error instead of falling back to the host sum; default 0),
  * "stream" = 0 | 1 | N (streaming ingest, rust/src/consumers/evaluator.rs:286-301: the reference consumes a relation
  * as a stream of <= 100k-gate messages; with N > 0 the tape is cut into windows of about N recorded calls ("1" = 131072),
- * and a worker thread schedules each window -- and sends its program entries to the GPU -- as soon as it is complete,
- * while the caller is still ingesting the following messages; zkgpu_finalize then only schedules the tail.  The cuts
- * depend on the tape alone, so the program is the same however the relation was split into messages.  What a window
- * may fuse or recycle rests on the drop records of the wires (the bundled Evaluator gives them; zkgpu_backend_drop).
- * Set before the first Relation message; ignored for GF(2) and with retain_all.  Default 0),
+ * and a worker thread schedules each window -- and, for the arithmetic kernels, sends its program entries to the GPU --
+ * as soon as it is complete, while the caller is still ingesting the following messages; zkgpu_finalize then only
+ * schedules the tail.  A window ends in front of the first recorded call that opens a new dependency level once N calls
+ * are recorded (a relation recorded level by level is never cut inside a level: its streamed program has the launches of
+ * the one scheduled at finalize, and over GF(2) it is that program byte for byte), at 2 N calls at the latest, never
+ * inside the exponent ladder of a Switch weight.  The cuts depend on the tape alone, so the program is the same however
+ * the relation was split into messages.  What a window may fuse or recycle rests on the drop records of the wires (the
+ * bundled Evaluator gives them; zkgpu_backend_drop).  Set before the first Relation message; ignored with retain_all.
+ * Default 0),
  * "schedule_threads" = N (threads ordering the levels of a window, default min(8, hardware threads)),
  * "hot_waves" = 0 | 3..7 (cap on the resident waves per SIMD of the Add/Mul kernel, by an unused LDS allocation;
  * 0 = no cap, the default -- a tuning handle, every cap measured slower on C2),

@@ -143,6 +143,45 @@ def test_full_size_c4_against_the_cpu_checker_and_the_oracle_digests(c4_referenc
 
 
 @pytest.mark.gpu
+def test_full_size_c4_streamed_is_the_program_scheduled_at_finalize(c4_reference):
+    """BASELINE configs[3] ingested as a stream (106 messages; windows of 131072 recorded calls = 8 layers, cut at the
+    level seams and scheduled by the worker thread while the next messages are parsed): levels, slots and the bytes of the
+    LDS-resident kernel's program are those of the schedule made at finalize, and the statement's counts, first failing
+    asserts and violation texts are the reference's for all 4096 lanes."""
+    wl, inst, wit, outs = c4_reference
+    batch = 4096
+    inst = inst.copy()
+    n_bad = wl.set_expected_outputs(inst, outs)
+    msgs = wl.relation_messages()
+    sessions = {}
+    for stream in (0, 1):
+        ev = zk.Evaluator()
+        ev.set_option('bool_path', 'lds')
+        ev.set_option('stream', str(stream))
+        ev.declare_inputs(wl.n_instance, wl.n_witness)
+        for m in msgs:
+            ev.ingest_message(m)
+        ev.finalize()
+        sessions[stream] = ev
+    sinfo = sessions[1].stream_info()
+    assert sinfo['windows'] >= 80 and sinfo['streamed_windows'] == sinfo['windows']
+    assert sessions[0].schedule_info() == sessions[1].schedule_info()
+    P, Q = sessions[0].lds_program(0), sessions[1].lds_program(0)
+    for k in ('ops8', 'rows', 'blocks', 'chunks'):
+        assert np.array_equal(P[k], Q[k]), k
+    sessions[0].close()
+    ev = sessions[1]
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    assert ev.uses_lds_path()
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (workloads.expected_satisfied(batch), n_bad) == (4053, 43)
+    first, flags = ev.lane_results(batch)
+    assert np.array_equal(first, np.where(np.arange(batch) % 97 == 0, 0, zk.NO_FAIL).astype(np.uint32)) and not flags.any()
+    assert ev.get_violations(97) == ['Wire_%d (may be weighted) should be 0, while it is not' % ((wl.D + 1) * wl.W + 1)]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('block_rows', [None, 4, 6, 8, 9, 10, 12])
 def test_lds_kernel_block_shapes_against_the_cpu_checker(block_rows, monkeypatch):
     """The LDS-resident kernel has one instantiation per block size and, inside it, one code path per number of rows of

@@ -32,6 +32,7 @@ struct WindowJob {
   std::vector<uint8_t> kind;
   std::vector<uint32_t> a, b, drops, pinned;
   std::vector<Tape::Ladder> ladders;
+  std::vector<uint8_t> const_parity;   // GF(2): low bit of every constant recorded so far (decides what add / mul by a constant become)
   bool final = false;
 };
 
@@ -249,6 +250,7 @@ void stream_worker(zkgpu_session* s) {
       w.n_ladders = job.ladders.size();
       w.final = job.final;
       w.pinned = &job.pinned;
+      if (!job.const_parity.empty()) w.const_parity = &job.const_parity;
       const WindowResult r = st.sched->add_window(w);
       if (st.upload) {
         // the window's entries go to HBM now; without a GPU (the CPU test tier) they are sent by the first replay call
@@ -294,6 +296,10 @@ void stream_enqueue(zkgpu_session* s, uint32_t hi, bool final) {
   job.ladders.assign(t.ladders.begin() + st.ladder_at, t.ladders.begin() + l1);
   st.ladder_at = l1;
   if (final) s->ev.values().for_each([&](WireId, const TapeWire& w) { job.pinned.push_back(w.h); });
+  if (s->backend.field().is_two) {
+    job.const_parity.resize(t.consts.size() + 1, 0);   // (+ 1: never empty, so the window knows the table is there)
+    for (size_t c = 0; c < t.consts.size(); ++c) job.const_parity[c] = !t.consts[c].empty() && (t.consts[c][0] & 1);
+  }
   st.next_lo = hi;
   {
     std::lock_guard<std::mutex> g(st.mu);
@@ -306,9 +312,11 @@ void stream_enqueue(zkgpu_session* s, uint32_t hi, bool final) {
 // TapeBackend's cut hook: a window of the tape is complete
 void stream_cut(void* arg) {
   zkgpu_session* s = (zkgpu_session*)arg;
-  if (s->backend.field().is_two) return;  // GF(2) programs are scheduled and encoded as a whole (LDS-resident kernel)
   if (!s->stream) {
     s->stream.reset(new StreamState());
+    // GF(2): the 16-byte entries the windows hold are the HBM-table kernel's; the LDS-resident kernel runs a program built
+    // from the finished schedule (Engine::load_program), so nothing is sent ahead unless that kernel is asked for
+    if (s->backend.field().is_two && s->bool_path != 1) s->stream->upload = false;
     s->stream->sched.reset(new StreamScheduler(s->backend.field(), schedule_options(s, false)));
     s->stream->worker = std::thread(stream_worker, s);
   }
@@ -1006,9 +1014,12 @@ int zkgpu_finalize(zkgpu_session* s, int retain_all) {
     if (s->stream && !opt.retain_all && !s->finalized) {
       // the windows scheduled while the messages were coming in + the rest of the tape as the final window
       stream_enqueue(s, (uint32_t)t.size(), true);
+      const double t_enq = since(t_begin);
       stream_wait(s);
+      const double t_wait = since(t_begin);
       if (!s->stream->error.empty()) throw std::runtime_error("streamed scheduling failed: " + s->stream->error);
       s->sched = s->stream->sched->finish(t.consts);
+      if (profile) fprintf(stderr, "[finalize] streamed: enqueue of the tail %.1f, wait for the worker %.1f, finish %.1f ms\n", t_enq, t_wait - t_enq, since(t_begin) - t_wait);
       s->stream_busy_s = s->stream->busy_s;
       s->stream_windows = s->stream->windows_done;
       {

@@ -116,7 +116,7 @@ class TaskPool {
     n_ = n;
     pending_.store(n, std::memory_order_relaxed);
     const uint64_t gen = (ticket_.load(std::memory_order_relaxed) >> 32) + 1;
-    ticket_.store(gen << 32, std::memory_order_release);   // publishes f_, n_, pending_: section `gen`, next task 0
+    ticket_.store(gen << 32, std::memory_order_seq_cst);   // publishes f_, n_, pending_: section `gen`, next task 0 (seq_cst: ordered before the look at sleepers_)
     if (sleepers_.load() != 0) {
       std::lock_guard<std::mutex> g(mu_);
       cv_.notify_all();
@@ -147,14 +147,14 @@ class TaskPool {
     uint64_t seen = 0;
     auto current = [&] { return ticket_.load(std::memory_order_acquire) >> 32; };
     for (;;) {
-      // Sections follow each other within a fraction of a millisecond while a window is scheduled: poll for a while
-      // before going to sleep (waking a parked thread costs tens of microseconds on metal and milliseconds on some VMs --
-      // more than a section takes)
+      // Sections follow each other within a fraction of a millisecond while a window is scheduled: poll for a moment
+      // before going to sleep (waking a parked thread costs about ten microseconds on metal), but not for long: idle
+      // pollers take cores from the thread that records the next window
       const auto t0 = std::chrono::steady_clock::now();
       uint32_t polls = 0;
       while (current() == seen && !quit_.load(std::memory_order_relaxed)) {
         if ((++polls & 63) == 0) {
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(3)) break;
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
           std::this_thread::yield();
         }
       }
@@ -226,6 +226,8 @@ struct StreamScheduler::Impl {
   std::vector<std::vector<uint32_t>> free_pairs;    // free pairs per pair bank (one list without bank-awareness)
   std::vector<uint32_t> next_fresh_pair;            // smallest never-used pair of each pair bank
   std::vector<uint8_t> pair_live;                   // per pair: values living in it (0, 1 or 2)
+  std::vector<uint64_t> dead_pairs;                 // scratch bitmap of release_batch (assign_slots)
+  std::vector<uint32_t> pending_release;            // slots released at the end of the window before (handed back at the start of the next)
   uint32_t open_single = kInf;                      // a pair one half of which went to an op outside the rows
   uint32_t row_pair = kInf;                         // the pair of the even op just placed (its odd neighbour takes the other half)
   uint32_t n_slots = 0;
@@ -683,13 +685,14 @@ void StreamScheduler::Impl::assign_slots() {
   };
   std::vector<Ext> ext;                               // the same for values of earlier windows
   std::vector<uint32_t> ext_head(n_wlevels + 1, kInf);
+  std::vector<uint32_t> free_now;
   if (!opt.retain_all) {
     // values of earlier windows that were still open: closed now?
     size_t keep = 0;
     for (uint32_t h : open_list) {
       if (!closed(h)) { open_list[keep++] = h; continue; }
       if (last_use[h] < base || n_wlevels == 0) {
-        free_slots.push_back(s.slot_of[h]);   // (never taken with bank-aware slots: GF(2) is one window)
+        free_now.push_back(s.slot_of[h]);     // (handed back below, once the allocator of the field is at hand)
       } else {
         ext.push_back({h, ext_head[last_use[h] - base]});
         ext_head[last_use[h] - base] = (uint32_t)ext.size() - 1;
@@ -765,14 +768,39 @@ void StreamScheduler::Impl::assign_slots() {
     }
     return n_slots++;
   };
-  auto give_back = [&](uint32_t slot) {
+  // Slots that become free together (the values whose last reader sits in one level; at the start of a window also
+  // what the window before left) are handed back as ONE batch.  GF(2): the pairs of a batch that are dead in both halves
+  // go onto the free lists in ascending order whatever order the values came in -- a window that closes values of the
+  // window before it finds them on other lists than the one-window schedule does, and the slot numbers (the bytes of the
+  // LDS program) must not depend on that.
+  std::vector<uint32_t> batch;
+  auto release_batch = [&]() {
     if (!s.boolean_path) {
-      free_slots.push_back(slot);
+      for (uint32_t slot : batch) free_slots.push_back(slot);
+      batch.clear();
       return;
     }
-    const uint32_t d = slot / 2;
-    if (--pair_live[d] == 0 && d != open_single) free_pairs[banked ? d % kPairBanks : 0].push_back(d);   // both halves are dead
+    uint32_t w_lo = kInf, w_hi = 0;
+    for (uint32_t slot : batch) {
+      const uint32_t d = slot / 2;
+      if (--pair_live[d] != 0 || d == open_single) continue;   // (the other half is alive, or still to be handed out)
+      if (dead_pairs.size() <= d / 64) dead_pairs.resize(d / 64 + 1, 0);
+      dead_pairs[d / 64] |= 1ull << (d % 64);
+      w_lo = std::min(w_lo, d / 64);
+      w_hi = std::max(w_hi, d / 64);
+    }
+    batch.clear();
+    for (uint32_t w = w_lo; w != kInf && w <= w_hi; ++w)
+      for (uint64_t bits = dead_pairs[w]; bits; bits &= bits - 1) {
+        const uint32_t d = w * 64 + (uint32_t)__builtin_ctzll(bits);
+        free_pairs[banked ? d % kPairBanks : 0].push_back(d);
+      }
+    for (uint32_t w = w_lo; w != kInf && w <= w_hi; ++w) dead_pairs[w] = 0;
   };
+  // what the window before this one released at its end + its values that have been closed since
+  batch.swap(pending_release);
+  batch.insert(batch.end(), free_now.begin(), free_now.end());
+  release_batch();
   // Order the ops of one (level, kind) run [k0, k1) of `order` for the LDS kernel.  The row ops of a level are ONE
   // sequence (and, then xor, not, copy: order_by_level) and thread t of the workgroup executes ops 2t and 2t + 1 of a
   // 2048-op row of it, so one LDS instruction of a wave serves the even (or the odd) ops of a 128-op block, in two groups
@@ -1145,9 +1173,13 @@ void StreamScheduler::Impl::assign_slots() {
       open_list.push_back(i);
     }
   };
+  auto gather_level = [&](uint32_t l) {
+    for (uint32_t h = expire_head[l]; h != kInf; h = expire_next[h - lo]) batch.push_back(s.slot_of[h]);
+    for (uint32_t e = ext_head[l]; e != kInf; e = ext[e].next) batch.push_back(s.slot_of[ext[e].h]);
+  };
   auto release_level = [&](uint32_t l) {
-    for (uint32_t h = expire_head[l]; h != kInf; h = expire_next[h - lo]) give_back(s.slot_of[h]);
-    for (uint32_t e = ext_head[l]; e != kInf; e = ext[e].next) give_back(s.slot_of[ext[e].h]);
+    gather_level(l);
+    release_batch();
   };
   auto row_class = [&](uint8_t k) { return k == TK_AND || k == TK_XOR || k == TK_NOT || k == TK_COPY; };
   for (uint32_t l = 0; l < n_wlevels; ++l) {
@@ -1232,7 +1264,12 @@ void StreamScheduler::Impl::assign_slots() {
     }
   }
   // what expires at the window's last level is free for the next window
-  if (!opt.retain_all && n_wlevels) release_level(n_wlevels - 1);
+  // (GF(2): kept for the batch the next window opens with, so that it is one batch as in a one-window schedule)
+  if (!opt.retain_all && n_wlevels) {
+    gather_level(n_wlevels - 1);
+    if (s.boolean_path) pending_release.swap(batch);
+    else release_batch();
+  }
 }
 
 void StreamScheduler::Impl::order_levels() {
@@ -1481,8 +1518,17 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
       for (size_t i = i0; i < i1; ++i) {
         uint8_t& k = m.kind[i];
         if (k != TK_ADD && k != TK_MUL && k != TK_ADDC && k != TK_MULC) continue;
-        const bool odd_const = (k == TK_ADDC || k == TK_MULC) && w.consts && m.rb[i] < w.consts->size() &&
-                               !(*w.consts)[m.rb[i]].empty() && ((*w.consts)[m.rb[i]][0] & 1);
+        bool odd_const = false;
+        if (k == TK_ADDC || k == TK_MULC) {
+          if (w.const_parity) {
+            if (m.rb[i] >= w.const_parity->size()) throw Error("scheduler: a GF(2) window names a constant its parity table does not hold");
+            odd_const = (*w.const_parity)[m.rb[i]] != 0;
+          } else if (w.consts && m.rb[i] < w.consts->size()) {
+            odd_const = !(*w.consts)[m.rb[i]].empty() && ((*w.consts)[m.rb[i]][0] & 1);
+          } else {
+            throw Error("scheduler: a GF(2) window comes without its constants");
+          }
+        }
         if (k == TK_ADD) k = TK_XOR;
         else if (k == TK_MUL) k = TK_AND;
         else if (k == TK_ADDC) { k = odd_const ? TK_NOT : TK_COPY; m.rb[i] = 0; }
@@ -1623,8 +1669,7 @@ Schedule build_schedule(const Tape& tape, const FieldHost& field, const Schedule
 }
 
 Schedule build_schedule_windowed(const Tape& tape, const FieldHost& field, const ScheduleOptions& opt) {
-  // GF(2) programs are re-encoded as a whole for the LDS-resident kernel: one window
-  return schedule_windows(tape, field, opt, field.is_two ? std::vector<uint32_t>() : tape.cuts);
+  return schedule_windows(tape, field, opt, tape.cuts);
 }
 
 }  // namespace zki

@@ -140,6 +140,8 @@ struct TapeWindow {
   bool final = false;                     // last window: every value not in `pinned` has seen its last reader
   const std::vector<uint32_t>* pinned = nullptr;
   const std::vector<Value>* consts = nullptr;   // the tape's constant pool (GF(2): the parity of a constant decides what add_constant / mul_constant become)
+  const std::vector<uint8_t>* const_parity = nullptr;   // ... or just the low bit of every constant of the pool so far (a streamed
+                                                        // window: the pool itself keeps growing on the recording thread)
 };
 
 struct WindowResult {  // what add_window() appended to the schedule

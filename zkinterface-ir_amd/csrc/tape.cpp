@@ -1,5 +1,7 @@
 #include "tape.hpp"
 
+#include <algorithm>
+
 #include <string.h>
 
 namespace zki {
@@ -159,6 +161,7 @@ uint32_t TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
   if (tape_.kind.size() >= max_ops_ || tape_.kind.size() >= 0xFFFFFFF0u)
     throw Error("GPU backend: the relation unrolls to more than " + std::to_string(max_ops_) +
                 " backend operations (option max_tape_ops)");
+  if (tape_.window_ops) note_level(kind, a, b);   // (may cut the tape in FRONT of this entry)
   tape_.kind.push_back(kind);
   tape_.a.push_back(a);
   tape_.b.push_back(b);
@@ -166,6 +169,34 @@ uint32_t TapeBackend::push(uint8_t kind, uint32_t a, uint32_t b) {
   const uint32_t h = (uint32_t)(tape_.kind.size() - 1);
   maybe_cut();
   return h;
+}
+
+// Streaming: where to cut.  A window is levelised on its own, behind everything the windows before it hold, so a cut in
+// the middle of a dependency level splits that level in two (a partial level costs a launch, or a barrier and a padded
+// row of the GF(2) kernel).  The recording knows the dependency depth of every entry (copies are transparent, sources have
+// depth 0 -- the scheduler's own levels differ in detail, this only has to find the seams): the entry that is the first
+// to reach a NEW greatest depth opens a level that nothing recorded before it belongs to -- the tape is cut in front of
+// such an entry once the window is full.  A tape that is not recorded level by level gets its cut at twice the window
+// (maybe_cut).  Cuts depend on the tape alone.
+void TapeBackend::note_level(uint8_t kind, uint32_t a, uint32_t b) {
+  uint32_t d = 0;
+  switch (kind) {
+    case TK_ADD: case TK_MUL: case TK_AND: case TK_XOR: d = std::max(depth_[a], depth_[b]) + 1; break;
+    case TK_ADDC: case TK_MULC: case TK_NOT: case TK_ASSERT: case TK_NZ: d = depth_[a] + 1; break;
+    case TK_COPY: d = depth_[a]; break;
+    default: break;   // constant, instance, witness, carried value
+  }
+  if (d > top_depth_) {
+    top_depth_ = d;
+    if (tape_.ladder_open == kNoWire) {
+      const uint32_t last = tape_.cuts.empty() ? 0 : tape_.cuts.back();
+      if (tape_.size() - last >= tape_.window_ops) {
+        tape_.cuts.push_back((uint32_t)tape_.size());
+        if (cut_hook_) cut_hook_(cut_arg_);
+      }
+    }
+  }
+  depth_.push_back(d);
 }
 
 uint32_t TapeBackend::arith(uint8_t kind, uint32_t a, uint32_t b) {

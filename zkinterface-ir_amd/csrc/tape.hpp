@@ -201,6 +201,12 @@ class TapeBackend {
     tape_.window_ops = ops;
     cut_hook_ = hook;
     cut_arg_ = arg;
+    if (!ops) {
+      depth_.clear();
+      depth_.shrink_to_fit();
+    } else if (depth_.size() < tape_.size()) {
+      depth_.resize(tape_.size(), 0);   // (set before the first Relation message: nothing recorded yet)
+    }
   }
 
   // Single-statement use (`evaluate <workspace>`): the values of an Instance /
@@ -252,13 +258,17 @@ class TapeBackend {
   uint32_t push(uint8_t kind, uint32_t a, uint32_t b);
   uint32_t arith(uint8_t kind, uint32_t a, uint32_t b);
   uint32_t bitwise(uint8_t kind, uint32_t a, uint32_t b);
+  // the fallback cut: a window twice as long as asked for that has not met a level seam (note_level, tape.cpp) ends here
   void maybe_cut() {
     if (!tape_.window_ops || tape_.ladder_open != kNoWire) return;
     const uint32_t last = tape_.cuts.empty() ? 0 : tape_.cuts.back();
-    if (tape_.size() - last < tape_.window_ops) return;
+    if (tape_.size() - last < 2 * (uint64_t)tape_.window_ops) return;
     tape_.cuts.push_back((uint32_t)tape_.size());
     if (cut_hook_) cut_hook_(cut_arg_);
   }
+  void note_level(uint8_t kind, uint32_t a, uint32_t b);
+  std::vector<uint32_t> depth_;   // streaming: dependency depth per entry
+  uint32_t top_depth_ = 0;
   void (*cut_hook_)(void*) = nullptr;
   void* cut_arg_ = nullptr;
   uint32_t intern(const Value& bytes);
