@@ -56,11 +56,12 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
         q = code - 2
         v = streams[q & 3][q >> 2]
         return v >= p
-    slots = [None] * n_slots
+    slots = _Slots(n_slots)
     first_fail = None
     noncanon = False
     rng = random.Random(shuffle_seed)
     for (first, count, opw, sequential) in launches:
+        slots.new_launch(bool(sequential))
         idx = list(range(int(first), int(first) + int(count)))
         if shuffle_seed is not None and not sequential:
             rng.shuffle(idx)
@@ -163,6 +164,42 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
         for dst, r in pending:
             slots[dst] = r
     return slots, first_fail, noncanon
+
+
+K_SLOT_IN_LDS = 0x40000000
+
+
+class _Slots:
+    """the wire table + the LDS of the workgroup that walks a strand: a slot number with K_SLOT_IN_LDS names a value that
+    lives in LDS for the duration of ONE sequential launch (csrc/schedule.hpp kSlotInLds); anywhere else it is an error"""
+
+    def __init__(self, n):
+        self.table = [None] * n
+        self.lds = {}
+        self.in_strand = False
+
+    def new_launch(self, sequential):
+        self.lds = {}
+        self.in_strand = sequential
+
+    def __getitem__(self, k):
+        if k & K_SLOT_IN_LDS:
+            assert self.in_strand, 'an LDS slot outside a strand'
+            return self.lds.get(k & ~K_SLOT_IN_LDS)
+        return self.table[k]
+
+    def __setitem__(self, k, v):
+        if k & K_SLOT_IN_LDS:
+            assert self.in_strand, 'an LDS slot outside a strand'
+            self.lds[k & ~K_SLOT_IN_LDS] = v
+        else:
+            self.table[k] = v
+
+    def __len__(self):
+        return len(self.table)
+
+    def __iter__(self):
+        return iter(self.table)
 
 
 def from_device_form(v, p, words_per_const, canonical=None):

@@ -77,6 +77,8 @@ constexpr u32 kNoFail = 0xFFFFFFFFu;
 // slot: kOperandIsSource | (2 + 4 * position + stream), the code of the assert_zero / not sinks (schedule.cpp)
 constexpr u32 kOperandIsSource = 0x80000000u;
 constexpr u32 kLaneFlagNonCanonical = 1u;
+// a slot number of a STRAND's entry with this bit names value k of the workgroup's LDS, [k][chunk][lane] (host: schedule.hpp)
+constexpr u32 kSlotInLds = 0x40000000u;
 
 // What only the input arms of the replay kernels read (instance / witness / carried values and their modes): kept behind
 // ONE pointer so that the eleven words do not sit in SGPRs through every other arm of the cold kernels (with them in the
@@ -214,7 +216,7 @@ struct R1csCorrArgs {
   void launch_replay_fused_w##W(int cls, dim3 grid, size_t lds_pad, hipStream_t st, const ReplayArgs2& a,         \
                                 const FieldParams& fp);                                                             \
   void launch_replay_strand_w##W(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const u32* level_ptr,   \
-                                 u32 n_levels, const FieldParams& fp);                                             \
+                                 u32 n_levels, size_t lds_bytes, const FieldParams& fp);                           \
   void launch_replay_w##W(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp);     \
   void launch_r1cs_w##W(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp);         \
   void launch_dump_w##W(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,  \

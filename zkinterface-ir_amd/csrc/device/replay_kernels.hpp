@@ -86,6 +86,54 @@ __device__ __forceinline__ void wire_store(uint4* __restrict__ rec, const Fp<N>&
   }
 }
 
+// Strands (replay_strand_kernel): a value that never leaves its strand lives in the workgroup's LDS, value k at
+// [k][chunk][lane] in 16-byte chunks like a record of the wire table (a wave's access to a chunk is 64 consecutive 16-byte
+// words: conflict-free ds_read_b128 / ds_write_b128).  A slot number with kSlotInLds names such a value; slot numbers are
+// wave-uniform (they come out of the program entry, on the scalar path), so the choice is a scalar branch.
+extern __shared__ __attribute__((aligned(16))) uint4 zk_strand_lds[];
+
+template <int N>
+__device__ __forceinline__ Fp<N> lds_value_load(u32 k, u32 lane) {
+  Fp<N> r;
+  const u32 base = k * Layout<N>::kRecord + lane;
+#pragma unroll
+  for (int c = 0; c < Layout<N>::kChunks; ++c) {
+    const uint4 v = zk_strand_lds[base + c * 64];
+    r.w[4 * c] = v.x;
+    r.w[4 * c + 1] = v.y;
+    if (4 * c + 2 < N) {
+      r.w[4 * c + 2] = v.z;
+      r.w[4 * c + 3] = v.w;
+    }
+  }
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_value_store(u32 k, u32 lane, const Fp<N>& r) {
+  const u32 base = k * Layout<N>::kRecord + lane;
+#pragma unroll
+  for (int c = 0; c < Layout<N>::kChunks; ++c)
+    zk_strand_lds[base + c * 64] = make_uint4(r.w[4 * c], r.w[4 * c + 1], 4 * c + 2 < N ? r.w[4 * c + 2] : 0u, 4 * c + 2 < N ? r.w[4 * c + 3] : 0u);
+}
+// the value of a slot: out of the wire table, or (LDS: a strand's kernel) out of the workgroup's LDS
+template <int N, bool LDS>
+__device__ __forceinline__ Fp<N> slot_load(const uint4* __restrict__ T, u32 slot, u32 lane) {
+  if constexpr (LDS) {
+    if (slot & kSlotInLds) return lds_value_load<N>(slot & ~kSlotInLds, lane);
+  }
+  return wire_load<N>(T + (size_t)slot * Layout<N>::kRecord);
+}
+template <int N, bool LDS>
+__device__ __forceinline__ void slot_store(uint4* __restrict__ T, u32 slot, u32 lane, const Fp<N>& r) {
+  if constexpr (LDS) {
+    if (slot & kSlotInLds) {
+      lds_value_store<N>(slot & ~kSlotInLds, lane, r);
+      return;
+    }
+  }
+  wire_store<N>(T + (size_t)slot * Layout<N>::kRecord, r);
+}
+
 // One input value of a lane: the low N words of its `stride_words`-word slot (the slot is narrower than N only for a
 // value carried over from a narrower field; it is wider in a session of several fields, whose input buffers have the
 // width of the widest one).  too_wide: the value has bits above the N words -- it is >= R > p and its residue cannot be
@@ -172,7 +220,7 @@ __device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& ar
 // a wire -- or, where the wire is an input the relation has only copied, the RAW value of that input (reference
 // kOperandIsSource | code, the code of unreduced_source_is_nonzero): PlaintextBackend keeps inputs unreduced and the bit
 // operations work on those bits.  A raw value that does not fit the limbs flags the lane.
-template <int N, class Args>
+template <int N, class Args, bool LDS = false>
 __device__ __forceinline__ Fp<N> bit_operand(u32 ref, const uint4* __restrict__ T, const Args& args, u32 lane_g, bool lane_valid,
                                              const FieldParams& fp) {
   if (ref & kOperandIsSource) {
@@ -182,12 +230,12 @@ __device__ __forceinline__ Fp<N> bit_operand(u32 ref, const uint4* __restrict__ 
     if (lane_valid && too_wide) atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
     return raw;
   }
-  return fp_from_mont<N>(wire_load<N>(T + (size_t)ref * Layout<N>::kRecord), fp);
+  return fp_from_mont<N>(slot_load<N, LDS>(T, ref, lane_g & 63), fp);
 }
-template <int N, class Args>
+template <int N, class Args, bool LDS = false>
 __device__ __forceinline__ Fp<N> bit_operation(u32 kind, u32 ref_a, u32 ref_b, const uint4* __restrict__ T, const Args& args, u32 lane_g,
                                                bool lane_valid, const FieldParams& fp) {
-  const Fp<N> x = bit_operand<N>(ref_a, T, args, lane_g, lane_valid, fp), y = bit_operand<N>(ref_b, T, args, lane_g, lane_valid, fp);
+  const Fp<N> x = bit_operand<N, Args, LDS>(ref_a, T, args, lane_g, lane_valid, fp), y = bit_operand<N, Args, LDS>(ref_b, T, args, lane_g, lane_valid, fp);
   Fp<N> r;
 #pragma unroll
   for (int i = 0; i < N; ++i) r.w[i] = kind == OP_AND ? (x.w[i] & y.w[i]) : (x.w[i] ^ y.w[i]);
@@ -312,13 +360,12 @@ __device__ __forceinline__ TapeOp2 load_entry_scalar(const TapeOp2* ops, u32 i) 
 //   kFusedMisc -- every kind except the integer bit operations over an odd field (inputs, constants, copies,
 //                 AddConstant/MulConstant, AssertZero, the `x != 0` indicator, and Add/Mul for sequential segments).
 //   kFusedAll  -- kFusedMisc + and / xor over an odd field (two from_mont + one to_mont each, evaluator.rs:924-933).
-template <int N>
-__device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restrict__ T, const FieldParams& fp) {
-  constexpr int REC = Layout<N>::kRecord;
+template <int N, bool LDS = false>
+__device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restrict__ T, const FieldParams& fp, u32 lane = 0) {
   const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
-  Fp<N> x0 = wire_load<N>(T + (size_t)op.a0 * REC), x1, y0 = wire_load<N>(T + (size_t)op.b0 * REC), y1;
-  if (ea) x1 = wire_load<N>(T + (size_t)op.a1 * REC);
-  if (eb) y1 = wire_load<N>(T + (size_t)op.b1 * REC);
+  Fp<N> x0 = slot_load<N, LDS>(T, op.a0, lane), x1, y0 = slot_load<N, LDS>(T, op.b0, lane), y1;
+  if (ea) x1 = slot_load<N, LDS>(T, op.a1, lane);
+  if (eb) y1 = slot_load<N, LDS>(T, op.b1, lane);
   u32 pv[N];   // the words of p in VGPRs, once per entry: every carry chain below subtracts them (fp_mont.hpp)
   if constexpr (N <= 12) p_words_resident<N>(pv, fp);
   else p_words<N>(pv, fp);   // (beyond 384 bits the kernel is short of registers: let hipcc rematerialise them)
@@ -330,36 +377,35 @@ __device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restric
   if (pair) {
     // a second gate of the same level fed by the shared producer X: store the first result, fetch the second
     // gate's other operand into registers the first no longer needs, and let the common store write it
-    wire_store<N>(T + (size_t)dst_slot * REC, r);
-    y0 = wire_load<N>(T + (size_t)op.pad1 * REC);
+    slot_store<N, LDS>(T, dst_slot, lane, r);
+    y0 = slot_load<N, LDS>(T, op.pad1, lane);
     r = pair == 1 ? fp_add<N>(x0, y0, fp, pv) : fp_mul<N>(x0, y0, fp, pv);
     dst_slot = op.pad0;
   }
-  wire_store<N>(T + (size_t)dst_slot * REC, r);
+  slot_store<N, LDS>(T, dst_slot, lane, r);
 }
 
 // one entry of any kind (the body of the kFusedMisc / kFusedAll instantiations)
-template <int N, int CLS>
+template <int N, int CLS, bool LDS = false>
 __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict__ T, const ReplayArgs2& args, u32 lane_g,
                                             bool lane_valid, const FieldParams& fp) {
-  constexpr int REC = Layout<N>::kRecord;
-  const u32 kind = op.kind & 0xFF;
+  const u32 kind = op.kind & 0xFF, lane = lane_g & 63;
   Fp<N> r;
   bool has_out = true;
   switch (kind) {
     case OP_ADD:
-    case OP_MUL: fused_addmul<N>(op, T, fp); has_out = false; break;
-    case OP_ADDC: r = fp_add<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
-    case OP_MULC: r = fp_mul<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
-    case OP_COPY: r = wire_load<N>(T + (size_t)op.a0 * REC); break;
-    case OP_NZ: r = fp_nonzero_indicator<N>(wire_load<N>(T + (size_t)op.a0 * REC), fp); break;
+    case OP_MUL: fused_addmul<N, LDS>(op, T, fp, lane); has_out = false; break;
+    case OP_ADDC: r = fp_add<N>(slot_load<N, LDS>(T, op.a0, lane), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+    case OP_MULC: r = fp_mul<N>(slot_load<N, LDS>(T, op.a0, lane), fp_load_const<N>(args.consts + (size_t)op.b0 * N), fp); break;
+    case OP_COPY: r = slot_load<N, LDS>(T, op.a0, lane); break;
+    case OP_NZ: r = fp_nonzero_indicator<N>(slot_load<N, LDS>(T, op.a0, lane), fp); break;
     case OP_AND:
     case OP_XOR:
-      if constexpr (CLS == kFusedAll) r = bit_operation<N>(kind, op.a0, op.b0, T, args, lane_g, lane_valid, fp);
+      if constexpr (CLS == kFusedAll) r = bit_operation<N, ReplayArgs2, LDS>(kind, op.a0, op.b0, T, args, lane_g, lane_valid, fp);
       else has_out = false;
       break;
     case OP_NOT:   // op.a1: the unreduced source behind the operand, if any
-      r = fp_indicator<N>(fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC)) &&
+      r = fp_indicator<N>(fp_is_zero<N>(slot_load<N, LDS>(T, op.a0, lane)) &&
                               !unreduced_source_is_nonzero<N>(op.a1, args, lane_g, lane_valid, fp), fp);
       break;
     case OP_CONST: r = fp_load_const<N>(args.consts + (size_t)op.a0 * N); break;
@@ -368,7 +414,7 @@ __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict
     case OP_CARRY: r = input_op<N>(kind, op.a0, args, lane_g, lane_valid, fp); break;
     case OP_ASSERT: {
       has_out = false;
-      const bool nz = !fp_is_zero<N>(wire_load<N>(T + (size_t)op.a0 * REC)) ||
+      const bool nz = !fp_is_zero<N>(slot_load<N, LDS>(T, op.a0, lane)) ||
                       unreduced_source_is_nonzero<N>(op.a1, args, lane_g, lane_valid, fp);
       if (__ballot(nz && lane_valid) != 0ull) {
         if (nz && lane_valid) atomicMin(&args.first_fail[lane_g], op.b0);
@@ -377,7 +423,7 @@ __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict
     }
     default: has_out = false; break;
   }
-  if (has_out) wire_store<N>(T + (size_t)op.dst * REC, r);
+  if (has_out) slot_store<N, LDS>(T, op.dst, lane, r);
 }
 
 template <int N, int CLS>
@@ -423,7 +469,7 @@ __global__ __launch_bounds__(256) void replay_strand_kernel(const ReplayArgs2 ar
   u32 b = lp[0];
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 e = lp[l + 1];
-    for (u32 i = b + wave; i < e; i += 4) fused_entry<N, CLS>(load_entry_scalar(args.ops, i), T, args, lane_g, lane_valid, fp);
+    for (u32 i = b + wave; i < e; i += 4) fused_entry<N, CLS, true>(load_entry_scalar(args.ops, i), T, args, lane_g, lane_valid, fp);
     b = e;
     __syncthreads();   // every wave of the workgroup reaches it once per level (the level bounds are wave-uniform)
   }

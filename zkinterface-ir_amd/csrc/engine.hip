@@ -60,9 +60,9 @@ void launch_fused(uint32_t nwords, int cls, dim3 grid, size_t lds_pad, hipStream
   }
 }
 void launch_strand(uint32_t nwords, int cls, dim3 grid, hipStream_t st, const zkgpu::ReplayArgs2& a, const uint32_t* level_ptr,
-                   uint32_t n_levels, const zkgpu::FieldParams& fp) {
+                   uint32_t n_levels, size_t lds_bytes, const zkgpu::FieldParams& fp) {
   switch (nwords) {
-#define X(W) case W: zkgpu::launch_replay_strand_w##W(cls, grid, st, a, level_ptr, n_levels, fp); break;
+#define X(W) case W: zkgpu::launch_replay_strand_w##W(cls, grid, st, a, level_ptr, n_levels, lds_bytes, fp); break;
     ZK_WIDTHS(X)
 #undef X
     default: throw std::runtime_error("Engine: unsupported limb count");
@@ -204,7 +204,26 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
   auto fail = [](size_t i, const char* what) {
     throw std::runtime_error("Engine: program entry " + std::to_string(i) + " has " + what + " out of range");
   };
+  // entries of a strand may name values in the workgroup's LDS (kSlotInLds | k, k below the strand's lds_slots): the
+  // strands' entry ranges, sorted by first entry
+  std::vector<std::pair<uint64_t, uint64_t>> lds_ranges;   // [first, end) of every strand with LDS slots
+  std::vector<uint32_t> lds_counts;
+  for (const Launch& L : s.launches)
+    if (L.sequential && s.fused && L.lds_slots) {
+      lds_ranges.emplace_back(L.first, (uint64_t)L.first + L.count);
+      lds_counts.push_back(L.lds_slots);
+    }
+  auto lds_cap_of = [&](size_t i) -> uint32_t {
+    auto it = std::upper_bound(lds_ranges.begin(), lds_ranges.end(), std::pair<uint64_t, uint64_t>((uint64_t)i, ~(uint64_t)0));
+    if (it == lds_ranges.begin()) return 0;
+    --it;
+    return i < it->second ? lds_counts[it - lds_ranges.begin()] : 0;
+  };
   auto slot = [&](size_t i, uint32_t v) {
+    if (v & kSlotInLds) {
+      if ((v & ~kSlotInLds) >= lds_cap_of(i)) fail(i, "an LDS slot of a strand");
+      return;
+    }
     if (v >= s.n_slots) fail(i, ("a wire-table slot (" + std::to_string(v) + " of " + std::to_string(s.n_slots) + ")").c_str());
   };
   // the unreduced source an assert_zero / not entry names (0 none, 1 a constant, 2 + 4 * position + stream)
@@ -291,12 +310,14 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
   for (const Launch& L : s.launches) {
     if ((uint64_t)L.first + L.count > n_ops) throw std::runtime_error("Engine: a launch reaches past the program");
     if (L.sequential && s.fused) {   // a strand: its level bounds must be a non-decreasing walk over exactly its entries
-      const uint32_t nl = L.level_end - L.level_begin;
+      const uint32_t nl = L.strand_levels;
       if ((uint64_t)L.level_ptr + nl + 1 > s.strand_level_ptr.size()) throw std::runtime_error("Engine: a strand's level bounds are missing");
       const uint32_t* lp = &s.strand_level_ptr[L.level_ptr];
       for (uint32_t q = 0; q < nl; ++q)
         if (lp[q] > lp[q + 1]) throw std::runtime_error("Engine: a strand's level bounds decrease");
       if (lp[0] != 0 || lp[nl] != L.count) throw std::runtime_error("Engine: a strand's level bounds do not cover its entries");
+      if ((uint64_t)L.lds_slots * (((s.words_per_const ? s.words_per_const : 1) + 3) / 4) * 64 * 16 > kStrandLdsBytes)
+        throw std::runtime_error("Engine: a strand keeps more values in LDS than fit");
     }
   }
 }
@@ -653,7 +674,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
       a.xcd_chunks = 0;
       a.op_stride = 1;
       launch_strand(nwords_, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, dim3(lbs), st, a,
-                    (const uint32_t*)d_level_ptr_ + L.level_ptr, L.level_end - L.level_begin, fp);
+                    (const uint32_t*)d_level_ptr_ + L.level_ptr, L.strand_levels, (size_t)L.lds_slots * ((nwords_ + 3) / 4) * 64 * 16, fp);
       return;
     }
     // a level: its Add/Mul entries (scheduled first) run in the instantiation that holds nothing else; the

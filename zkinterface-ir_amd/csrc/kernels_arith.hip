@@ -23,9 +23,15 @@ void ZKGPU_FN(launch_replay_fused_w)(int cls, dim3 grid, size_t lds_pad, hipStre
 }
 
 void ZKGPU_FN(launch_replay_strand_w)(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const u32* level_ptr, u32 n_levels,
-                                      const FieldParams& fp) {
-  if (cls == kFusedAll) replay_strand_kernel<ZKGPU_W, kFusedAll><<<grid, 256, 0, st>>>(a, level_ptr, n_levels, fp);
-  else replay_strand_kernel<ZKGPU_W, kFusedMisc><<<grid, 256, 0, st>>>(a, level_ptr, n_levels, fp);
+                                      size_t lds_bytes, const FieldParams& fp) {
+  // (up to 128 KiB of dynamic LDS for the strand's own values: above the 64 KiB a kernel gets without asking)
+  if (lds_bytes > 32 * 1024) {   // (per device; a strand is a handful of launches per replay)
+    const void* k = cls == kFusedAll ? reinterpret_cast<const void*>(&replay_strand_kernel<ZKGPU_W, kFusedAll>)
+                                     : reinterpret_cast<const void*>(&replay_strand_kernel<ZKGPU_W, kFusedMisc>);
+    (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  }
+  if (cls == kFusedAll) replay_strand_kernel<ZKGPU_W, kFusedAll><<<grid, 256, lds_bytes, st>>>(a, level_ptr, n_levels, fp);
+  else replay_strand_kernel<ZKGPU_W, kFusedMisc><<<grid, 256, lds_bytes, st>>>(a, level_ptr, n_levels, fp);
 }
 
 // The scheduler always emits ops_per_wave = 1 for a level (measured fastest) and one wave per lane block

@@ -154,7 +154,7 @@ class TaskPool {
       uint32_t polls = 0;
       while (current() == seen && !quit_.load(std::memory_order_relaxed)) {
         if ((++polls & 63) == 0) {
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) break;
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
           std::this_thread::yield();
         }
       }
@@ -177,6 +177,7 @@ class TaskPool {
   std::atomic<uint64_t> ticket_{0};   // section << 32 | next unclaimed task
   std::atomic<uint32_t> pending_{0}, sleepers_{0};
   std::atomic<bool> quit_{false};
+  const long spin_us_ = getenv("ZKI_POOL_SPIN_US") ? atol(getenv("ZKI_POOL_SPIN_US")) : 100;   // (tuning experiments)
 };
 
 enum : uint8_t {  // per-op state inside a window
@@ -227,6 +228,9 @@ struct StreamScheduler::Impl {
   std::vector<uint32_t> next_fresh_pair;            // smallest never-used pair of each pair bank
   std::vector<uint8_t> pair_live;                   // per pair: values living in it (0, 1 or 2)
   std::vector<uint64_t> dead_pairs;                 // scratch bitmap of release_batch (assign_slots)
+  // strands (runs of narrow levels walked by one workgroup per lane block): per level of the window, one past the last
+  // level of its strand (0: the level has a launch of its own), and at a strand's first level the LDS slots it uses
+  std::vector<uint32_t> strand_end, strand_lds_slots;
   std::vector<uint32_t> pending_release;            // slots released at the end of the window before (handed back at the start of the next)
   uint32_t open_single = kInf;                      // a pair one half of which went to an op outside the rows
   uint32_t row_pair = kInf;                         // the pair of the even op just placed (its odd neighbour takes the other half)
@@ -773,10 +777,30 @@ void StreamScheduler::Impl::assign_slots() {
   // go onto the free lists in ascending order whatever order the values came in -- a window that closes values of the
   // window before it finds them on other lists than the one-window schedule does, and the slot numbers (the bytes of the
   // LDS program) must not depend on that.
+  // Strands: what a strand produces and reads for the last time inside itself, and nobody can ask for afterwards, lives in
+  // the LDS of the workgroup that walks it (kSlotInLds) -- a strand's temporaries are re-read by the same workgroup one
+  // level later, and through the wire table that is a store, its acknowledgement and a load from L2 per level.
+  const uint32_t narrow_w = s.fused ? std::max(opt.strand_width, opt.narrow_width) : 0;
+  strand_end.assign(n_wlevels, 0);
+  strand_lds_slots.assign(n_wlevels, 0);
+  if (narrow_w && !opt.retain_all && opt.strand_lds)
+    for (uint32_t l = 0; l < n_wlevels;) {
+      if (level_start[l + 1] - level_start[l] >= narrow_w) { ++l; continue; }
+      uint32_t e = l;
+      while (e < n_wlevels && level_start[e + 1] - level_start[e] < narrow_w) ++e;
+      for (uint32_t q = l; q < e; ++q) strand_end[q] = e;
+      l = e;
+    }
+  const uint32_t lds_value_bytes = ((field.nwords + 3) / 4) * 64 * 16;
+  const uint32_t lds_cap = std::min<uint32_t>(1024, kStrandLdsBytes / std::max<uint32_t>(lds_value_bytes, 1));
+  std::vector<uint32_t> lds_free;
+  uint32_t lds_next = 0, strand_first = 0;
   std::vector<uint32_t> batch;
   auto release_batch = [&]() {
     if (!s.boolean_path) {
-      for (uint32_t slot : batch) free_slots.push_back(slot);
+      for (uint32_t slot : batch)
+        if (slot & kSlotInLds) lds_free.push_back(slot & ~kSlotInLds);
+        else free_slots.push_back(slot);
       batch.clear();
       return;
     }
@@ -1163,7 +1187,22 @@ void StreamScheduler::Impl::assign_slots() {
     }
   };
   auto place = [&](uint32_t i, uint32_t bank = kInf) {
-    s.slot_of[i] = take_slot(bank);
+    const uint32_t wl = s.level_of[i] - base;
+    if (wl < strand_end.size() && strand_end[wl] && closed(i) && std::max(last_use[i], s.level_of[i]) - base < strand_end[wl] &&
+        (!lds_free.empty() || lds_next < lds_cap)) {
+      // strand-local: an LDS slot (released like any other, at the level of its last reader)
+      uint32_t k;
+      if (!lds_free.empty()) {
+        k = lds_free.back();
+        lds_free.pop_back();
+      } else {
+        k = lds_next++;
+        strand_lds_slots[strand_first] = lds_next;
+      }
+      s.slot_of[i] = kSlotInLds | k;
+    } else {
+      s.slot_of[i] = take_slot(bank);
+    }
     if (opt.retain_all) return;
     if (closed(i)) {
       const uint32_t lu = std::max(last_use[i], s.level_of[i]) - base;
@@ -1184,6 +1223,11 @@ void StreamScheduler::Impl::assign_slots() {
   auto row_class = [&](uint8_t k) { return k == TK_AND || k == TK_XOR || k == TK_NOT || k == TK_COPY; };
   for (uint32_t l = 0; l < n_wlevels; ++l) {
     if (!opt.retain_all && l > 0) release_level(l - 1);
+    if (strand_end[l] && (l == 0 || strand_end[l - 1] != strand_end[l])) {   // a strand begins: its LDS is its own
+      lds_free.clear();
+      lds_next = 0;
+      strand_first = l;
+    }
     // GF(2): a level wide enough for a launch of its own runs as rows of the LDS-resident kernel (lds_program.cpp), two
     // ops per thread in the order of its row SEQUENCE -- the and, xor, not and copy ops of the level, in that order
     // (order_by_level); a narrower one joins a sequential segment (emit_launches)
@@ -1439,8 +1483,16 @@ void StreamScheduler::Impl::emit_launches() {
       uint32_t e = l;
       while (e < n_wlevels && level_start[e + 1] - level_start[e] < narrow) ++e;
       L.count = (uint32_t)(level_start[e] - level_start[l]);
+      // the level bounds of the strand: one interval per NON-EMPTY level (a level whose gates were all absorbed by their
+      // readers has nothing to run and needs no barrier)
       L.level_ptr = (uint32_t)s.strand_level_ptr.size();
-      for (uint32_t q = l; q <= e; ++q) s.strand_level_ptr.push_back((uint32_t)(level_start[q] - level_start[l]));
+      s.strand_level_ptr.push_back(0);
+      for (uint32_t q = l; q < e; ++q)
+        if (level_start[q + 1] > level_start[q]) {
+          s.strand_level_ptr.push_back((uint32_t)(level_start[q + 1] - level_start[l]));
+          ++L.strand_levels;
+        }
+      L.lds_slots = l < strand_lds_slots.size() ? strand_lds_slots[l] : 0;
       L.ops_per_wave = std::max<uint32_t>(L.count, 1);
       L.sequential = true;
       L.level_end = base + e;

@@ -20,6 +20,12 @@
 
 namespace zki {
 
+// A slot number with this bit names a value of a STRAND that never leaves the strand (produced in it, last read in it, nobody
+// can ask for it afterwards): it lives in the LDS of the workgroup that walks the strand, [k][chunk][lane], not in the wire
+// table (device/args.hpp kSlotInLds).  Only entries of a strand's launch may carry such slots.
+constexpr uint32_t kSlotInLds = 0x40000000u;
+constexpr uint32_t kStrandLdsBytes = 128 * 1024;   // of the CU's 160 KiB
+
 struct DevOp {  // == zkgpu::TapeOp (device/replay_kernels.hpp)
   uint32_t dst, a, b, kind;
 };
@@ -42,6 +48,8 @@ struct Launch {
                               // its level_end - level_begin + 1 entry offsets (relative to `first`)
   uint32_t window = 0;        // tape window the launch belongs to (its entries were uploaded with that window)
   uint32_t hot_count = 0;     // a level of the fused program: its first hot_count entries are the Add/Mul ones
+  uint32_t strand_levels = 0; // a strand: its non-empty levels = the intervals of its level_ptr list (level_ptr holds one more entry)
+  uint32_t lds_slots = 0;     // a strand: values that live in the workgroup's LDS instead of the wire table (slots kSlotInLds | k, k < lds_slots)
   bool has_bitops = false;    // holds and / xor over an odd field (the kernels' cold instantiation)
 };
 
@@ -59,6 +67,7 @@ struct ScheduleOptions {
   bool pinned_are_carried = false;  // ... because the next field segment takes them over from the wire table (capi.cpp)
   uint32_t threads = 0;             // worker threads for the per-level ordering (0 = min(8, hardware threads))
   bool bank_aware = true;           // GF(2): order the ops and number the slots so that one LDS instruction hits 32 banks
+  bool strand_lds = true;           // strands keep the values that never leave them in LDS (kSlotInLds)
 };
 
 struct Schedule {
