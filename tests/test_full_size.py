@@ -225,6 +225,20 @@ def test_lds_kernel_block_shapes_against_the_cpu_checker(block_rows, monkeypatch
 
 
 @pytest.mark.gpu
+def test_lds_kernel_fuzz_of_shapes_mixes_and_block_sizes():
+    """tools/fuzz_bool_lds.py, bounded: 20 random shapes of the LDS-resident GF(2) kernel -- widths from 96 to 19,000 gates
+    per level, every gate mix (all and, no and, nothing but not), ragged batches, block sizes forced and free, every third
+    relation ingested as a stream -- every lane's first failing assert against the numpy checker"""
+    import importlib.util
+    import os
+    from helpers import ROOT
+    spec = importlib.util.spec_from_file_location('fuzz_bool_lds', os.path.join(ROOT, 'tools', 'fuzz_bool_lds.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(20, seed=4, verbose=False) == 20
+
+
+@pytest.mark.gpu
 def test_full_size_c5_against_python_integer_digests_and_the_cpu_row_check():
     """BASELINE configs[4]: witness generation by zkgpu_r1cs_assign level by level, then the row check.  The generated
     variables of four lanes equal the committed Python-integer values (257 variables spread over all levels); with

@@ -60,13 +60,6 @@ def test_bool_lds_kernel_owns_the_registers_its_asm_names(bool_kernels):
     assert sorted(int(re.search(r'<(\d+)>', n).group(1)) for n in lds) == [4, 6, 8, 9, 10, 12]
 
 
-def test_bool_lds_kernel_variant_builds_keep_the_allocation():
-    """tools/build_variant.sh experiments compile the same unit with other -D flags"""
-    res = kernel_resources.resources('kernels_bool.hip', ['-DZKGPU_LDS_AHEAD=2'])
-    lds = _check_lds_kernels(res, _highest_hand_managed_register())
-    assert sorted(int(re.search(r'<(\d+)>', n).group(1)) for n in lds) == [4, 6, 8, 9, 10]
-
-
 def test_other_boolean_kernels_do_not_spill(bool_kernels):
     for name, k in bool_kernels.items():
         assert k['scratch'] == 0 and k['vgpr_spill'] == 0, (name, k)

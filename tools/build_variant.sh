@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build a variant of libzkgpu.so whose GF(2) kernels are compiled with extra -D flags (kernel experiments):
-#   tools/build_variant.sh NAME "-DZKGPU_LDS_AHEAD=2 ..."   ->  zkinterface-ir_amd/lib/variants/libzkgpu_NAME.so
+#   tools/build_variant.sh NAME "-D..."   ->  zkinterface-ir_amd/lib/variants/libzkgpu_NAME.so
 # tools/c4_diag.py loads it with ZKGPU_VARIANT=NAME.  The product library (lib/libzkgpu.so) is not touched.
 set -e
 cd "$(dirname "$0")/../zkinterface-ir_amd"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing experiments on the LDS-resident GF(2) kernel at the C4 shape (C4_WIDTH / C4_DEPTH / C4_BATCH change it).
-ZKGPU_VARIANT=<name> loads a library built by tools/build_variant.sh (e.g. "-DZKGPU_LDS_AHEAD=2"), ZKGPU_LDS_BLOCK_ROWS
+ZKGPU_VARIANT=<name> loads a library built by tools/build_variant.sh (extra -D flags for kernels_bool.hip), ZKGPU_LDS_BLOCK_ROWS
 forces the block size the engine would otherwise pick.  The expected outputs are not filled in, so every lane fails
 at its first non-zero output bit: the checksum of the first-fail words printed with the time is the same for every
 variant that computes the right values (profiles/r02_tuning_sweeps.txt holds the numbers this produced)."""

@@ -92,6 +92,9 @@ struct InputAux {
   u32 in_stride_words;          // 32-bit words per input value in inst / wit (N, or more in a session of several fields)
   u32 raw_const_base;           // stream 3 of the source codes: constants >= p whose bits are read, kept as plain integers in
                                 // the constant pool from this entry on (Schedule::raw_const_of)
+  // developer instrumentation (null in production): the strand kernel of lane block 0 writes clock stamps here,
+  // [level < kStampLevels][wave 0..3][4]: level start, entry fetched, entry done, barrier passed (tools/strand_stamps.py)
+  unsigned long long* stamps;
 };
 
 struct ReplayArgs {
@@ -132,6 +135,7 @@ struct ReplayArgs2 {
   u32 op_stride;          // 1 or 4, see the kernel
   const InputAux* aux;    // as in ReplayArgs
 };
+constexpr u32 kStampLevels = 256;
 
 // instantiations of replay_fused_kernel (replay_kernels.hpp)
 constexpr int kFusedHot = 0, kFusedMisc = 1, kFusedAll = 2;

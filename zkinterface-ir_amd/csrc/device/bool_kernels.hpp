@@ -236,19 +236,17 @@ __device__ __forceinline__ u32 lds_sload(const u32* table, u32 idx) {
 // travel on the vector path.  The slot fields become LDS byte addresses by ONE SDWA shift each (the 16-bit half is the
 // shifted operand; the wire table starts at LDS address 0: the kernel has no static LDS).
 constexpr int kLdsCompilerVgprs = 64;
-#ifndef ZKGPU_LDS_AHEAD
-#define ZKGPU_LDS_AHEAD 1   // rows whose operand reads are in flight behind the row being computed (2 measured the same)
-#endif
-constexpr int kLdsAhead = ZKGPU_LDS_AHEAD;
+// rows whose operand reads are in flight behind the row being computed.  Fixed: two rows ahead measured the same
+// (profiles/r03_tuning_sweeps.txt) and that build once computed wrong wires (the mid-block prepare only covers one row of
+// program words), so it is not a switch any more -- the counted waits below are written for exactly one row.
+constexpr int kLdsAhead = 1;
 constexpr int kRegP = 64, kRegH = 124, kRegT = kRegH - 4;   // kRegT .. + 3: address / result temporaries of a step
 template <int BR> constexpr int kRegV = kRegP + 4 * BR;   // value sets follow the BR rows of program words
 template <int BR> constexpr bool kLdsFits = kRegP + 4 * BR + 4 * (kLdsAhead + 1) <= kRegT;
 // Four registers between the value sets and the step temporaries, where a block size leaves them: the LDS addresses of
 // the next block's row 0, computed in the middle of a block (ldsp_run)
 template <int BR> constexpr int kRegU = kRegV<BR> + 4 * (kLdsAhead + 1);
-// (one row of reads ahead only: with more, a block's start also needs the program words of its later rows, which the
-// wait in the middle of the block before it does not cover)
-template <int BR> constexpr bool kLdsEarly = kLdsAhead == 1 && kRegU<BR> + 4 <= kRegT;
+template <int BR> constexpr bool kLdsEarly = kRegU<BR> + 4 <= kRegT;
 static_assert((kRegT + 2) % 2 == 0, "the two results of a row step are the data of one ds_write_b64: an aligned register pair");
 
 #define ZKGPU_SDWA_LO " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0\n\t"
@@ -412,8 +410,6 @@ __device__ __forceinline__ void ldsp_block(const u32* hdr_next3, u32 vzero, cons
                                            const u32 (&voff)[BR], Hook&& hook = Hook()) {
   if constexpr (N <= BR && A <= N) {
     ldsp_issue<BR, 0, T0>();   // (the addresses of row 0 were computed in front of the barrier: ldsp_run)
-    if constexpr (N > 1 && kLdsAhead > 1) { ldsp_addr<BR, 1>(); ldsp_issue<BR, 1>(); }
-    if constexpr (N > 2 && kLdsAhead > 2) { ldsp_addr<BR, 2>(); ldsp_issue<BR, 2>(); }
     // (the header load stays behind the barrier: issued in front of it, with the rest of the prologue, the replay of C4
     // took 3 % longer -- profiles/r03_tuning_sweeps.txt)
     ldsp_gload_header(hdr_next3, vzero);
@@ -535,7 +531,7 @@ __device__ __forceinline__ void ldsp_run(const BoolLdsArgs& args, u32 first, u32
 // BR: rows every block fetches (the host picks the instantiation that fetches least for the program at hand)
 template <int BR>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVgprs))) void bool_lds_kernel(const BoolLdsArgs args) {
-  static_assert(BR > kLdsAhead && BR <= kLdsMaxBlockRows && kLdsAhead >= 1 && kLdsAhead <= 3 && kLdsFits<BR>, "block rows");
+  static_assert(BR > kLdsAhead && BR <= kLdsMaxBlockRows && kLdsAhead == 1 && kLdsFits<BR>, "block rows");
   extern __shared__ __attribute__((aligned(16))) u32 T[];
   asm volatile("" ::: "v125");   // the highest hand-managed register: the kernel is allocated 126 (-> 128) registers
   const u32 tid = threadIdx.x;

@@ -298,6 +298,99 @@ __device__ __forceinline__ Fp<N> fp_mul(const Fp<N>& a, const Fp<N>& b, const Fi
   return fp_cond_sub<N>(t, __ballot(t[N] != 0), fp, nullptr, pv);
 }
 
+// ---- the same product, written for LATENCY -------------------------------------------------------------------------
+// fp_mul above accumulates a column's word products into ONE 96-bit accumulator, each v_mad_u64_u32 waiting for the one
+// before it and each v_addc_co_u32 for its own mad: fine with eight waves per SIMD (some other wave always has an
+// instruction ready), but a STRAND is one workgroup per lane block -- one wave per SIMD at most -- and there the
+// dependent chain is what takes the time (tools/mul_latency.hip: about 2.4 times the cycles per product of this form).
+// Here every column k of the double-width result has an accumulator of its own (lo64 : hi32), a row of products
+// x[j] * y goes to columns that are all different, and a statement issues four mads with four different carry registers
+// (SGPR pairs, VOP3b) before the four add-with-carries that consume them: consecutive instructions never depend on each
+// other.  Operand-scanning Montgomery: step k clears the low word of column k with m = lo * n0inv, m * p[j] going to
+// columns k .. k + N - 1, and hands the column's upper words on to columns k + 1 and k + 2.  Same result as fp_mul, bit
+// for bit (canonical out); twice the registers.
+__device__ __forceinline__ void madc4(u64& c0, u64& c1, u64& c2, u64& c3, u32& h0, u32& h1, u32& h2, u32& h3, u32 x0, u32 x1, u32 x2,
+                                      u32 x3, u32 y) {
+  u64 s0, s1, s2, s3;
+  asm("v_mad_u64_u32 %0, %8, %12, %16, %0\n\t"
+      "v_mad_u64_u32 %1, %9, %13, %16, %1\n\t"
+      "v_mad_u64_u32 %2, %10, %14, %16, %2\n\t"
+      "v_mad_u64_u32 %3, %11, %15, %16, %3\n\t"
+      "v_addc_co_u32_e64 %4, %8, 0, %4, %8\n\t"
+      "v_addc_co_u32_e64 %5, %9, 0, %5, %9\n\t"
+      "v_addc_co_u32_e64 %6, %10, 0, %6, %10\n\t"
+      "v_addc_co_u32_e64 %7, %11, 0, %7, %11"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(y));
+}
+// ... with the first factors wave-uniform (the words of p, in SGPRs: one scalar operand per instruction) and the second a VGPR
+__device__ __forceinline__ void madc4_s(u64& c0, u64& c1, u64& c2, u64& c3, u32& h0, u32& h1, u32& h2, u32& h3, u32 x0, u32 x1, u32 x2,
+                                        u32 x3, u32 y) {
+  u64 s0, s1, s2, s3;
+  asm("v_mad_u64_u32 %0, %8, %16, %12, %0\n\t"
+      "v_mad_u64_u32 %1, %9, %16, %13, %1\n\t"
+      "v_mad_u64_u32 %2, %10, %16, %14, %2\n\t"
+      "v_mad_u64_u32 %3, %11, %16, %15, %3\n\t"
+      "v_addc_co_u32_e64 %4, %8, 0, %4, %8\n\t"
+      "v_addc_co_u32_e64 %5, %9, 0, %5, %9\n\t"
+      "v_addc_co_u32_e64 %6, %10, 0, %6, %10\n\t"
+      "v_addc_co_u32_e64 %7, %11, 0, %7, %11"
+      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
+      : "s"(x0), "s"(x1), "s"(x2), "s"(x3), "v"(y));
+}
+// (hi : lo) += x, a 32-bit word added to a 96-bit accumulator
+__device__ __forceinline__ void addw(u64& lo, u32& hi, u32 x) {
+  u64 s;
+  asm("v_mad_u64_u32 %0, %2, 1, %3, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(lo), "+v"(hi), "=&s"(s) : "v"(x));
+}
+
+template <int N>
+__device__ __forceinline__ Fp<N> fp_mul_wide(const Fp<N>& a, const Fp<N>& b, const FieldParams& fp, const u32* pv = nullptr) {
+  static_assert(N % 4 == 0 || N % 4 == 2, "");
+  u64 lo[2 * N + 2];
+  u32 hi[2 * N + 2];
+#pragma unroll
+  for (int k = 0; k < 2 * N + 2; ++k) { lo[k] = 0; hi[k] = 0; }
+  // the double-width product: row i = a * b[i] into columns i .. i + N - 1
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int j = 0; j + 4 <= N; j += 4)
+      madc4(lo[i + j], lo[i + j + 1], lo[i + j + 2], lo[i + j + 3], hi[i + j], hi[i + j + 1], hi[i + j + 2], hi[i + j + 3], a.w[j], a.w[j + 1],
+            a.w[j + 2], a.w[j + 3], b.w[i]);
+    if constexpr (N % 4 == 2) {
+      ZKGPU_MADC(lo[i + N - 2], hi[i + N - 2], a.w[N - 2], b.w[i]);
+      ZKGPU_MADC(lo[i + N - 1], hi[i + N - 1], a.w[N - 1], b.w[i]);
+    }
+  }
+  // the reduction, column by column
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const u32 m = (u32)lo[k] * fp.n0inv;
+#pragma unroll
+    for (int j = 0; j + 4 <= N; j += 4)
+      madc4_s(lo[k + j], lo[k + j + 1], lo[k + j + 2], lo[k + j + 3], hi[k + j], hi[k + j + 1], hi[k + j + 2], hi[k + j + 3], fp.p[j],
+              fp.p[j + 1], fp.p[j + 2], fp.p[j + 3], m);
+    if constexpr (N % 4 == 2) {
+      ZKGPU_MADC_S(lo[k + N - 2], hi[k + N - 2], m, fp.p[N - 2]);
+      ZKGPU_MADC_S(lo[k + N - 1], hi[k + N - 1], m, fp.p[N - 1]);
+    }
+    // the low word of column k is zero now: its upper words belong to the next two columns
+    addw(lo[k + 1], hi[k + 1], (u32)(lo[k] >> 32));
+    addw(lo[k + 2], hi[k + 2], hi[k]);
+  }
+  u32 t[N + 1];
+#pragma unroll
+  for (int k = N; k < 2 * N; ++k) {
+    t[k - N] = (u32)lo[k];
+    addw(lo[k + 1], hi[k + 1], (u32)(lo[k] >> 32));
+    addw(lo[k + 2], hi[k + 2], hi[k]);
+  }
+  t[N] = (u32)lo[2 * N];
+  // t < 2p here; one conditional subtraction.
+  return fp_cond_sub<N>(t, __ballot(t[N] != 0), fp, nullptr, pv);
+}
+
 // N wave-uniform words (a coefficient in Montgomery form) read on the scalar path into SGPRs
 template <int N>
 struct FpS {

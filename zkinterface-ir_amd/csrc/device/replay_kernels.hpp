@@ -467,11 +467,43 @@ __global__ __launch_bounds__(256) void replay_strand_kernel(const ReplayArgs2 ar
   typedef const u32 __attribute__((address_space(4))) cu32;
   cu32* lp = (cu32*)(unsigned long long)level_ptr;
   u32 b = lp[0];
+#ifdef ZKGPU_STRAND_STAMPS   // developer build (tools/strand_stamps.py): where the time of a level goes
+  unsigned long long* const stamps = ((InputAuxS*)(unsigned long long)args.aux)->stamps;
+  const bool stamp = stamps != nullptr && blockIdx.x == 0 && n_levels >= kStampLevels;
+#endif
   for (u32 l = 0; l < n_levels; ++l) {
     const u32 e = lp[l + 1];
-    for (u32 i = b + wave; i < e; i += 4) fused_entry<N, CLS, true>(load_entry_scalar(args.ops, i), T, args, lane_g, lane_valid, fp);
+#ifdef ZKGPU_STRAND_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (stamp) t0 = t1 = t2 = __builtin_readcyclecounter();
+#endif
+    for (u32 i = b + wave; i < e; i += 4) {
+      const TapeOp2 op = load_entry_scalar(args.ops, i);
+#ifdef ZKGPU_STRAND_STAMPS
+      if (stamp) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t1 = __builtin_readcyclecounter();
+      }
+#endif
+      fused_entry<N, CLS, true>(op, T, args, lane_g, lane_valid, fp);
+    }
+#ifdef ZKGPU_STRAND_STAMPS
+    if (stamp) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      t2 = __builtin_readcyclecounter();
+    }
+#endif
     b = e;
     __syncthreads();   // every wave of the workgroup reaches it once per level (the level bounds are wave-uniform)
+#ifdef ZKGPU_STRAND_STAMPS
+    if (stamp && l < kStampLevels && lane == 0) {
+      unsigned long long* q = stamps + ((size_t)l * 4 + wave) * 4;
+      q[0] = t0;
+      q[1] = t1;
+      q[2] = t2;
+      q[3] = __builtin_readcyclecounter();
+    }
+#endif
   }
 }
 

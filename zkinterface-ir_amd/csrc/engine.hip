@@ -150,6 +150,7 @@ Engine::~Engine() {
   dfree(d_carry_slots_);
   dfree(d_input_aux_);
   dfree(d_generic_params_);
+  dfree(d_stamps_);
   dfree(d_r1cs_rows_);
   dfree(d_r1cs_terms_);
   dfree(d_r1cs_coefs_);
@@ -506,6 +507,14 @@ void Engine::set_batch(uint32_t batch) {
     aux.in_stride_words = in_stride_ / 4;
     // (the pool: the tape's constants in device form, then the raw ones)
     aux.raw_const_base = (uint32_t)(sched_.const_words.size() / std::max<uint32_t>(sched_.words_per_const, 1) - sched_.raw_const_of.size());
+    // developer instrumentation: ZKGPU_STRAND_STAMPS=<file> -- clock stamps of the first levels of the strands of >= 256
+    // levels, lane block 0 (the last such strand of a replay wins), written to the file by synchronize()
+    if (const char* path = getenv("ZKGPU_STRAND_STAMPS")) {
+      if (!d_stamps_) HIP_OK(hipMalloc(&d_stamps_, zkgpu::kStampLevels * 16 * 8));
+      HIP_OK(hipMemset(d_stamps_, 0, zkgpu::kStampLevels * 16 * 8));
+      aux.stamps = (unsigned long long*)d_stamps_;
+      stamps_path_ = path;
+    }
     if (!d_input_aux_) HIP_OK(hipMalloc(&d_input_aux_, sizeof aux));
     HIP_OK(hipMemcpy(d_input_aux_, &aux, sizeof aux, hipMemcpyHostToDevice));
   }
@@ -1075,6 +1084,14 @@ void Engine::r1cs_results(std::vector<uint32_t>* first_fail_row, uint64_t counts
 void Engine::synchronize() {
   use_device();
   HIP_OK(hipStreamSynchronize((hipStream_t)stream_));
+  if (d_stamps_ && !stamps_path_.empty()) {
+    std::vector<unsigned long long> h(zkgpu::kStampLevels * 16);
+    HIP_OK(hipMemcpy(h.data(), d_stamps_, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(stamps_path_.c_str(), "wb")) {
+      fwrite(h.data(), 8, h.size(), f);
+      fclose(f);
+    }
+  }
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, (hipEvent_t)ev_begin_, (hipEvent_t)ev_end_) == hipSuccess) last_ms_ = ms;
 }

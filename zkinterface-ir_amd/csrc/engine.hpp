@@ -121,6 +121,8 @@ class Engine {
   void staged_upload(void* dst, const uint8_t* src, size_t bytes);
 
   Schedule sched_;  // host copy (launch list)
+  void* d_stamps_ = nullptr;        // developer instrumentation (ZKGPU_STRAND_STAMPS)
+  std::string stamps_path_;
   bool loaded_ = false;
   bool boolean_ = false;
   bool generic_ = false;           // canonical residues, the any-modulus kernels (FieldHost::generic)

@@ -23,11 +23,7 @@ void launch_bool_replay(dim3 grid, hipStream_t st, const BoolReplayArgs& a) {
   bool_replay_kernel<<<grid, 256, 0, st>>>(a);
 }
 
-#if ZKGPU_LDS_AHEAD > 1   // a third value set: no registers left for 12-row blocks
-#define ZKGPU_LDS_BLOCK_ROWS(X) X(4) X(6) X(8) X(9) X(10)
-#else
 #define ZKGPU_LDS_BLOCK_ROWS(X) X(4) X(6) X(8) X(9) X(10) X(12)
-#endif
 
 hipError_t bool_lds_set_max_shared(int bytes) {
 #define X(BR)                                                                                                          \

@@ -557,8 +557,24 @@ void StreamScheduler::Impl::levelise() {
     if (ni == 2) note_reader(rb[i - lo], (uint32_t)lv);
     top = std::max(top, (uint32_t)lv + 1);
   }
+  // Inside a STRAND (a run of narrow levels walked by one workgroup, a barrier per level) "one level before" puts an input's
+  // fetch from HBM and its conversion -- a whole Montgomery product -- into the level in front of its reader, which in a
+  // dependency chain is as often as not a level of additions: that level then lasts as long as the input takes (measured
+  // on the chained structured relation: 4,100 cycles instead of 1,500).  Where the two levels in front of the reader are
+  // both narrow the input goes one level further up, next to the products of the chain, on a wave that has nothing to do.
+  std::vector<uint32_t> width;
+  if (s.fused && !sources.empty()) {
+    width.assign(top - base + 1, 0);
+    for (uint32_t i = lo; i < hi; ++i)
+      if (st(i) != ST_ELIDED && n_inputs(kind[i - lo]) != 0) ++width[level[i] - base];
+  }
+  const uint32_t narrow = std::max(opt.strand_width, opt.narrow_width);
   for (uint32_t i : sources) {
-    level[i] = first_use[i - lo] == kInf ? base : first_use[i - lo] - 1;
+    uint32_t lv = first_use[i - lo] == kInf ? base : first_use[i - lo] - 1;
+    if (!width.empty() && first_use[i - lo] != kInf && lv >= base + 1 && width[lv - base] < narrow && width[lv - 1 - base] < narrow &&
+        width[lv - base] + width[lv - 1 - base] > 0)
+      --lv;
+    level[i] = lv;
     if (last_use[i] < level[i]) last_use[i] = level[i];
     top = std::max(top, level[i] + 1);
   }
