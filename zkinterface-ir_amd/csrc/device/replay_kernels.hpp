@@ -363,8 +363,12 @@ __device__ __forceinline__ TapeOp2 load_entry_scalar(const TapeOp2* ops, u32 i) 
 template <int N, bool LDS = false>
 __device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restrict__ T, const FieldParams& fp, u32 lane = 0) {
   const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
-  Fp<N> x0 = slot_load<N, LDS>(T, op.a0, lane), x1, y0 = slot_load<N, LDS>(T, op.b0, lane), y1;
+  // (in the order of their use: where an operand may come from LDS or from the wire table -- a strand -- the wait in front
+  // of its first use covers every load issued before it on either path, so the operands of the first inner operation go
+  // first and what only the last operation reads goes last: its fetch from HBM then overlaps the inner product)
+  Fp<N> x0 = slot_load<N, LDS>(T, op.a0, lane), x1, y0, y1;
   if (ea) x1 = slot_load<N, LDS>(T, op.a1, lane);
+  y0 = slot_load<N, LDS>(T, op.b0, lane);
   if (eb) y1 = slot_load<N, LDS>(T, op.b1, lane);
   u32 pv[N];   // the words of p in VGPRs, once per entry: every carry chain below subtracts them (fp_mont.hpp)
   if constexpr (N <= 12) p_words_resident<N>(pv, fp);

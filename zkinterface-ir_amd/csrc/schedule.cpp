@@ -274,6 +274,8 @@ struct StreamScheduler::Impl {
   void propagate_copies();
   void levelise();
   void fuse_and_pair();
+  void place_strand_sources();
+  std::vector<uint32_t> window_sources;   // constant / instance / witness / carry ops of the window (levelise)
   void order_by_level();
   void assign_slots();
   void order_levels();
@@ -557,27 +559,12 @@ void StreamScheduler::Impl::levelise() {
     if (ni == 2) note_reader(rb[i - lo], (uint32_t)lv);
     top = std::max(top, (uint32_t)lv + 1);
   }
-  // Inside a STRAND (a run of narrow levels walked by one workgroup, a barrier per level) "one level before" puts an input's
-  // fetch from HBM and its conversion -- a whole Montgomery product -- into the level in front of its reader, which in a
-  // dependency chain is as often as not a level of additions: that level then lasts as long as the input takes (measured
-  // on the chained structured relation: 4,100 cycles instead of 1,500).  Where the two levels in front of the reader are
-  // both narrow the input goes one level further up, next to the products of the chain, on a wave that has nothing to do.
-  std::vector<uint32_t> width;
-  if (s.fused && !sources.empty()) {
-    width.assign(top - base + 1, 0);
-    for (uint32_t i = lo; i < hi; ++i)
-      if (st(i) != ST_ELIDED && n_inputs(kind[i - lo]) != 0) ++width[level[i] - base];
-  }
-  const uint32_t narrow = std::max(opt.strand_width, opt.narrow_width);
   for (uint32_t i : sources) {
-    uint32_t lv = first_use[i - lo] == kInf ? base : first_use[i - lo] - 1;
-    if (!width.empty() && first_use[i - lo] != kInf && lv >= base + 1 && width[lv - base] < narrow && width[lv - 1 - base] < narrow &&
-        width[lv - base] + width[lv - 1 - base] > 0)
-      --lv;
-    level[i] = lv;
+    level[i] = first_use[i - lo] == kInf ? base : first_use[i - lo] - 1;
     if (last_use[i] < level[i]) last_use[i] = level[i];
     top = std::max(top, level[i] + 1);
   }
+  window_sources.swap(sources);
   n_wlevels = top - base;
 }
 
@@ -641,6 +628,53 @@ void StreamScheduler::Impl::fuse_and_pair() {
       extend(ra[i - lo], level[c1]);
       extend(rb[i - lo], level[c1]);
     }
+  }
+}
+
+// Inside a STRAND (a run of narrow levels walked by one workgroup, a barrier per level) "one level before its first reader"
+// can put an input's fetch from HBM and its conversion -- a whole Montgomery product -- into a level of the chain that only
+// adds (that level then lasts as long as the input takes: measured on the chained structured relation, 4,100 cycles instead
+// of 1,500), or into a level whose gates have all been absorbed by their readers, which would otherwise not exist at all.
+// Once fusion has decided what the levels hold, an input of a narrow region moves up to the nearest level in front of its
+// reader that has work of its own, products if possible, and a wave to spare.
+void StreamScheduler::Impl::place_strand_sources() {
+  if (!s.fused || window_sources.empty() || !n_wlevels) return;
+  std::vector<uint32_t>& level = s.level_of;
+  std::vector<uint16_t> count(n_wlevels, 0), heavy(n_wlevels, 0);   // entries per level (saturating), entries with a product
+  auto bump = [](uint16_t& c) { if (c < 0xFFFF) ++c; };
+  auto has_product = [&](uint32_t i) {
+    const uint8_t k = kind[i - lo];
+    if (k == TK_MUL || k == TK_MULC || k == TK_INSTANCE || k == TK_WITNESS || k == TK_CARRY) return true;
+    if (k != TK_ADD) return false;
+    for (uint32_t x : {ra[i - lo], rb[i - lo]})
+      if (inner(x) && kind[x - lo] == TK_MUL) return true;
+    return false;
+  };
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (st(i) != ST_ENTRY || n_inputs(kind[i - lo]) == 0) continue;
+    bump(count[level[i] - base]);
+    if (has_product(i)) bump(heavy[level[i] - base]);
+  }
+  const uint32_t narrow = std::max(opt.strand_width, opt.narrow_width);
+  for (uint32_t i : window_sources) {
+    if (st(i) != ST_ENTRY) continue;
+    const uint32_t P = level[i] - base;
+    uint32_t target = P;
+    if (count[P] < narrow) {
+      const bool converts = kind[i - lo] != TK_CONST;
+      const uint32_t floor_l = P >= 4 ? P - 4 : 0;
+      uint32_t nonempty = kInf, good = kInf;
+      for (uint32_t L = P + 1; L-- > floor_l;) {
+        if (count[L] >= narrow) break;   // (a wide level: not part of this strand)
+        if (count[L] == 0) continue;
+        if (nonempty == kInf) nonempty = L;
+        if (converts && heavy[L] > 0 && count[L] < 4) { good = L; break; }
+      }
+      target = good != kInf ? good : nonempty != kInf ? nonempty : P;
+    }
+    level[i] = base + target;
+    bump(count[target]);
+    if (kind[i - lo] != TK_CONST) bump(heavy[target]);
   }
 }
 
@@ -1612,6 +1646,7 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     m.levelise();
     lap();
     m.fuse_and_pair();
+    m.place_strand_sources();
     lap();
     m.order_by_level();
     lap();
