@@ -47,7 +47,14 @@ const char* zkgpu_last_error(const zkgpu_session* s);
 const char* zkgpu_version(void);
 
 /* ---- 1. ZKBackend trait (evaluator.rs:17-76) ----------------------------- */
-/* Wires are uint32 handles owned by the session (like IRFlattener::Wire = WireId). */
+/* Wires are uint32 handles owned by the session (like IRFlattener::Wire = WireId); they are session-wide numbers, never
+ * reused.
+ * set_field: the reference's Evaluator calls it for every Relation message with whatever modulus the header holds
+ * (evaluator.rs:262-268).  The same modulus again only updates is_boolean.  ANOTHER modulus opens a new field segment
+ * (see "Field segments" below): the wires that live on are the handles the caller has not reported dropped
+ * (zkgpu_backend_drop) -- they keep their numbers and hold, in the new field, the integers they held; a handle that was
+ * dropped before the change is an error to name afterwards.  A binding whose Wire type does not implement Drop keeps
+ * every value alive, and every value would have to be carried: refused beyond 2^20 live wires, with a text that says so. */
 int zkgpu_backend_set_field(zkgpu_session* s, const uint8_t* modulus_le, size_t len, uint32_t degree,
                             int is_boolean);                                   /* :28 */
 int zkgpu_backend_copy(zkgpu_session* s, uint32_t wire, uint32_t* out);        /* :38 */
@@ -267,9 +274,9 @@ int zkgpu_n_engines(const zkgpu_session* s);                  /* engines the bat
  * are handed over in that width whichever segment consumes them (a value that does not fit the limbs of the field that
  * consumes it flags its lane).  A session that changes between GF(2) and another field keeps its GF(2) wires as
  * integers too (the any-modulus kernels, zkgpu_field_representation 2): one value per input position in the common
- * width instead of one byte.  Not supported, with an error that says so: a
- * change on a caller-driven backend (zkgpu_backend_set_field: the library cannot see which wires are alive), several
- * devices, R1CS entry points, zkgpu_replay_timed; option "stream" is switched off at the first change.
+ * width instead of one byte.  A caller-driven backend changes its field through zkgpu_backend_set_field (the wires that
+ * live on: the handles not dropped).  Not supported, with an error that says so: R1CS entry points, zkgpu_replay_timed;
+ * option "stream" is switched off at the first change.
  * _info: out = {values carried in, first assert sequence number, 32-bit words per value, values carried out}. */
 int zkgpu_n_field_segments(const zkgpu_session* s);
 int zkgpu_field_segment_info(const zkgpu_session* s, uint32_t k, uint32_t out[4]);

@@ -140,7 +140,9 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                 stream = {OP['instance']: 0, OP['witness']: 1, OP['carry']: 2}[kind]
                 v = streams[stream][a]
                 mode = mode_of(stream, a)
-                if not boolean and v >= wide:      # wider than the limbs of this field: cannot be represented, the lane is flagged
+                # wider than the limbs of this field: reduced like any other value where only arithmetic reads it (the
+                # reference's gates are `% m` of whatever integer comes in); flagged where its bits matter
+                if not boolean and v >= wide and mode in (0xFF, 0x03):
                     noncanon = True
                 if v >= p and mode == 0xFF:     # the unreduced value would reach an integer bit operation / Evaluator::get
                     noncanon = True

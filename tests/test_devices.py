@@ -142,3 +142,82 @@ def test_counts_through_rccl_with_a_one_device_communicator():
     two.synchronize()
     with pytest.raises(zk.ZkGpuError, match='force_rccl'):
         two.counts()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('retain', [False, True])
+def test_field_segments_over_several_engines(retain):
+    """a relation whose field characteristic changes between messages (tests/test_field_segments.py) with the lanes split
+    over three engines: every engine runs a chain of its own (one engine per field segment); counts, per-lane results,
+    violation texts and the wire values of every call equal the single-engine session's and the oracle's"""
+    import test_field_segments as fs
+    from zkinterface_ir_amd import sieve_writer as sw
+    msgs = fs._messages(fs.GROW)
+    base = fs._lanes_grow()
+    rows = [base[k % len(base)] for k in range(200)]
+    sessions = {}
+    for devices in (None, '0,0,0'):
+        ev = zk.Evaluator()
+        if devices:
+            ev.set_option('devices', devices)
+        ev.declare_inputs(2, 2)
+        for m in msgs:
+            ev.ingest_message(m)
+        ev.finalize(retain_all=retain)
+        inst, wit = batch_arrays([r[0] for r in rows], [r[1] for r in rows], ev.elem_bytes)
+        ev.set_inputs(inst, wit, len(rows))
+        ev.replay()
+        ev.synchronize()
+        sessions[devices] = ev
+    one, many = sessions[None], sessions['0,0,0']
+    assert many.n_engines == 3 and many.n_field_segments == 2
+    assert many.counts() == one.counts() == (150, 50)
+    assert np.array_equal(one.lane_results(len(rows))[0], many.lane_results(len(rows))[0])
+    for lane in (0, 1, 2, 3, 66, 130, 199):
+        ref = oracle_lane(sw.int_to_le(fs.P1), rows[lane][0], rows[lane][1], msgs, 32, trace=False)
+        assert many.get_violations(lane) == one.get_violations(lane) == ref.violations, lane
+    if retain:
+        assert many.dump_trace_values(len(rows)) == one.dump_trace_values(len(rows))
+
+
+@pytest.mark.gpu
+def test_r1cs_rows_over_two_engines_give_the_single_engine_results():
+    """the C5 shape, small: witness generation level by level and the row check with the lanes split over two engines
+    (rows replicated like the program): first failing rows, counts and the values of sampled variables equal the
+    single-engine session's"""
+    wl = workloads.R1csSynthetic(M=600, n_base=32, n_coefs=50, seed=5)
+    batch = 200
+    row_ptr, tv, tc, cb = wl.csr()
+    results = {}
+    for devices in (None, '0,0'):
+        ev = zk.Evaluator()
+        if devices:
+            ev.set_option('devices', devices)
+        ev.declare_inputs(0, wl.n_witness)
+        ev.ingest_message(wl.base_relation())
+        ev.finalize(retain_all=True)
+        ev.r1cs_load_csr(row_ptr, tv, tc, cb, wl.width, wl.M)
+        w = wl.witnesses(batch)
+        ev.set_inputs(None, w.tobytes(), batch)
+        ev.replay()
+        lo = 0
+        for hi in wl.level_bounds:
+            ev.r1cs_assign(lo, int(hi) - lo)
+            lo = int(hi)
+        zl = ev.r1cs_get_var(wl.last_z, batch)
+        for lane in range(batch):
+            v = zl[lane] if lane % 9 else (zl[lane] + 1) % wl.p
+            w[lane, wl.n_base] = np.frombuffer(v.to_bytes(wl.width, 'little'), dtype=np.uint8)
+        ev.set_inputs(None, w.tobytes(), batch)
+        ev.replay()
+        lo = 0
+        for hi in wl.level_bounds:
+            ev.r1cs_assign(lo, int(hi) - lo)
+            lo = int(hi)
+        ev.r1cs_check()
+        ff, counts = ev.r1cs_results(batch)
+        results[devices] = (np.asarray(ff).copy(), tuple(counts), zl, ev.r1cs_get_vars([wl.n_base + 1, wl.n_base + 1 + wl.M // 2, wl.last_z], batch))
+    one, two = results[None], results['0,0']
+    n_bad = sum(1 for lane in range(batch) if lane % 9 == 0)
+    assert one[1] == two[1] == (batch - n_bad, n_bad)
+    assert np.array_equal(one[0], two[0]) and one[2] == two[2] and one[3] == two[3]

@@ -172,12 +172,14 @@ def test_inputs_and_constants_cross_a_field_change_on_the_gpu():
 
 
 def test_what_a_field_change_still_refuses():
-    # (between GF(2) and another field: tests/test_any_modulus.py -- the GF(2) wires of such a session are integers)
-    # a caller-driven backend owns wires the library cannot see
+    # (between GF(2) and another field: tests/test_any_modulus.py -- the GF(2) wires of such a session are integers;
+    # through the trait-level entry points: test_field_change_through_the_trait_level_entry_points below)
+    # a finalized session records nothing more, whatever the modulus
     ev = zk.Evaluator()
     ev.backend_set_field(bytes([101]))
-    ev.backend_witness(0)
-    with pytest.raises(zk.ZkGpuError, match='caller-driven backend cannot'):
+    ev.backend_assert_zero(ev.backend_witness(0), 0)
+    ev.finalize()
+    with pytest.raises(zk.ZkGpuError, match='already finalized'):
         ev.backend_set_field(bytes([97]))
     # the gate set alone may change from message to message (it only selects the Evaluator's own arms)
     msgs = [sw.write_relation(bytes([101]), 'arithmetic', 'simple', [], [('witness', 0)]),
@@ -383,3 +385,169 @@ def test_a_streamed_ingest_gives_up_streaming_at_the_field_change_and_nothing_el
             ff, flagged = _simulate(ev, [P1, P2], [e], [w])
             assert not flagged and expected_product_violations(ev, ff) == ref.violations and (ref.violations == []) == good
     assert dumps['0'] == dumps['16']
+
+
+# ---- the same through the trait-level entry points (zkgpu_backend_*): what a Rust `impl ZKBackend` binds.  The reference's
+# Evaluator calls set_field for every Relation message (evaluator.rs:262-268); a new modulus opens a field segment, and the
+# wires that live on are the caller's handles that have not been dropped (zkgpu_backend_drop = `impl Drop` of its Wire).
+def _trait_session(second_modulus, shrink):
+    ev = zk.Evaluator()
+    ev.backend_set_field(sw.int_to_le(P1))
+    w0 = ev.backend_witness(0)
+    w1 = ev.backend_witness(1)
+    prod = ev.backend_multiply(w0, w1)
+    ev.backend_drop(w1)                                   # ('free', 1, 1)
+    ev.backend_set_field(sw.int_to_le(second_modulus))    # the header of the second Relation message
+    p2 = second_modulus
+    e = ev.backend_instance(0)
+    ne = ev.backend_mul_constant(e, sw.int_to_le(p2 - 1))
+    d = ev.backend_add(prod, ne)
+    c = ev.backend_copy(d)                                # (AssertZero copies its wire, evaluator.rs:340)
+    ev.backend_assert_zero(c, 5)
+    ev.backend_drop(c)
+    if shrink:
+        c6 = ev.backend_copy(w0)
+        c6b = ev.backend_copy(c6)
+        ev.backend_assert_zero(c6b, 6)
+        for h in (c6b, c6):
+            ev.backend_drop(h)
+    else:
+        sq = ev.backend_multiply(w0, w0)
+        e1 = ev.backend_instance(1)
+        ne1 = ev.backend_mul_constant(e1, sw.int_to_le(p2 - 1))
+        d1 = ev.backend_add(sq, ne1)
+        c1 = ev.backend_copy(d1)
+        ev.backend_assert_zero(c1, 9)
+        for h in (c1, d1, ne1, e1, sq):
+            ev.backend_drop(h)
+    for h in (d, ne, e, prod, w0):
+        ev.backend_drop(h)
+    return ev
+
+
+@pytest.mark.parametrize('shrink', [False, True])
+def test_field_change_through_the_trait_level_entry_points(shrink):
+    parts, p2 = (SHRINK, P3) if shrink else (GROW, P2)
+    msgs = _messages(parts)
+    ev = _trait_session(p2, shrink)
+    ev.finalize()
+    assert ev.n_field_segments == 2
+    assert ev.field_segment_info(0)['carried_out'] == 1 and ev.field_segment_info(1)['carried_in'] == 1
+    assert ev.assert_wires().tolist() == ([5, 6] if shrink else [5, 9])
+    lanes = [([e0], [w0, w1]) for w0, w1, e0 in ((0, 5, 0), (97, 1, 0), (97, 1, 97), (100, 1, 3), (100, 1, 100), (98, 99, (98 * 99) % 101))] \
+        if shrink else _lanes_grow()
+    for inst, wit in lanes:
+        ref = oracle_lane(sw.int_to_le(P1), inst, wit, msgs, 32, trace=False)
+        ff, flagged = _simulate(ev, [P1, p2], inst, wit)
+        want = [] if ff is None else ['Wire_%d (may be weighted) should be 0, while it is not' % ev.assert_wires()[ff]]
+        assert not flagged and want == ref.violations, (inst, wit, ff)
+
+
+def test_a_caller_driven_field_change_needs_the_drops_and_keeps_old_handles_valid():
+    ev = zk.Evaluator()
+    ev.backend_set_field(sw.int_to_le(P1))
+    a = ev.backend_witness(0)
+    b = ev.backend_add_constant(a, bytes([7]))
+    ev.backend_drop(a)
+    ev.backend_set_field(sw.int_to_le(P2))
+    # a was dropped before the change: it has no value in the new segment; b lives on under its old handle
+    with pytest.raises(zk.ZkGpuError, match='dropped before the field characteristic changed'):
+        ev.backend_copy(a)
+    c = ev.backend_multiply(b, b)
+    assert c > b                                           # handles are session-wide: never reused across the change
+    ev.backend_assert_zero(ev.backend_copy(c), 1)
+    ev.finalize()
+    assert ev.n_field_segments == 2 and ev.tape_len == 2 + 3   # witness, add_constant | multiply, copy, assert_zero
+    ff, _ = _simulate(ev, [P1, P2], [], [P1 - 7])          # (94 + 7) mod 101 = 0, squared: 0
+    assert ff is None
+    ff, _ = _simulate(ev, [P1, P2], [], [1])
+    assert ff == 0
+
+
+# ---- a wide field, then a narrow one: the carried values and the inputs are wider than the second field's limbs ----
+BN = circuits.BN254_R
+WIDE_THEN_NARROW = [(BN, 'arithmetic', [('witness', 0), ('witness', 1), ('mul', 2, 0, 1), ('free', 1, 1)]),
+                    (P2, 'arithmetic', [('mul', 3, 2, 0), ('instance', 4), ('mulc', 5, 4, sw.int_to_le(P2 - 1)), ('add', 6, 3, 5),
+                                        ('assert_zero', 6), ('free', 0, 0), ('free', 2, 6)])]
+
+
+def _lanes_wide_then_narrow():
+    rows = []
+    for w0, w1, ok in ((3, 4, True), (BN - 1, BN - 2, True), (2 ** 200 + 12345, 2 ** 253 + 7, False), (2 ** 64, 2 ** 61 - 1, True), (0, 5, True)):
+        prod = (w0 * w1) % BN                      # an integer below BN254's r: far wider than 2^61
+        e = (prod * w0) % P2 + (0 if ok else 1)    # the narrow field multiplies the carried product by the witness read again
+        rows.append(([e % P2 if ok else e], [w0, w1]))
+    return rows
+
+
+def test_a_narrower_field_reduces_the_wide_values_it_takes_over():
+    """BN254 then 2^61 - 1: the carried product (8 words) and the witness read again (8 words in the session's buffers) are
+    wider than the second field's two words.  The reference's gates are `(a * b) % m` of whatever integers come in
+    (evaluator.rs:908-922): the values are reduced, no lane is flagged (round-3 advisor finding)."""
+    msgs = _messages(WIDE_THEN_NARROW)
+    ev = _session(msgs, 1, 2)
+    assert ev.n_field_segments == 2 and ev.elem_bytes == 32
+    ev.set_option('inspect_segment', '1')
+    assert ev.input_modes(2) == [0x00] and ev.input_modes(True)[0] == 0x00
+    ev.set_option('inspect_segment', '')
+    for inst, wit in _lanes_wide_then_narrow():
+        ref = oracle_lane(sw.int_to_le(BN), inst, wit, msgs, 32, trace=False)
+        ff, flagged = _simulate(ev, [BN, P2], inst, wit)
+        assert not flagged and expected_product_violations(ev, ff) == ref.violations, (inst, wit)
+    assert [oracle_lane(sw.int_to_le(BN), i, w, msgs, 32, trace=False).violations == [] for i, w in _lanes_wide_then_narrow()] == [True, True, False, True, True]
+
+
+@pytest.mark.gpu
+def test_wide_then_narrow_fields_on_the_gpu():
+    msgs = _messages(WIDE_THEN_NARROW)
+    rows = _lanes_wide_then_narrow()
+    for retain in (False, True):
+        ev = _session(msgs, 1, 2, retain)
+        inst, wit = batch_arrays([r[0] for r in rows], [r[1] for r in rows], ev.elem_bytes)
+        ev.set_inputs(inst, wit, len(rows))
+        ev.replay()
+        ev.synchronize()
+        for lane, (i, w) in enumerate(rows):
+            ref = oracle_lane(sw.int_to_le(BN), i, w, msgs, 32, trace=False)
+            assert ev.get_violations(lane) == ref.violations, lane
+        assert ev.counts() == (4, 1) and not ev.lane_results(len(rows))[1].any()
+    # the any-modulus kernels take the same values: an even second modulus
+    p_even = 2 ** 61 - 2
+    parts = [WIDE_THEN_NARROW[0], (p_even, 'arithmetic', [('mul', 3, 2, 0), ('instance', 4), ('mulc', 5, 4, sw.int_to_le(p_even - 1)), ('add', 6, 3, 5),
+                                                          ('assert_zero', 6), ('free', 0, 0), ('free', 2, 6)])]
+    msgs2 = _messages(parts)
+    rows2 = [([((w0 * w1) % BN * w0) % p_even], [w0, w1]) for _, (w0, w1) in rows]
+    ev = _session(msgs2, 1, 2)
+    assert ev.field_representation(1) == 2
+    inst, wit = batch_arrays([r[0] for r in rows2], [r[1] for r in rows2], ev.elem_bytes)
+    ev.set_inputs(inst, wit, len(rows2))
+    ev.replay()
+    ev.synchronize()
+    for lane, (i, w) in enumerate(rows2):
+        ref = oracle_lane(sw.int_to_le(BN), i, w, msgs2, 32, trace=False)
+        assert ev.get_violations(lane) == ref.violations == [], lane
+    assert ev.counts() == (len(rows2), 0)
+
+
+@pytest.mark.gpu
+def test_a_message_value_wider_than_the_buffers_is_reduced_under_the_field_that_reads_it():
+    """`evaluate <workspace>` use: GF(101) then GF(2^61 - 1), the witness 2^70 + 3 of the Witness message is wider than the
+    session's 8-byte values.  It is multiplied in the FIRST segment: its residue mod 101 goes in, not mod 2^61 - 1 (round-3
+    advisor finding); the verdict is the oracle's."""
+    big = 2 ** 70 + 3
+    for ok in (True, False):
+        e = ((big * 7) % P1) ** 2 % P2 + (0 if ok else 1)
+        stmt = [sw.write_instance(sw.int_to_le(P1), [sw.int_to_le(e)]),
+                sw.write_witness(sw.int_to_le(P1), [sw.int_to_le(big), sw.int_to_le(7)])] + \
+            _messages([(P1, 'arithmetic', [('witness', 0), ('witness', 1), ('mul', 2, 0, 1), ('free', 0, 1)]),
+                       (P2, 'arithmetic', [('mul', 3, 2, 2), ('instance', 4), ('mulc', 5, 4, sw.int_to_le(P2 - 1)), ('add', 6, 3, 5),
+                                           ('assert_zero', 6), ('free', 2, 6)])])
+        ev = zk.Evaluator.from_messages(stmt)
+        ev.finalize()
+        assert ev.n_field_segments == 2 and ev.elem_bytes == 8
+        ev.set_inputs_from_messages()
+        ev.replay()
+        ev.synchronize()
+        from oracle_lib import OracleRun
+        ref = OracleRun(buffers=stmt, trace=False)
+        assert ev.get_violations(0) == ref.violations and (ref.violations == []) == ok

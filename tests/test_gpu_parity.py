@@ -801,6 +801,32 @@ def test_trait_level_recording_replays_on_gpu():
     assert ev.counts() == (3, 2)
 
 
+@pytest.mark.parametrize('shrink', [False, True])
+def test_trait_level_recording_with_a_field_change_replays_on_gpu(shrink):
+    """zkgpu_backend_set_field with another modulus (what the reference's Evaluator does for every Relation message,
+    evaluator.rs:262-268) opens a field segment; the handles that were not dropped live on.  Every lane's violations
+    against the oracle's run of the equivalent two-message relation."""
+    import test_field_segments as fs
+    from zkinterface_ir_amd import sieve_writer as sw
+    parts, p2 = (fs.SHRINK, fs.P3) if shrink else (fs.GROW, fs.P2)
+    msgs = fs._messages(parts)
+    ev = fs._trait_session(p2, shrink)
+    ev.finalize()
+    assert ev.n_field_segments == 2
+    rows = [([e0], [w0, w1]) for w0, w1, e0 in ((0, 5, 0), (97, 1, 0), (97, 1, 97), (100, 1, 3), (100, 1, 100), (98, 99, (98 * 99) % 101))] \
+        if shrink else fs._lanes_grow()
+    inst, wit = batch_arrays([r[0] for r in rows], [r[1] for r in rows], ev.elem_bytes)
+    ev.set_inputs(inst, wit, len(rows))
+    ev.replay()
+    ev.synchronize()
+    n_ok = 0
+    for lane, (i, w) in enumerate(rows):
+        ref = oracle_lane(sw.int_to_le(fs.P1), i, w, msgs, 32, trace=False)
+        assert ev.get_violations(lane) == ref.violations, (lane, i, w)
+        n_ok += ref.violations == []
+    assert ev.counts() == (n_ok, len(rows) - n_ok)
+
+
 @pytest.mark.parametrize('name', ['with_function', 'with_several_functions', 'switch_builder', 'switch_nested_in_function'])
 def test_builder_circuits_replay_true(name):
     """rust/src/producers/builder.rs:727-1175: the four GateBuilder circuits evaluate with zero violations."""

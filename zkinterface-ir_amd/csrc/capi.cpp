@@ -11,6 +11,7 @@
 #include <mutex>
 #include <thread>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/zkgpu.h"
@@ -66,6 +67,7 @@ struct FieldSegment {
   TapeBackend backend;
   Schedule sched;
   std::unique_ptr<Engine> engine;
+  std::vector<std::unique_ptr<Engine>> peers;   // option "devices": this segment's engines on the other devices (like zkgpu_session::peers)
   std::vector<uint32_t> carried_out;   // its handles whose values the next segment reads, in carry order
   std::vector<uint32_t> value_op_index;
 };
@@ -90,6 +92,12 @@ struct zkgpu_session {
   bool finalized = false;
   bool engine_loaded = false;   // the engine holds the finished program (a streamed ingest opens the engine earlier)
   bool used_evaluator = false;  // messages went through the bundled Evaluator (zkgpu_ingest_* / declare_inputs)
+  // Caller-driven backend (zkgpu_backend_*): the handles the caller holds are SESSION-wide numbers.  In the first field
+  // segment they are tape indices; a field change (zkgpu_backend_set_field with another modulus) moves the handle space up
+  // by the entries recorded so far -- handle = handle_base + tape index of the current segment -- and the wires that were
+  // alive at the change (every handle not reported dropped) are re-bound: old handle -> tape index in `rebound`.
+  uint32_t handle_base = 0;
+  std::unordered_map<uint32_t, uint32_t> rebound;
   bool retain_all = false;
   uint32_t declared_inst = 0, declared_wit = 0;
   uint32_t lane_group = 0;
@@ -341,8 +349,10 @@ std::vector<Engine*> all_engines(zkgpu_session* s) {
 // every engine an option setter has to reach: those and the engines of the field segments before the current one
 std::vector<Engine*> configurable_engines(zkgpu_session* s) {
   std::vector<Engine*> v = all_engines(s);
-  for (auto& seg : s->prev)
+  for (auto& seg : s->prev) {
     if (seg->engine) v.push_back(seg->engine.get());
+    for (auto& p : seg->peers) v.push_back(p.get());
+  }
   return v;
 }
 
@@ -389,7 +399,10 @@ void need_engine(zkgpu_session* s) {
     s->engine.reset();
     s->peers.clear();
     s->reducer.reset();
-    for (auto& seg : s->prev) seg->engine.reset();
+    for (auto& seg : s->prev) {
+      seg->engine.reset();
+      seg->peers.clear();
+    }
     const uint32_t n_inst = lane_inputs(s, true), n_wit = lane_inputs(s, false);
     auto setup = [&](Engine* x) {
       configure_engine(s, x);
@@ -398,26 +411,35 @@ void need_engine(zkgpu_session* s) {
       if (s->r1cs_extra_vars) x->reserve_extra_slots(s->r1cs_extra_vars);
     };
     if (!s->prev.empty()) {
-      // several field segments: one engine per field on ONE device, chained on the stream of the first; the caller's
-      // input buffers have the width of the widest field
-      if (s->devices.size() > 1) throw std::runtime_error("a session of several field segments runs on one device");
-      e.reset(new Engine(dev0));   // (never an engine of an earlier chain: it would still run on that chain's stream)
+      // several field segments: per device one engine per field, chained on the stream of the first; the caller's input
+      // buffers have the width of the widest field.  With option "devices" every device gets a chain of its own for its
+      // share of the lanes (the programs are replicated, as for a single field).
       const uint32_t stride = session_elem_bytes(s);
       const size_t n = n_segments(s);
-      std::vector<Engine*> chain;
-      for (size_t k = 0; k < n; ++k) {
-        std::unique_ptr<Engine> x = (k == n - 1) ? std::move(e) : std::unique_ptr<Engine>(new Engine(dev0));
-        configure_engine(s, x.get());
-        x->set_writeback(k == n - 1 && s->n_pinned != 0);
-        x->set_input_stride(stride);
-        const Tape& t = seg_backend(s, k).tape();
-        x->load_program(seg_sched(s, k), seg_backend(s, k).field(), n_inst, n_wit, t.n_carry, k ? seg_backend(s, k - 1).field().nwords : 0);
-        chain.push_back(x.get());
-        if (k < n - 1) s->prev[k]->engine = std::move(x);
-        else s->engine = std::move(x);
+      const size_t n_dev = std::max<size_t>(1, s->devices.size());
+      for (auto& seg : s->prev) seg->peers.clear();
+      for (size_t d = 0; d < n_dev; ++d) {
+        const int dev = s->devices.empty() ? dev0 : s->devices[d];
+        std::vector<Engine*> chain;
+        for (size_t k = 0; k < n; ++k) {
+          std::unique_ptr<Engine> x(new Engine(dev));   // (never an engine of an earlier chain: it would still run on that chain's stream)
+          configure_engine(s, x.get());
+          x->set_writeback(k == n - 1 && s->n_pinned != 0);
+          x->set_input_stride(stride);
+          const Tape& t = seg_backend(s, k).tape();
+          x->load_program(seg_sched(s, k), seg_backend(s, k).field(), n_inst, n_wit, t.n_carry, k ? seg_backend(s, k - 1).field().nwords : 0);
+          chain.push_back(x.get());
+          if (k < n - 1) {
+            if (d == 0) s->prev[k]->engine = std::move(x);
+            else s->prev[k]->peers.push_back(std::move(x));
+          } else {
+            if (d == 0) s->engine = std::move(x);
+            else s->peers.push_back(std::move(x));
+          }
+        }
+        for (size_t k = 0; k < n; ++k) chain[k]->chain_to(chain[0], k == 0, k == n - 1);
       }
-      for (size_t k = 0; k < n; ++k) chain[k]->chain_to(chain[0], k == 0, k == n - 1);
-      s->lane_first.assign(2, 0);
+      s->lane_first.assign(s->peers.size() + 2, 0);
       s->engine_loaded = true;
       return;
     }
@@ -432,12 +454,17 @@ void need_engine(zkgpu_session* s) {
   }
 }
 
-// (several field segments) engine k of the chain
-std::vector<Engine*> chain_engines(zkgpu_session* s) {
+// (several field segments) the chain of device `d` of the session (0: the first listed / the current device)
+std::vector<Engine*> chain_engines(zkgpu_session* s, size_t d = 0) {
   std::vector<Engine*> v;
-  for (auto& seg : s->prev) v.push_back(seg->engine.get());
-  v.push_back(s->engine.get());
+  for (auto& seg : s->prev) v.push_back(d == 0 ? seg->engine.get() : seg->peers.at(d - 1).get());
+  v.push_back(d == 0 ? s->engine.get() : s->peers.at(d - 1).get());
   return v;
+}
+// engine of segment g on device d
+Engine* seg_engine_on(zkgpu_session* s, size_t g, size_t d) {
+  if (g < s->prev.size()) return d == 0 ? s->prev[g]->engine.get() : s->prev[g]->peers.at(d - 1).get();
+  return d == 0 ? s->engine.get() : s->peers.at(d - 1).get();
 }
 
 void single_segment_only(const zkgpu_session* s, const char* what) {
@@ -504,15 +531,15 @@ void stream_cut(void* arg);
 // The Relation message about to be ingested names another field characteristic than the backend works in: close the
 // current field segment and open the next (FieldSegment above).  Runs between two messages, so the top-level scope is
 // the only one that exists.
-void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
+// `live`: the tape handles (of the current backend) of the wires that live on, in the caller's order; returns the handles
+// they have in the new backend, in the same order.
+std::vector<uint32_t> switch_field_core(zkgpu_session* s, const Value& modulus, uint32_t degree, bool is_boolean, const std::vector<uint32_t>& live) {
   FieldHost next;
-  next.init(header.field_characteristic);
-  if (header.field_degree != 1) return;   // (set_field reports it, with the reference's text)
+  next.init(modulus);
   // Between GF(2) and another field the reference carries the wires over as the integers they are (evaluator.rs:232-237);
   // bit-packed wires cannot be: such a session keeps its GF(2) segments as integers too (the any-modulus kernels) --
   // the one that has been recorded (its tape does not depend on the representation) as well as a new one.
   const bool from_gf2 = s->backend.field().is_two, to_gf2 = next.is_two;
-  if (s->devices.size() > 1) throw std::runtime_error("GPU backend: a field change between Relation messages is not available with several devices (option \"devices\")");
   if (s->r1cs_ready) throw std::runtime_error("GPU backend: a field change between Relation messages is not available for R1CS sessions");
   if (s->stream) {   // a streamed schedule of the old segment: dropped, the segment is scheduled at finalize like the others
     stream_wait(s);
@@ -531,30 +558,31 @@ void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
   // old tape: behind copies alone it is still the instance / witness value or the constant it started as -- possibly
   // >= the old characteristic, since PlaintextBackend never reduces those (evaluator.rs:862-864,896-898,940-946) -- and
   // the new segment reads that input or constant itself, under its own field; anything a gate has produced is a
-  // canonical value of the old field and travels through the carry stream.  Detach the wires from the old backend (no
-  // drop record: the old segment keeps them readable) ...
+  // canonical value of the old field and travels through the carry stream.
   std::unique_ptr<FieldSegment> seg(new FieldSegment());
   struct Origin {
     uint8_t kind;      // TK_INSTANCE / TK_WITNESS: position `at`; TK_CONST: constant `at` of the old tape; TK_CARRY: carried
     uint32_t at;
   };
-  std::vector<WireId> ids;
   std::vector<Origin> origin;
   {
     const Tape& old = s->backend.tape();
-    s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
-      uint32_t h = w.h;
+    std::unordered_map<uint32_t, uint32_t> carried_index;   // (two live handles of one value share a carry position)
+    for (uint32_t h0 : live) {
+      if (h0 >= old.size() || old.kind[h0] == TK_ASSERT) throw std::runtime_error("GPU backend: a wire that lives on across the field change is not a value of the session");
+      uint32_t h = h0;
       while (old.kind[h] == TK_COPY) h = old.a[h];
-      ids.push_back(id);
       if (old.kind[h] == TK_INSTANCE || old.kind[h] == TK_WITNESS || old.kind[h] == TK_CONST) {
         origin.push_back(Origin{old.kind[h], old.a[h]});
       } else {
-        origin.push_back(Origin{TK_CARRY, (uint32_t)seg->carried_out.size()});
-        seg->carried_out.push_back(w.h);
+        auto it = carried_index.find(h0);
+        if (it == carried_index.end()) {
+          it = carried_index.emplace(h0, (uint32_t)seg->carried_out.size()).first;
+          seg->carried_out.push_back(h0);
+        }
+        origin.push_back(Origin{TK_CARRY, it->second});
       }
-      w.h = kNoWire;
-      w.owner = nullptr;
-    });
+    }
   }
   const uint32_t assert_base = s->backend.assert_base() + (uint32_t)s->backend.tape().assert_op.size();
   TapeBackend fresh;
@@ -563,24 +591,95 @@ void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
   s->backend = std::move(fresh);
   if (to_gf2) s->backend.use_generic_field();
   s->backend.set_assert_base(assert_base);
-  s->backend.set_field(header.field_characteristic, header.field_degree, is_boolean);
+  s->backend.set_field(modulus, degree, is_boolean);
   // ... and re-bind them, in the same order
-  size_t k = 0;
-  s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
-    if (k >= ids.size() || ids[k] != id) throw std::runtime_error("GPU backend: the scope changed while a field segment was opened");
-    const Origin& o = origin[k];
+  std::vector<uint32_t> out;
+  out.reserve(live.size());
+  std::unordered_map<uint32_t, uint32_t> carry_handle;
+  for (const Origin& o : origin) {
     uint32_t h;
-    if (o.kind == TK_CARRY) h = s->backend.h_carry(o.at);
-    else if (o.kind == TK_CONST) h = s->backend.h_constant(TapeBackend::literal_bytes(seg->backend.tape().consts[o.at]));
-    else h = s->backend.h_input_at(o.kind, o.at);
-    w = TapeWire(h, &s->backend);
-    ++k;
-  });
+    if (o.kind == TK_CARRY) {
+      auto it = carry_handle.find(o.at);
+      if (it == carry_handle.end()) it = carry_handle.emplace(o.at, s->backend.h_carry(o.at)).first;
+      h = it->second;
+    } else if (o.kind == TK_CONST) {
+      h = s->backend.h_constant(TapeBackend::literal_bytes(seg->backend.tape().consts[o.at]));
+    } else {
+      h = s->backend.h_input_at(o.kind, o.at);
+    }
+    out.push_back(h);
+  }
   s->backend.end_rebinding();
   s->value_op_index.clear();
   s->prev.push_back(std::move(seg));
+  return out;
 }
 
+void switch_field(zkgpu_session* s, const Header& header, bool is_boolean) {
+  if (header.field_degree != 1) return;   // (set_field reports it, with the reference's text)
+  // detach the wires of the (top-level, the only one between messages) scope from the old backend -- no drop record: the
+  // old segment keeps them readable -- and bind them to what they are in the new one
+  std::vector<WireId> ids;
+  std::vector<uint32_t> live;
+  s->ev.values().for_each([&](WireId id, const TapeWire& w) {
+    ids.push_back(id);
+    live.push_back(w.h);
+  });
+  const std::vector<uint32_t> fresh = switch_field_core(s, header.field_characteristic, header.field_degree, is_boolean, live);
+  size_t k = 0;
+  s->ev.values_mut().for_each_mut([&](WireId id, TapeWire& w) {
+    if (k >= ids.size() || ids[k] != id) throw std::runtime_error("GPU backend: the scope changed while a field segment was opened");
+    w.h = kNoWire;      // (no drop record in the old backend)
+    w.owner = nullptr;
+    w = TapeWire(fresh[k], &s->backend);
+    ++k;
+  });
+}
+
+// ---- caller-driven backend: session-wide handles ------------------------------------------------------------------
+uint32_t local_handle(const zkgpu_session* s, uint32_t h) {
+  if (h >= s->handle_base) return h - s->handle_base;
+  auto it = s->rebound.find(h);
+  if (it == s->rebound.end())
+    throw std::runtime_error("GPU backend: wire " + std::to_string(h) + " was dropped before the field characteristic changed (or never existed)");
+  return it->second;
+}
+uint32_t global_handle(const zkgpu_session* s, uint32_t local) { return s->handle_base + local; }
+
+// zkgpu_backend_set_field with another modulus than the backend works in (evaluator.rs:262-268: the reference's Evaluator
+// calls set_field for every Relation message, with whatever modulus the header holds): a new field segment.  The wires
+// that live on are the caller's handles that have not been dropped (zkgpu_backend_drop = `impl Drop` of its Wire type).
+void switch_field_caller_driven(zkgpu_session* s, const Value& modulus, uint32_t degree, bool is_boolean) {
+  if (degree != 1) {
+    s->backend.set_field(modulus, degree, is_boolean);   // (reports it, with the reference's text)
+    return;
+  }
+  const Tape& t = s->backend.tape();
+  std::vector<uint8_t> dropped(t.size(), 0);
+  for (uint32_t h : t.drop_handle)
+    if (h < t.size()) dropped[h] = 1;
+  // session-wide handle of every live wire, and its tape index: the values of this segment ...
+  std::vector<uint32_t> globals, live;
+  for (const auto& kv : s->rebound)
+    if (!dropped[kv.second]) {
+      globals.push_back(kv.first);
+      live.push_back(kv.second);
+    }
+  for (uint32_t i = t.n_rebound; i < t.size(); ++i)
+    if (t.kind[i] != TK_ASSERT && !dropped[i]) {
+      globals.push_back(s->handle_base + i);
+      live.push_back(i);
+    }
+  if (live.size() > (1u << 20))
+    throw std::runtime_error("GPU backend: " + std::to_string(live.size()) + " wires are alive at the field change: a caller-driven backend must "
+                             "report the wires it lets go of (zkgpu_backend_drop, `impl Drop` of its Wire type) for its field to change");
+  const uint32_t next_base = s->handle_base + (uint32_t)t.size();
+  const std::vector<uint32_t> fresh = switch_field_core(s, modulus, degree, is_boolean, live);
+  s->rebound.clear();
+  for (size_t k = 0; k < globals.size(); ++k) s->rebound[globals[k]] = fresh[k];
+  // the new segment's own handles start behind every handle issued so far; its tape starts with the re-bound entries
+  s->handle_base = next_base;
+}
 void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
   const bool side_consumers = s->validator || s->stats;
   for (const auto& m : split_messages(data, len)) {
@@ -611,12 +710,22 @@ void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
       if (msg.kind == Message::IsRelation && s->backend.field_set() && !s->ev.has_error()) {
         // a new modulus opens a new field segment (evaluator.rs:232-237, :262-268); what FieldHost cannot take
         // (an even modulus, more than 512 bits, zero) is left to set_field, which reports it with the reference's text
-        bool differs = false;
-        try {
-          FieldHost f;
-          f.init(msg.relation.header.field_characteristic);
-          differs = memcmp(f.p, s->backend.field().p, sizeof f.p) != 0;
-        } catch (const std::exception&) {
+        // (the significant little-endian bytes of the header's characteristic against the one in use: no field constants
+        // are derived just to compare; what FieldHost cannot take -- zero, one, more than 4096 bits -- is reported by
+        // set_field, with the reference's text, from inside the new segment)
+        const Value& hv = msg.relation.header.field_characteristic;
+        const Value& cv = s->backend.modulus();
+        size_t hn = hv.size(), cn = cv.size();
+        while (hn > 0 && hv[hn - 1] == 0) --hn;
+        while (cn > 0 && cv[cn - 1] == 0) --cn;
+        bool differs = hn != cn || memcmp(hv.data(), cv.data(), hn) != 0;
+        if (differs) {
+          try {
+            FieldHost f;
+            f.init(hv);
+          } catch (const std::exception&) {
+            differs = false;   // left to set_field
+          }
         }
         if (differs) switch_field(s, msg.relation.header, mask::contains_feature(msg.relation.gate_mask, mask::BOOL));
       }
@@ -800,12 +909,23 @@ void r1cs_check_assignable(zkgpu_session* s, uint32_t first_row, uint32_t n_rows
 
 void r1cs_to_device(zkgpu_session* s) {
   need_engine(s);
-  single_device_only(s, "the R1CS row kernel");
   if (!s->r1cs_ready) throw std::runtime_error("no R1CS: call zkgpu_r1cs_from_tape or zkgpu_r1cs_load_csr");
   if (!s->r1cs_on_device) {
-    s->engine->r1cs_upload(s->r1cs_rows_dev, s->r1cs_terms_dev, s->r1cs_coef_words);
+    // (option "devices": the rows are replicated like the program; every engine checks the rows for its share of the lanes)
+    for (Engine* e : all_engines(s)) e->r1cs_upload(s->r1cs_rows_dev, s->r1cs_terms_dev, s->r1cs_coef_words);
     s->r1cs_on_device = true;
   }
+}
+
+// the engines that hold lanes of the batch (a single engine: that one)
+template <class F>
+void per_active_engine(zkgpu_session* s, F&& f) {
+  std::vector<Engine*> eng = all_engines(s);
+  if (s->peers.empty()) {
+    f(eng[0]);
+    return;
+  }
+  per_engine(active_engines(s), [&](size_t k) { f(eng[k]); });
 }
 
 }  // namespace
@@ -819,61 +939,85 @@ const char* zkgpu_version(void) { return "zkgpu 0.1 (gfx950)"; }
 
 // ---- ZKBackend trait -------------------------------------------------------
 int zkgpu_backend_set_field(zkgpu_session* s, const uint8_t* modulus_le, size_t len, uint32_t degree, int is_boolean) {
-  return guarded(s, [&] { s->backend.set_field(Value(modulus_le, modulus_le + len), degree, is_boolean != 0); });
+  return guarded(s, [&] {
+    const Value modulus(modulus_le, modulus_le + len);
+    if (s->backend.field_set() && !s->used_evaluator) {
+      // another characteristic than the one in use: the recording continues in a new field segment
+      size_t n = modulus.size(), m = s->backend.modulus().size();
+      while (n > 0 && modulus[n - 1] == 0) --n;
+      while (m > 0 && s->backend.modulus()[m - 1] == 0) --m;
+      if (n != m || memcmp(modulus.data(), s->backend.modulus().data(), n) != 0) {
+        if (s->finalized) throw std::runtime_error("session already finalized");
+        switch_field_caller_driven(s, modulus, degree, is_boolean != 0);
+        return;
+      }
+    }
+    s->backend.set_field(modulus, degree, is_boolean != 0);
+  });
 }
 int zkgpu_backend_copy(zkgpu_session* s, uint32_t wire, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_copy(wire); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_copy(local_handle(s, wire))); });
 }
 int zkgpu_backend_constant(zkgpu_session* s, const uint8_t* v, size_t len, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_constant(TapeBackend::from_bytes_le(Value(v, v + len))); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_constant(TapeBackend::from_bytes_le(Value(v, v + len)))); });
 }
 int zkgpu_backend_assert_zero(zkgpu_session* s, uint32_t wire, uint64_t local_wire_id) {
   return guarded(s, [&] {
+    const uint32_t w = local_handle(s, wire);
     s->backend.note_assert_wire(local_wire_id);
-    s->backend.h_assert_zero(wire);
+    s->backend.h_assert_zero(w);
   });
 }
 int zkgpu_backend_add(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_add(a, b); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_add(local_handle(s, a), local_handle(s, b))); });
 }
 int zkgpu_backend_multiply(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_multiply(a, b); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_multiply(local_handle(s, a), local_handle(s, b))); });
 }
 int zkgpu_backend_add_constant(zkgpu_session* s, uint32_t a, const uint8_t* c, size_t len, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_add_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_add_constant(local_handle(s, a), TapeBackend::from_bytes_le(Value(c, c + len)))); });
 }
 int zkgpu_backend_mul_constant(zkgpu_session* s, uint32_t a, const uint8_t* c, size_t len, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_mul_constant(a, TapeBackend::from_bytes_le(Value(c, c + len))); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_mul_constant(local_handle(s, a), TapeBackend::from_bytes_le(Value(c, c + len)))); });
 }
 int zkgpu_backend_and(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_and(a, b); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_and(local_handle(s, a), local_handle(s, b))); });
 }
 int zkgpu_backend_xor(zkgpu_session* s, uint32_t a, uint32_t b, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_xor(a, b); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_xor(local_handle(s, a), local_handle(s, b))); });
 }
 int zkgpu_backend_not(zkgpu_session* s, uint32_t a, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_not(a); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_not(local_handle(s, a))); });
 }
 int zkgpu_backend_ladder(zkgpu_session* s, uint64_t first_call, uint32_t base, uint32_t result) {
   return guarded(s, [&] {
-    if (first_call > s->backend.tape().size() || result >= s->backend.tape().size())
+    // first_call is a value of zkgpu_tape_len() (the calls of every field segment so far): the current segment's entries
+    // start at the calls of the segments before it, behind its own re-bound entries
+    const Tape& t = s->backend.tape();
+    const uint64_t before = zkgpu_tape_len(s) - (t.size() - t.n_rebound);
+    if (first_call < before || first_call - before + t.n_rebound > t.size())
       throw std::runtime_error("zkgpu_backend_ladder: not a range of recorded calls");
-    s->backend.h_ladder((size_t)first_call, base, result);
+    const uint32_t r = local_handle(s, result), b = local_handle(s, base);
+    if (r >= t.size()) throw std::runtime_error("zkgpu_backend_ladder: not a range of recorded calls");
+    s->backend.h_ladder((size_t)(first_call - before + t.n_rebound), b, r);
   });
 }
 int zkgpu_backend_drop(zkgpu_session* s, uint32_t wire) {
   return guarded(s, [&] {
-    if (wire >= s->backend.tape().size()) throw std::runtime_error("zkgpu_backend_drop: not a wire of this session");
-    s->backend.drop_wire(wire);
+    if (wire < s->handle_base && !s->rebound.count(wire)) return;   // (a wire of an earlier field segment that did not live on: nothing to tell)
+    const uint32_t w = local_handle(s, wire);
+    if (w >= s->backend.tape().size()) throw std::runtime_error("zkgpu_backend_drop: not a wire of this session");
+    s->backend.drop_wire(w);
+    if (wire < s->handle_base) s->rebound.erase(wire);
   });
 }
 int zkgpu_backend_instance(zkgpu_session* s, uint32_t position, uint32_t* out) {
-  return guarded(s, [&] { *out = s->backend.h_instance(TapeBackend::instance_ref(position)); });
+  return guarded(s, [&] { *out = global_handle(s, s->backend.h_instance(TapeBackend::instance_ref(position))); });
 }
 int zkgpu_backend_witness(zkgpu_session* s, uint32_t position, uint32_t* out) {
   return guarded(s, [&] {
     TapeElement e = TapeBackend::witness_ref(position);
-    *out = s->backend.h_witness(&e);
+    *out = global_handle(s, s->backend.h_witness(&e));
   });
 }
 
@@ -923,7 +1067,7 @@ uint64_t zkgpu_tape_len(const zkgpu_session* s) {
   if (!s) return 0;
   if (s->inspect_segment >= 0) return seg_backend(s, inspected(s)).tape().size();
   uint64_t n = 0;
-  for (size_t k = 0; k < n_segments(s); ++k) n += seg_backend(s, k).tape().size() - seg_backend(s, k).tape().n_carry;
+  for (size_t k = 0; k < n_segments(s); ++k) n += seg_backend(s, k).tape().size() - seg_backend(s, k).tape().n_rebound;   // (re-bound wires are no calls)
   return n;
 }
 uint64_t zkgpu_tape_value_ops(const zkgpu_session* s) {
@@ -1174,15 +1318,18 @@ int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* 
   return guarded(s, [&] {
     need_engine(s);
     if (!s->prev.empty()) {
-      // field segments: the first engine of the chain takes the buffers, the others read the same device copies
-      std::vector<Engine*> chain = chain_engines(s);
-      for (Engine* e : chain) e->synchronize();   // (no hand-over overlap here: every segment reads the inputs)
-      s->lane_first.assign(2, 0);
-      s->lane_first[1] = batch;
-      s->batch = batch;
-      for (Engine* e : chain) e->set_batch(batch);
-      chain[0]->upload_inputs(instances, witnesses);
-      for (size_t k = 1; k < chain.size(); ++k) chain[k]->use_device_inputs(chain[0]->device_instances(), chain[0]->device_witnesses());
+      // field segments: per device the first engine of the chain takes its share of the buffers, the others read the same
+      // device copies (no hand-over overlap here: every segment reads the inputs)
+      split_lanes(s, batch);
+      const uint32_t w = session_elem_bytes(s);
+      const size_t irow = (size_t)lane_inputs(s, true) * w, wrow = (size_t)lane_inputs(s, false) * w;
+      per_engine(active_engines(s), [&](size_t d) {
+        std::vector<Engine*> chain = chain_engines(s, d);
+        for (Engine* e : chain) e->synchronize();
+        for (Engine* e : chain) e->set_batch(s->lane_first[d + 1] - s->lane_first[d]);
+        chain[0]->upload_inputs(instances ? instances + irow * s->lane_first[d] : nullptr, witnesses ? witnesses + wrow * s->lane_first[d] : nullptr);
+        for (size_t k = 1; k < chain.size(); ++k) chain[k]->use_device_inputs(chain[0]->device_instances(), chain[0]->device_witnesses());
+      });
       s->results_fresh = false;
       return;
     }
@@ -1224,15 +1371,37 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
     const auto& lw = s->backend.lane0_witnesses();
     if (ni > li.size() || nw > lw.size())
       throw std::runtime_error("the tape consumes more instance/witness values than the ingested messages hold");
-    const FieldHost& f = s->backend.field();
+    // A value too wide for the buffer goes in as its residue -- under the field of the segment that CONSUMES the position
+    // (a session whose modulus changes holds one tape per field, and an input may be read again by a later segment that the
+    // wire lived on into: capi.cpp switch_field).  Segments with different moduli reading one such position would each need
+    // their own residue: refused.
+    auto field_of_position = [&](bool witness, uint32_t position) -> const FieldHost& {
+      const FieldHost* found = nullptr;
+      for (size_t g = 0; g < n_segments(s); ++g) {
+        const Tape& t = seg_backend(s, g).tape();
+        const uint8_t want = witness ? TK_WITNESS : TK_INSTANCE;
+        bool reads = false;
+        for (size_t i = 0; i < t.size() && !reads; ++i) reads = t.kind[i] == want && t.a[i] == position;
+        if (!reads) continue;
+        const FieldHost& f = seg_backend(s, g).field();
+        if (found && memcmp(found->p, f.p, sizeof f.p) != 0)
+          throw std::runtime_error(std::string("GPU backend: ") + (witness ? "witness" : "instance") + " value " + std::to_string(position) +
+                                   " is wider than zkgpu_elem_bytes and is read under two field characteristics: hand the batch "
+                                   "over with zkgpu_set_inputs in values of a width that holds it");
+        found = &f;
+      }
+      return found ? *found : s->backend.field();
+    };
     // a value too wide for the buffer is >= p.  Where only the residue matters (mode 0) the residue goes in; at a strict
     // position (0xFF) all-ones does, which the device flags like any other non-canonical strict input; at a position only
     // zero tests read (0x01) all-ones too -- it is >= p and non-zero, which is all those look at.  A position read both by
     // zero tests and by arithmetic (0x02) would need the residue AND the fact that the integer is not zero: refused.
-    auto fill = [&](const std::vector<Value>& vals, std::vector<uint8_t>& buf, const std::vector<uint8_t>& modes) {
+    auto fill = [&](const std::vector<Value>& vals, std::vector<uint8_t>& buf, const std::vector<uint8_t>& modes, bool witness) {
       for (size_t k = 0; k < vals.size(); ++k) {
         bool big = false;
-        put_value(vals[k], &buf[k * w], w, f, &big);
+        size_t sig = vals[k].size();
+        while (sig > 0 && vals[k][sig - 1] == 0) --sig;
+        put_value(vals[k], &buf[k * w], w, sig > w ? field_of_position(witness, (uint32_t)k) : s->backend.field(), &big);
         const uint8_t mode = k < modes.size() ? modes[k] : 0;
         if (big && (mode == 0xFF || mode == 0x01)) memset(&buf[k * w], 0xff, w);
         if (big && mode == 0x03)
@@ -1248,14 +1417,12 @@ int zkgpu_set_inputs_from_messages(zkgpu_session* s) {
     std::vector<uint8_t> mi(ni, 0), mw(nw, 0);
     if (ni) zkgpu_input_modes(s, 0, mi.data(), mi.size());
     if (nw) zkgpu_input_modes(s, 1, mw.data(), mw.size());
-    fill(li, inst, mi);
-    fill(lw, wit, mw);
+    fill(li, inst, mi, false);
+    fill(lw, wit, mw, true);
     if (!s->prev.empty()) {
       std::vector<Engine*> chain = chain_engines(s);
       for (Engine* e : chain) e->synchronize();
-      s->lane_first.assign(2, 0);
-      s->lane_first[1] = 1;
-      s->batch = 1;
+      split_lanes(s, 1);   // (one lane: the first device's chain)
       for (Engine* e : chain) e->set_batch(1);
       chain[0]->upload_inputs(inst.data(), wit.data());
       for (size_t k = 1; k < chain.size(); ++k) chain[k]->use_device_inputs(chain[0]->device_instances(), chain[0]->device_witnesses());
@@ -1419,17 +1586,19 @@ int zkgpu_replay(zkgpu_session* s) {
     need_engine(s);
     s->results_fresh = false;
     if (!s->prev.empty()) {
-      // field segment after field segment on one stream; between two, the wires that live on travel as canonical integers
-      std::vector<Engine*> chain = chain_engines(s);
-      for (size_t k = 0; k < chain.size(); ++k) {
-        chain[k]->replay(false);
-        if (k + 1 < chain.size()) {
-          const FieldSegment& seg = *s->prev[k];
-          std::vector<uint32_t> slots(seg.carried_out.size());
-          for (size_t q = 0; q < slots.size(); ++q) slots[q] = seg.sched.slot_of[seg.carried_out[q]];
-          chain[k]->carry_out(slots, chain[k + 1]);
+      // field segment after field segment on one stream per device; between two, the wires that live on travel as canonical integers
+      per_engine(active_engines(s), [&](size_t d) {
+        std::vector<Engine*> chain = chain_engines(s, d);
+        for (size_t k = 0; k < chain.size(); ++k) {
+          chain[k]->replay(false);
+          if (k + 1 < chain.size()) {
+            const FieldSegment& seg = *s->prev[k];
+            std::vector<uint32_t> slots(seg.carried_out.size());
+            for (size_t q = 0; q < slots.size(); ++q) slots[q] = seg.sched.slot_of[seg.carried_out[q]];
+            chain[k]->carry_out(slots, chain[k + 1]);
+          }
         }
-      }
+      });
     } else if (s->peers.empty()) {
       s->engine->replay(false);
     } else {
@@ -1452,10 +1621,15 @@ int zkgpu_synchronize(zkgpu_session* s) {
   return guarded(s, [&] {
     need_engine(s);
     std::vector<Engine*> eng = all_engines(s);
-    for (auto& seg : s->prev) seg->engine->synchronize();
-    if (s->peers.empty()) s->engine->synchronize();
-    else
-      for (size_t k : active_engines(s)) eng[k]->synchronize();
+    if (s->peers.empty()) {
+      for (auto& seg : s->prev) seg->engine->synchronize();
+      s->engine->synchronize();
+    } else {
+      for (size_t k : active_engines(s)) {
+        for (size_t g = 0; g < s->prev.size(); ++g) seg_engine_on(s, g, k)->synchronize();
+        eng[k]->synchronize();
+      }
+    }
   });
 }
 float zkgpu_last_replay_ms(const zkgpu_session* s) {   // several devices: the slowest share
@@ -1557,7 +1731,15 @@ int zkgpu_dump_trace_values(zkgpu_session* s, uint64_t first, uint64_t count, ui
         std::vector<uint32_t> slots(hi - lo);
         for (uint64_t k = lo; k < hi; ++k) slots[k - lo] = seg_sched(s, g).slot_of[idx[k - base]];
         std::vector<uint8_t> tmp;
-        seg_engine(s, g)->dump_slots(slots, &tmp);
+        if (s->peers.empty()) {
+          seg_engine(s, g)->dump_slots(slots, &tmp);
+        } else {   // shares are contiguous and in lane order
+          for (size_t d : active_engines(s)) {
+            std::vector<uint8_t> part;
+            seg_engine_on(s, g, d)->dump_slots(slots, &part);
+            tmp.insert(tmp.end(), part.begin(), part.end());
+          }
+        }
         const uint32_t ws = seg_engine(s, g)->elem_bytes();
         for (uint32_t lane = 0; lane < batch; ++lane)
           for (uint64_t k = lo; k < hi; ++k)
@@ -1718,16 +1900,18 @@ int zkgpu_r1cs_assign(zkgpu_session* s, uint32_t first_row, uint32_t n_rows) {
   return guarded(s, [&] {
     r1cs_check_assignable(s, first_row, n_rows);
     r1cs_to_device(s);
-    s->engine->r1cs_run(true, first_row, n_rows);
+    per_active_engine(s, [&](Engine* e) { e->r1cs_run(true, first_row, n_rows); });
   });
 }
 
 int zkgpu_r1cs_check(zkgpu_session* s) {
   return guarded(s, [&] {
     r1cs_to_device(s);
-    s->engine->r1cs_begin_check();
-    s->engine->r1cs_run(false, 0, (uint32_t)s->r1cs_rows_dev.size());
-    s->engine->r1cs_finish_check();
+    per_active_engine(s, [&](Engine* e) {
+      e->r1cs_begin_check();
+      e->r1cs_run(false, 0, (uint32_t)s->r1cs_rows_dev.size());
+      e->r1cs_finish_check();
+    });
   });
 }
 
@@ -1735,7 +1919,22 @@ int zkgpu_r1cs_results(zkgpu_session* s, uint32_t* first_fail_row, uint64_t coun
   return guarded(s, [&] {
     need_engine(s);
     std::vector<uint32_t> ff;
-    s->engine->r1cs_results(first_fail_row ? &ff : nullptr, counts);
+    if (s->peers.empty()) {
+      s->engine->r1cs_results(first_fail_row ? &ff : nullptr, counts);
+    } else {   // shares are contiguous and in lane order; the counts are summed on the host (exact either way)
+      std::vector<Engine*> eng = all_engines(s);
+      if (counts) counts[0] = counts[1] = 0;
+      for (size_t k : active_engines(s)) {
+        std::vector<uint32_t> part;
+        uint64_t c[2] = {0, 0};
+        eng[k]->r1cs_results(first_fail_row ? &part : nullptr, c);
+        ff.insert(ff.end(), part.begin(), part.end());
+        if (counts) {
+          counts[0] += c[0];
+          counts[1] += c[1];
+        }
+      }
+    }
     if (first_fail_row && !ff.empty()) memcpy(first_fail_row, ff.data(), ff.size() * 4);
   });
 }
@@ -1754,7 +1953,7 @@ int zkgpu_r1cs_get_vars(zkgpu_session* s, const uint64_t* vars, uint32_t n_vars,
       else throw std::runtime_error("variable out of range");
     }
     std::vector<uint8_t> tmp;
-    s->engine->dump_slots(slots, &tmp);
+    dump_slots_all(s, slots, &tmp);
     if (!tmp.empty()) memcpy(out, tmp.data(), tmp.size());
   });
 }
@@ -1804,7 +2003,12 @@ int zkgpu_r1cs_correction_values(zkgpu_session* s, const uint64_t* tape_ops, uin
   });
 }
 
-float zkgpu_r1cs_last_ms(const zkgpu_session* s) { return (s && s->engine) ? s->engine->last_r1cs_ms() : 0.f; }
+float zkgpu_r1cs_last_ms(const zkgpu_session* s) {   // several devices: the slowest share
+  if (!s || !s->engine) return 0.f;
+  float ms = s->engine->last_r1cs_ms();
+  for (const auto& p : s->peers) ms = std::max(ms, p->last_r1cs_ms());
+  return ms;
+}
 
 uint64_t zkgpu_table_bytes(const zkgpu_session* s) {
   if (!s || !s->engine) return 0;

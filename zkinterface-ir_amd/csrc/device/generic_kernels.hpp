@@ -280,10 +280,33 @@ __global__ __launch_bounds__(256) void replay_generic_kernel(const ReplayArgs ar
         const u32 stream = op.kind == OP_INSTANCE ? 0u : op.kind == OP_WITNESS ? 1u : 2u;
         const bool too_wide = g_stream_load(stream, op.a, args, lane_g, lane_valid, n, a);
         const uint8_t* modes = stream == 0 ? aux->strict_inst : stream == 1 ? aux->strict_wit : aux->strict_carry;
-        // (replay_kernels.hpp input_op: a value the limbs cannot hold, or one >= p where the residue will not do)
-        if (lane_valid && (too_wide || (modes[op.a] == 0xFF && g_geq_p(a, n, gp))))
+        const u32 mode = modes[op.a];
+        // (replay_kernels.hpp input_op: flagged only where the value's bits matter and the limbs cannot hold them, or where it
+        // is >= p and the residue will not do; anywhere else a value of any width is reduced, as the reference's arithmetic does)
+        if (lane_valid && ((too_wide && (mode == 0xFF || mode == 0x03)) || (mode == 0xFF && g_geq_p(a, n, gp))))
           atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
-        g_reduce<CAP>(a, r, gp);
+        if (!(too_wide && lane_valid)) {
+          g_reduce<CAP>(a, r, gp);
+        } else {
+          // Horner over the groups of n words: W = 2^(32 n) mod p = (2^(32 n) - 1) mod p + 1
+          const u32* base = stream == 2 ? aux->carry : reinterpret_cast<const u32*>(stream ? args.wit : args.inst);
+          const u32 n_vals = stream == 2 ? aux->n_carry : (stream ? args.n_wit : args.n_inst);
+          const u32 stride = stream == 2 ? aux->carry_words : aux->in_stride_words;
+          const u32* q = base + ((size_t)lane_g * n_vals + op.a) * stride;
+          u32 W[CAP], t[CAP], one[CAP];
+          for (u32 w = 0; w < n; ++w) { t[w] = 0xFFFFFFFFu; one[w] = w == 0 ? 1u : 0u; }
+          g_reduce<CAP>(t, W, gp);
+          g_reduce<CAP>(one, t, gp);   // (1 mod p: 0 for p = 1 is refused on the host; p = 2 gives 1)
+          g_add<CAP>(W, t, W, gp);
+          const u32 groups = (stride + n - 1) / n;
+          for (u32 w = 0; w < n; ++w) r[w] = 0;
+          for (u32 c = groups; c-- > 0;) {
+            for (u32 w = 0; w < n; ++w) t[w] = c * n + w < stride ? q[c * n + w] : 0u;
+            g_reduce<CAP>(t, b, gp);
+            g_mul<CAP>(r, W, a, gp);
+            g_add<CAP>(a, b, r, gp);
+          }
+        }
         break;
       }
       case OP_ASSERT: {

@@ -200,8 +200,30 @@ __device__ __forceinline__ bool unreduced_source_is_nonzero(u32 code, const Args
   return lane_valid && (too_wide || fp_geq_p<N>(raw, fp));
 }
 
-// An input op of either replay kernel: load, flag the lane where the value cannot be represented (wider than the limbs)
-// or is >= p at a strict position, and return the Montgomery form of its residue.
+// Words [c N, (c + 1) N) of an input value of `stride_words` words, zero-extended: a value wider than the field's limbs
+// (a session whose fields differ in width hands its inputs over in the width of the widest, and a wire carried over from
+// a wider field is as wide as that field) is reduced limb group by limb group (input_op).
+template <int N>
+__device__ __forceinline__ Fp<N> input_chunk(const void* __restrict__ base, u32 lane_g, u32 n_vals, u32 idx, bool valid, u32 stride_words, u32 c) {
+  Fp<N> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.w[i] = 0;
+  if (valid) {
+    const u32* p = reinterpret_cast<const u32*>(base) + ((size_t)lane_g * n_vals + idx) * stride_words;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (c * N + i < stride_words) r.w[i] = p[c * N + i];
+  }
+  return r;
+}
+
+// An input op of either replay kernel: load, flag the lane where the residue will not do, and return the Montgomery form
+// of the value's residue.  The reference keeps inputs unreduced (evaluator.rs:862-864,940-946) and arithmetic reduces
+// them, `(a + b) % m`, however large they are: at a position that only arithmetic reads (mode 0x00, or 0x01 / 0x02 whose
+// zero tests look at the raw input themselves) a value wider than the N words is REDUCED -- Horner over its groups of N
+// words, R = 2^(32 N): x R mod p = ((..(top R + next) R + ..) R + low) R, i.e. to_mont(group) added to the running value
+// times R (a Montgomery product by R^2) -- and only where its bits matter (0xFF: it reaches an integer bit operation or
+// Evaluator::get as it is; 0x03: and / xor read the raw input, which their N-word operand cannot hold) is the lane flagged.
 template <int N, class Args>
 __device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& args, u32 lane_g, bool lane_valid, const FieldParams& fp) {
   const u32 stream = kind == OP_INSTANCE ? 0u : kind == OP_WITNESS ? 1u : 2u;
@@ -209,11 +231,22 @@ __device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& ar
   const Fp<N> raw = stream_load<N>(stream, position, args, lane_g, lane_valid, too_wide);
   InputAuxS* aux = (InputAuxS*)(unsigned long long)args.aux;
   const uint8_t* modes = stream == 0 ? aux->strict_inst : stream == 1 ? aux->strict_wit : aux->strict_carry;
-  // The reference keeps inputs unreduced (evaluator.rs:862-864,940-946).  At a strict position the value can reach an
-  // integer bit operation or Evaluator::get as it is, where the residue would not do: flag the lane.
-  if (lane_valid && (too_wide || (position_is_strict(modes, position) && fp_geq_p<N>(raw, fp))))
+  const u32 mode = modes[position];
+  if (lane_valid && ((too_wide && (mode == 0xFF || mode == 0x03)) || (mode == 0xFF && fp_geq_p<N>(raw, fp))))
     atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
-  return fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
+  if (__ballot(too_wide && lane_valid) == 0ull) return fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
+  // some lane holds a value of more than N words (rare: one pass over the groups for the whole wave)
+  const void* base = stream == 2 ? (const void*)aux->carry : (const void*)(stream ? args.wit : args.inst);
+  const u32 n_vals = stream == 2 ? aux->n_carry : (stream ? args.n_wit : args.n_inst);
+  const u32 stride = stream == 2 ? aux->carry_words : aux->in_stride_words;
+  const u32 groups = (stride + N - 1) / N;
+  Fp<N> r2;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r2.w[i] = fp.r2[i];
+  Fp<N> acc = fp_to_mont<N>(input_chunk<N>(base, lane_g, n_vals, position, lane_valid, stride, groups - 1), fp);
+  for (u32 c = groups - 1; c-- > 0;)
+    acc = fp_add<N>(fp_mul<N>(acc, r2, fp), fp_to_mont<N>(input_chunk<N>(base, lane_g, n_vals, position, lane_valid, stride, c), fp), fp);
+  return acc;
 }
 
 // An operand of an integer bit operation (`and` / `xor` over an odd field, evaluator.rs:924-933): the canonical integer of
