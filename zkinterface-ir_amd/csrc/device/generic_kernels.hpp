@@ -293,16 +293,17 @@ __global__ __launch_bounds__(256) void replay_generic_kernel(const ReplayArgs ar
           const u32 n_vals = stream == 2 ? aux->n_carry : (stream ? args.n_wit : args.n_inst);
           const u32 stride = stream == 2 ? aux->carry_words : aux->in_stride_words;
           const u32* q = base + ((size_t)lane_g * n_vals + op.a) * stride;
-          u32 W[CAP], t[CAP], one[CAP];
-          for (u32 w = 0; w < n; ++w) { t[w] = 0xFFFFFFFFu; one[w] = w == 0 ? 1u : 0u; }
-          g_reduce<CAP>(t, W, gp);
-          g_reduce<CAP>(one, t, gp);   // (1 mod p: 0 for p = 1 is refused on the host; p = 2 gives 1)
-          g_add<CAP>(W, t, W, gp);
+          u32 W[CAP];   // (one more private array: the groups go through a / b)
+          for (u32 w = 0; w < n; ++w) a[w] = 0xFFFFFFFFu;
+          g_reduce<CAP>(a, W, gp);
+          for (u32 w = 0; w < n; ++w) a[w] = w == 0 ? 1u : 0u;
+          g_reduce<CAP>(a, b, gp);   // (1 mod p)
+          g_add<CAP>(W, b, W, gp);
           const u32 groups = (stride + n - 1) / n;
           for (u32 w = 0; w < n; ++w) r[w] = 0;
           for (u32 c = groups; c-- > 0;) {
-            for (u32 w = 0; w < n; ++w) t[w] = c * n + w < stride ? q[c * n + w] : 0u;
-            g_reduce<CAP>(t, b, gp);
+            for (u32 w = 0; w < n; ++w) a[w] = c * n + w < stride ? q[c * n + w] : 0u;
+            g_reduce<CAP>(a, b, gp);
             g_mul<CAP>(r, W, a, gp);
             g_add<CAP>(a, b, r, gp);
           }
