@@ -142,7 +142,7 @@ def first_verdict_seconds(zk, wl, msgs, inst, wit, batch, stream, pinned, bool_p
 def build_session(zk, name, wl, batch, lane_offset, lane_group, bool_path=None, streams=2):
     """probe pass for the expected outputs, then the real session with resident inputs"""
     t0 = time.time()
-    if hasattr(wl, 'N'):   # StructuredArith: the expected values are a closed form, no probe pass
+    if getattr(wl, 'closed_form', False):   # StructuredArith, Sha256Compress: the expected values come with the inputs, no probe pass
         inst, wit, n_bad = wl.inputs(batch, lane_offset)
         return finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_bad, t0, time.time(), 0)
     inst, wit = wl.inputs(batch, lane_offset)
@@ -180,6 +180,9 @@ def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_b
     ev = zk.Evaluator()
     if bool_path:
         ev.set_option('bool_path', bool_path)
+        # GF(2) relations are ingested as a stream: the windows end at the seams between dependency levels, and the program
+        # of a relation recorded level by level is the finalize-time program byte for byte (tests/test_full_size.py)
+        ev.set_option('stream', '1')
     ev.set_option('streams', str(streams))
     # developer switches for A/B runs (profiles/*_tuning_sweeps.txt); the metric is quoted on the defaults
     for env, opt in (('ZKI_STREAM', 'stream'), ('ZKI_FUSE', 'fuse'), ('ZKI_OPW', 'level_ops_per_wave'), ('ZKI_HOT_WAVES', 'hot_waves'),
@@ -544,6 +547,10 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
         wl = workloads.StructuredArith(N=width or 1408, chained=args.chained)
         batch = bpg or 1024
         bytes_table, bool_path = BYTES_PER_OP, None
+    elif name == 'sha256':
+        wl = workloads.Sha256Compress()
+        batch = bpg or 4096
+        bytes_table, bool_path = BYTES_PER_OP_BOOL, args.bool_path
     else:
         wl = workloads.BoolLayered(W=width or 16384, D=depth or 640,
                                    wiring=os.environ.get('ZKI_C4_WIRING', 'random'))
@@ -566,7 +573,7 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
         # became): the backend calls the rewrite removed -- scope copies, ladder products -- move no bytes at all
         pk = ev.schedule_dump()[0][:, 1] & 0xFF
         algo_bytes_per_lane = float(sum({**BYTES_PER_OP, 13: 64}.get(int(k), 0) * int(c) for k, c in zip(*np.unique(pk, return_counts=True))))
-    lds = name == 'c4' and ev.uses_lds_path()
+    lds = name in ('c4', 'sha256') and ev.uses_lds_path()
     wide_launches = 1 if lds else info['launches'] - info['sequential_launches']
 
     counts_t = torch.as_tensor(_DevU64x2(ev.counts_device_ptr()), device='cuda') if dist_on else None
@@ -670,6 +677,12 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
                        'BN254 (shape of producers/examples.rs:72-212), witness batch=%d per GPU, %d GPU(s)'
                        % (' (chained: each iteration reads the previous result)' if wl.chained else '', wl.N, batch, world))
             kernel = 'replay_fused_kernel<8, 0> + <8, 1>' if fused else 'replay_kernel<8, false, false>'
+        elif name == 'sha256':
+            metric = 'gate-ops/sec (whole node), GF(2), SHA-256 compression function (1.2 * 10^5 And/Xor gates in 3,900 levels), batched witnesses'
+            dtype = 'u1 (GF(2), %d witnesses per word)' % (32 if lds else 64)
+            wl_name = ('SHA-256 compression of one padded block as a Boolean relation (%d gates, %d levels), witness batch=%d per GPU, '
+                       '%d GPU(s); expected digests from hashlib' % (gates, info['levels'], batch, world))
+            kernel = 'bool_lds_kernel (narrow levels: packets walked by one wave)' if lds else 'bool_replay_kernel'
         else:
             metric = 'gate-ops/sec (whole node), GF(2), 10M-gate And/Xor/Not relation, bit-packed batched witnesses'
             dtype = 'u1 (GF(2), %d witnesses per word)' % (32 if lds else 64)
@@ -705,7 +718,7 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
                        'ranks_seen': ranks_seen, 'rank_base': rank_base,
                        'pcie_inclusive_ms_per_step': None if pcie_ms is None else round(pcie_ms, 3),
                        'satisfied': total[0], 'failed': total[1],
-                       'expected_outputs': ('closed form in Python integers' if structured else
+                       'expected_outputs': ('closed form in Python integers' if structured else 'hashlib.sha256 of every lane\'s message' if name == 'sha256' else
                                             'GPU probe pass on another schedule and kernel; %d of %d lanes checked against '
                                             'tests/golden/%s_all_lanes.json (oracle chain)' % (host['lanes_checked_against_golden_hashes'], batch, name)),
                        'host_seconds': {k: round(v, 3) for k, v in host.items() if k.endswith('_s')},
@@ -825,7 +838,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', choices=['c2', 'c4', 'c5', 'structured'], default='c2',
+    ap.add_argument('--workload', choices=['c2', 'c4', 'c5', 'structured', 'sha256'], default='c2',
                     help='c2 = BASELINE configs[1] (headline); c4 = GF(2) 10M-gate relation, batch 4096; c5 = R1CS rows; '
                          'structured = For / Call / Switch relation of ~1M backend calls (--width = loop iterations)')
     ap.add_argument('--batch-per-gpu', type=int, default=0)
@@ -900,6 +913,8 @@ def main():
         args.chained = True
         sec['structured_chained'] = bench_tape('structured', args, zk, workloads, ctx, 10, 2, False, cpu_budget_s=2.0)
         args.chained = False
+        # a real Boolean circuit: thousands of narrow levels
+        sec['sha256'] = bench_tape('sha256', args, zk, workloads, ctx, 10, 2, False, cpu_budget_s=2.0)
         out['secondary'] = sec
         out['secondary_wall_s'] = round(time.time() - t0, 1)
     if rank == 0:

@@ -225,6 +225,49 @@ def test_lds_kernel_block_shapes_against_the_cpu_checker(block_rows, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('path', ['lds', 'hbm'])
+def test_sha256_compression_against_hashlib_and_the_oracle(path):
+    """workloads.Sha256Compress: the SHA-256 compression function as a GF(2) relation (121,072 gates, 3,920 levels of a few
+    dozen gates: the narrow-level path of the LDS-resident kernel).  Every lane hashes its own message; the claimed digests
+    are hashlib's, one bit flipped on every 7th lane: counts, every lane's first failing assert, the violation text and --
+    for three lanes -- the oracle's run of the same messages."""
+    wl = workloads.Sha256Compress()
+    batch = 300
+    inst, wit, bad = wl.inputs(batch, corrupt_every=7)
+    msgs = wl.relation_messages()
+    ev = zk.Evaluator()
+    ev.set_option('bool_path', path)
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in msgs:
+        ev.ingest_message(m)
+    ev.finalize()
+    ev.set_inputs(inst.tobytes(), wit.tobytes(), batch)
+    assert ev.uses_lds_path() == (path == 'lds')
+    ev.replay()
+    ev.synchronize()
+    assert ev.counts() == (batch - bad, bad)
+    first, flags = ev.lane_results(batch)
+    want = np.where(np.arange(batch) % 7 == 0, np.arange(batch) % 256, zk.NO_FAIL).astype(np.uint32)   # assert k checks digest bit k
+    assert np.array_equal(first, want) and not flags.any()
+    for lane in (0, 1, 7):
+        ref = oracle_lane(wl.mod_le, [int(x) for x in inst[lane, :, 0]], [int(x) for x in wit[lane, :, 0]], msgs, 1, trace=False)
+        assert ev.get_violations(lane) == ref.violations, lane
+    # the digest wires themselves (a session without the epilogue): hashlib's bits
+    probe = zk.Evaluator()
+    probe.set_option('bool_path', path)
+    probe.declare_inputs(0, wl.n_witness)
+    for m in wl.relation_messages(with_epilogue=False, free_last=False):
+        probe.ingest_message(m)
+    probe.finalize()
+    probe.set_inputs(None, wit[:40].tobytes(), 40)
+    probe.replay()
+    probe.synchronize()
+    got = np.stack([np.asarray(probe.get(w, 40), dtype=np.uint8) for w in wl.output_wire_ids()], axis=1)
+    clean, _, _ = wl.inputs(40, corrupt_every=0)
+    assert np.array_equal(got, clean[:, :, 0])
+
+
+@pytest.mark.gpu
 def test_lds_kernel_fuzz_of_shapes_mixes_and_block_sizes():
     """tools/fuzz_bool_lds.py, bounded: 20 random shapes of the LDS-resident GF(2) kernel -- widths from 96 to 19,000 gates
     per level, every gate mix (all and, no and, nothing but not), ragged batches, block sizes forced and free, every third

@@ -97,6 +97,25 @@ def interpret(prog, consts, inst_bits, wit_bits):
                     T[real + 33] = 0xFFFFFFFF              # (padding ops only ever write the 32 scratch slots)
                 if desc & 16:
                     end_of_level()
+        elif flags & (1 << 9) and flags & (1 << 15):
+            # a run of narrow levels walked by ONE wave: `nrows` packets of 64 entries, lane l executing entry l of a packet
+            # (all its reads before its writes: the 64 lanes run in lockstep), packet after packet with no barrier
+            assert flags & (1 << 8)
+            end_of_level()
+            for pk in range(nrows):
+                packet = ops8[first_w + 64 * pk: first_w + 64 * (pk + 1)]
+                reads, writes = set(), []
+                for dst, a, b, kind in ((int(x) for x in e) for e in packet):
+                    if kind in (K_XOR, K_AND, K_NOT, K_COPY, K_ASSERT):
+                        reads.add(a)
+                        if kind in (K_XOR, K_AND):
+                            reads.add(b)
+                    if kind in (K_XOR, K_AND, K_NOT, K_COPY, K_CONST, K_INSTANCE, K_WITNESS):
+                        writes.append(dst)
+                assert len(set(writes)) == len(writes), 'two entries of a packet write one slot'
+                assert not (reads & set(writes)), 'a packet reads a slot it writes: its entries are not independent'
+                for e in packet:
+                    exec_entry(e)
         elif flags & (1 << 9):
             assert flags & (1 << 8)
             end_of_level()                                 # (the chunk before ended its level)
@@ -279,3 +298,38 @@ def test_wide_levels_of_every_schedule_variant_keep_their_pairs():
         ev.finalize(retain_all=retain)
         _, _, consts, _ = ev.schedule_dump()
         assert interpret(ev.lds_program(), consts, inst[:, :, 0], wit[:, :, 0]).tolist() == want, (retain, bank)
+
+
+def test_narrow_levels_run_as_packets_walked_by_one_wave():
+    """Real Boolean circuits are thousands of levels of a few dozen gates (the SHA-256 compression: 1.2 * 10^5 gates in 3,900
+    levels): levels of fewer than 257 ops are not padded to 2048-op rows with a barrier each but form runs of 64-entry
+    packets that one wave walks (lds_layout.hpp kLdsChunkWave).  Four rounds of the compression function: the program's
+    verdicts are the oracle's, and the interpreter checks that the entries of a packet are independent."""
+    wl = workloads.Sha256Compress(rounds=4)
+    msgs = wl.relation_messages()
+    lanes = 5
+    rng = np.random.default_rng(3)
+    wit = rng.integers(0, 2, size=(lanes, 512, 1), dtype=np.uint8)
+    inst = np.zeros((lanes, 256, 1), dtype=np.uint8)
+    ev = zk.Evaluator()
+    ev.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in msgs:
+        ev.ingest_message(m)
+    ev.finalize()
+    P = ev.lds_program(0)
+    wave_chunks = [c for c in P['chunks'] if int(c[2]) & (1 << 15)]
+    assert wave_chunks and sum(int(c[1]) for c in wave_chunks) * 64 > wl.n_gates   # most gates sit in packets
+    first = interpret(P, ev.schedule_dump()[2], inst[:, :, 0], wit[:, :, 0])
+    # the claimed digest is all zeros: the first assert that fails is the first digest bit that is 1
+    for lane in range(lanes):
+        ref = oracle_lane(wl.mod_le, [0] * 256, [int(x) for x in wit[lane, :, 0]], msgs, 1, trace=False)
+        want = [] if first[lane] == NO_FAIL else ['Wire_%d (may be weighted) should be 0, while it is not' % ev.assert_wires()[int(first[lane])]]
+        assert want == ref.violations and ref.violations, lane
+    # the row path instead (every level its own padded row): same verdicts
+    ev2 = zk.Evaluator()
+    ev2.set_option('bool_narrow_width', '3')
+    ev2.declare_inputs(wl.n_instance, wl.n_witness)
+    for m in msgs:
+        ev2.ingest_message(m)
+    ev2.finalize()
+    assert np.array_equal(interpret(ev2.lds_program(0), ev2.schedule_dump()[2], inst[:, :, 0], wit[:, :, 0]), first)

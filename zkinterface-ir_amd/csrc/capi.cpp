@@ -116,6 +116,7 @@ struct zkgpu_session {
   uint32_t sched_threads = 0;
   bool bank_aware = true;
   bool strand_lds = true;
+  uint32_t bool_narrow_width = 0;   // 0 = the scheduler's default
   uint32_t strand_width = 0;   // 0 = the scheduler's default
   std::unique_ptr<StreamState> stream;
   double stream_busy_s = 0;
@@ -216,6 +217,7 @@ ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
   opt.threads = s->sched_threads;
   opt.bank_aware = s->bank_aware;
   opt.strand_lds = s->strand_lds;
+  if (s->bool_narrow_width) opt.bool_narrow_width = s->bool_narrow_width;
   if (s->strand_width) opt.strand_width = s->strand_width;
   return opt;
 }
@@ -1449,7 +1451,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     // the scheduler of a streamed ingest took its options when the first window was cut: a later change would be ignored
     // silently by the windows already scheduled -- refuse it instead
     if (s->stream && (k == "fuse" || k == "pair" || k == "fermat" || k == "propagate_copies" || k == "sort_by_operand" ||
-                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "schedule_threads"))
+                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "bool_narrow_width" || k == "schedule_threads"))
       throw std::runtime_error(k + ": the streamed schedule has started (option \"stream\"); set scheduling options before the first Relation message");
     if (k == "bool_path") {
       if (v == "auto") s->bool_path = 0;
@@ -1496,6 +1498,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->bank_aware = v != "0";
     } else if (k == "strand_lds") {
       s->strand_lds = v != "0";
+    } else if (k == "bool_narrow_width") {
+      s->bool_narrow_width = (uint32_t)std::max(3, std::min(2048, atoi(v.c_str())));
     } else if (k == "schedule_threads") {
       s->sched_threads = (uint32_t)std::max(0, atoi(v.c_str()));
     } else if (k == "hot_waves") {

@@ -557,7 +557,36 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
     ++c;
     if (!((flags >> 10) & 1)) {
       // generic chunk: inputs, constants, asserts, NOP padding, or a sequential (narrow-level) segment
-      if ((flags >> 9) & 1) {
+      if (flags & kLdsChunkWave) {
+        // a run of narrow levels: wave 0 walks its packets of 64 entries, lane l executing entry l (lds_layout.hpp).  The
+        // entries of four packets are fetched while the four before them run: the program stream is the only thing that
+        // comes from memory, and a wave's LDS accesses complete in order, so nothing else is waited for between levels.
+        if (tid < (u32)kLdsPacketOps) {
+          // (entries as the 8-byte words they are: {dst, a, b, kind} little-endian; 0 = a no-op)
+          const u64* __restrict__ w = reinterpret_cast<const u64*>(args.ops) + first + tid;
+          auto entry = [](u64 x) { return LdsOp{(unsigned short)x, (unsigned short)(x >> 16), (unsigned short)(x >> 32), (unsigned short)(x >> 48)}; };
+          u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // four packets in hand, four on their way (the compiler owns 64 registers here)
+          if (0 < rows) c0 = w[0 * kLdsPacketOps];
+          if (1 < rows) c1 = w[1 * kLdsPacketOps];
+          if (2 < rows) c2 = w[2 * kLdsPacketOps];
+          if (3 < rows) c3 = w[3 * kLdsPacketOps];
+          for (u32 p0 = 0; p0 < rows; p0 += 4) {
+            u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+            if (p0 + 4 < rows) n0 = w[(size_t)(p0 + 4) * kLdsPacketOps];
+            if (p0 + 5 < rows) n1 = w[(size_t)(p0 + 5) * kLdsPacketOps];
+            if (p0 + 6 < rows) n2 = w[(size_t)(p0 + 6) * kLdsPacketOps];
+            if (p0 + 7 < rows) n3 = w[(size_t)(p0 + 7) * kLdsPacketOps];
+            lds_exec(entry(c0), T, args, col, valid_mask);
+            lds_exec(entry(c1), T, args, col, valid_mask);
+            lds_exec(entry(c2), T, args, col, valid_mask);
+            lds_exec(entry(c3), T, args, col, valid_mask);
+            c0 = n0;
+            c1 = n1;
+            c2 = n2;
+            c3 = n3;
+          }
+        }
+      } else if ((flags >> 9) & 1) {
         if (tid == 0)
           for (u32 i = 0; i < rows; ++i) lds_exec(args.ops[first + i], T, args, col, valid_mask);
       } else if ((flags & 0xFF) == OP_INSTANCE || (flags & 0xFF) == OP_WITNESS) {

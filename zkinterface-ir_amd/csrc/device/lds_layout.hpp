@@ -32,5 +32,12 @@ constexpr int kLdsBlockAndShift = 5, kLdsBlockSplitShift = 9;   // 4 and 11 bits
 constexpr int kLdsChunkAndShift = 11;                            // 4 bits of the chunk's flags word
 constexpr uint32_t kLdsScratchSlots = 32, kLdsZeroSlot = 32, kLdsOnesSlot = 33, kLdsExtraSlots = 34;   // offsets past the real slots
 constexpr uint32_t kLdsChunkBarrier = 1u << 8, kLdsChunkSequential = 1u << 9, kLdsChunkBlocks = 1u << 10;
+// A sequential chunk with kLdsChunkWave: a run of NARROW levels (fewer than ScheduleOptions::bool_narrow_width ops each)
+// as `rows` PACKETS of kLdsPacketOps entries, every level padded to whole packets with no-ops.  Wave 0 of the workgroup walks
+// the packets in order, lane l executing entry l of a packet: the entries of a packet are independent (one level), and a
+// wave's LDS accesses complete in order, so a level's writes are seen by the next level's reads without any barrier -- one
+// workgroup barrier for the whole run instead of one per level and a padded 2048-op row each.
+constexpr uint32_t kLdsChunkWave = 1u << 15;
+constexpr int kLdsPacketOps = 64;
 
 }  // namespace zkgpu

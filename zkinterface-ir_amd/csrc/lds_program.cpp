@@ -114,9 +114,25 @@ LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& blo
   };
   for (const Launch& L : s.launches) {
     if (L.sequential) {
+      // a run of narrow levels: packets of 64 entries walked by one wave (lds_layout.hpp kLdsChunkWave), every level padded
+      // to whole packets; a run whose levels hold two entries at most stays a plain sequence walked by one thread
+      const uint32_t* lp = L.level_ptr + L.strand_levels < s.strand_level_ptr.size() ? &s.strand_level_ptr[L.level_ptr] : nullptr;
+      uint32_t widest = 0;
+      for (uint32_t q = 0; lp && q < L.strand_levels; ++q) widest = std::max(widest, lp[q + 1] - lp[q]);
+      if (!lp || widest <= 2) {
+        const uint32_t first = (uint32_t)lo.size();
+        for (uint32_t k = 0; k < L.count; ++k) lo.push_back(encode(s.ops[L.first + k]));
+        ln.insert(ln.end(), {first, L.count, zkgpu::kLdsChunkSequential | zkgpu::kLdsChunkBarrier, 0u});
+        continue;
+      }
+      const LdsOp pad{scratch, 0, 0, (unsigned short)TK_NOP};
       const uint32_t first = (uint32_t)lo.size();
-      for (uint32_t k = 0; k < L.count; ++k) lo.push_back(encode(s.ops[L.first + k]));
-      ln.insert(ln.end(), {first, L.count, zkgpu::kLdsChunkSequential | zkgpu::kLdsChunkBarrier, 0u});
+      for (uint32_t q = 0; q < L.strand_levels; ++q) {
+        for (uint32_t k = lp[q]; k < lp[q + 1]; ++k) lo.push_back(encode(s.ops[L.first + k]));
+        while ((lo.size() - first) % zkgpu::kLdsPacketOps) lo.push_back(pad);
+      }
+      ln.insert(ln.end(), {first, ((uint32_t)lo.size() - first) / zkgpu::kLdsPacketOps,
+                           zkgpu::kLdsChunkSequential | zkgpu::kLdsChunkWave | zkgpu::kLdsChunkBarrier, 0u});
       continue;
     }
     // The ops of a level arrive sorted by kind, the row kinds last: and, xor, not, copy (schedule.cpp order_by_level).

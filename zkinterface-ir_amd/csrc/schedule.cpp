@@ -1281,7 +1281,7 @@ void StreamScheduler::Impl::assign_slots() {
     // GF(2): a level wide enough for a launch of its own runs as rows of the LDS-resident kernel (lds_program.cpp), two
     // ops per thread in the order of its row SEQUENCE -- the and, xor, not and copy ops of the level, in that order
     // (order_by_level); a narrower one joins a sequential segment (emit_launches)
-    const bool rows_level = s.boolean_path && level_start[l + 1] - level_start[l] >= opt.narrow_width;
+    const bool rows_level = s.boolean_path && level_start[l + 1] - level_start[l] >= opt.bool_narrow_width;
     uint64_t rows0 = level_start[l + 1];   // first op of the row sequence
     for (uint64_t k = level_start[l]; k < level_start[l + 1] && rows0 == level_start[l + 1]; ++k)
       if (row_class(kind[order[k] - lo])) rows0 = k;
@@ -1522,7 +1522,7 @@ void StreamScheduler::Impl::emit_launches() {
     uint64_t k1;
     // a level too narrow to pay for a launch of its own goes into a sequential launch with its narrow neighbours: a
     // strand (workgroup per lane block, barrier between levels) in the fused format, one wave per lane block otherwise
-    const uint32_t narrow = s.fused ? std::max(opt.strand_width, opt.narrow_width) : opt.narrow_width;
+    const uint32_t narrow = s.fused ? std::max(opt.strand_width, opt.narrow_width) : s.boolean_path ? opt.bool_narrow_width : opt.narrow_width;
     if (width >= narrow) {
       L.count = (uint32_t)width;
       L.ops_per_wave = 1;

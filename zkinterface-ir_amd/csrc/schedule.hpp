@@ -56,6 +56,9 @@ struct Launch {
 struct ScheduleOptions {
   bool retain_all = false;          // every value keeps its own slot (wire dumps for parity tests)
   uint32_t narrow_width = 3;        // levels with fewer ops than this are fused into sequential launches
+  uint32_t bool_narrow_width = 257; // ... GF(2): levels with fewer ops than this (at most four packets of 64) do not run as padded
+                                    // 2048-op rows with a workgroup barrier each: consecutive ones form a run that ONE wave
+                                    // of the LDS-resident kernel walks packet by packet (lds_layout.hpp kLdsChunkWave)
   uint32_t strand_width = 17;       // ... with the fused entry format: into strands (one workgroup per lane block walks the
                                     // levels with a barrier between them, device/replay_kernels.hpp replay_strand_kernel)
   int sort_by_operand = 3;          // order of a level's ops: 0 tape order, 1 by first-operand slot, 2 that + shared-operand walk, 3 the walk alone

@@ -259,6 +259,119 @@ class BoolLayered:
         return [self.D * self.W + t for t in range(self.n_out)]
 
 
+class Sha256Compress:
+    """A real Boolean circuit instead of a layered PRNG one: the SHA-256 compression of ONE padded message block (FIPS 180-4)
+    over GF(2), gateset `boolean` -- 64 rounds and the 48-word message schedule out of 32-bit ripple-carry adders (3 xor +
+    2 and per bit), Ch, Maj and the sigma functions (rotations are wiring): about 1.2 * 10^5 And / Xor / Not gates in a few
+    thousand dependency levels of a few dozen gates each, the shape the narrow-level path of the GF(2) kernel is for.
+    Witness = the 512 bits of the block (word by word, least significant bit first inside a word), instance = the 256 digest
+    bits a statement claims; the epilogue compares them {Instance, Xor, AssertZero}.  The expected digests are hashlib's."""
+
+    K = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+         0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+         0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+         0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+         0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+         0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+    IV = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+
+    def __init__(self, rounds=64, seed=0x5A256):
+        assert 1 <= rounds <= 64
+        self.closed_form = True   # (bench.py: the expected values come with the inputs, no probe pass)
+        self.rounds, self.seed, self.p = rounds, seed, 2
+        self.mod_le = bytes([2])
+        self.width = 1
+        self.n_witness, self.n_instance, self.n_out = 512, 256, 256
+        g = []                                   # gates, in wire order: wire k is defined by gate k (inputs and constants included)
+        self._g = g
+
+        def new(t):
+            g.append(t)
+            return len(g) - 1
+        xor = lambda a, b: new(('xor', len(g), a, b))
+        and_ = lambda a, b: new(('and', len(g), a, b))
+        msg = [[new(('witness', len(g))) for _ in range(32)] for _ in range(16)]
+        zero = new(('constant', len(g), bytes([0])))
+        one = new(('constant', len(g), bytes([1])))
+        const = lambda v: [one if (v >> i) & 1 else zero for i in range(32)]
+        rotr = lambda x, r: [x[(i + r) % 32] for i in range(32)]
+        shr = lambda x, r: [x[i + r] if i + r < 32 else zero for i in range(32)]
+        xor3 = lambda x, y, z: [xor(xor(a, b), c) for a, b, c in zip(x, y, z)]
+
+        def add(x, y):                           # ripple carry, bit 0 first; the carry out of bit 31 is dropped (mod 2^32)
+            out, c = [], None
+            for i in range(32):
+                t = xor(x[i], y[i])
+                out.append(t if c is None else xor(t, c))
+                if i < 31:
+                    u = and_(x[i], y[i])
+                    c = u if c is None else xor(u, and_(c, t))
+            return out
+        W = list(msg)
+        for t in range(16, max(16, rounds)):
+            s0 = xor3(rotr(W[t - 15], 7), rotr(W[t - 15], 18), shr(W[t - 15], 3))
+            s1 = xor3(rotr(W[t - 2], 17), rotr(W[t - 2], 19), shr(W[t - 2], 10))
+            W.append(add(add(add(W[t - 16], s0), W[t - 7]), s1))
+        st = [const(v) for v in self.IV]
+        a, b, c, d, e, f, h_g, h = st
+        gg = h_g
+        for t in range(rounds):
+            S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25))
+            ch = [xor(gi, and_(ei, xor(fi, gi))) for ei, fi, gi in zip(e, f, gg)]          # (e & f) ^ (~e & g)
+            t1 = add(add(add(add(h, S1), ch), const(self.K[t])), W[t])
+            S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22))
+            maj = [xor(and_(ai, bi), and_(ci, xor(ai, bi))) for ai, bi, ci in zip(a, b, c)]
+            t2 = add(S0, maj)
+            h, gg, f, e, d, c, b, a = gg, f, e, add(d, t1), c, b, a, add(t1, t2)
+        out = [add(x, y) for x, y in zip(st, [a, b, c, d, e, f, gg, h])]
+        self.digest_wires = [w for word in out for w in word]       # word by word, least significant bit first
+        self.n_gates = sum(1 for t in g if t[0] in ('xor', 'and', 'not'))
+        self.n_wires = len(g)
+
+    def relation_messages(self, with_epilogue=True, free_last=True):
+        from .sieve_writer import write_relation
+        gates = list(self._g)
+        n = self.n_wires
+        if with_epilogue:
+            for k, w in enumerate(self.digest_wires):
+                gates += [('instance', n + 2 * k), ('xor', n + 2 * k + 1, w, n + 2 * k), ('assert_zero', n + 2 * k + 1)]
+            gates.append(('free', n, n + 2 * len(self.digest_wires) - 1))
+        if free_last:
+            gates.append(('free', 0, n - 1))
+        msgs = []
+        for at in range(0, len(gates), MAX_GATES_PER_MESSAGE):
+            msgs.append(write_relation(self.mod_le, 'boolean', 'simple', [], gates[at:at + MAX_GATES_PER_MESSAGE]))
+        return msgs
+
+    def output_wire_ids(self):
+        return list(self.digest_wires)
+
+    @staticmethod
+    def _block_bits(block):
+        """64 bytes -> 512 witness bits: big-endian words, least significant bit first inside a word"""
+        words = np.frombuffer(block, dtype='>u4').astype(np.uint32)
+        return ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(512)
+
+    def inputs(self, batch, lane_offset=0, corrupt_every=97):
+        """(instances [batch][256][1], witnesses [batch][512][1], lanes made false): every lane hashes its own 55-byte message
+        (one padded block); the claimed digest is hashlib's, with one bit flipped on every `corrupt_every`-th lane"""
+        import hashlib
+        assert self.rounds == 64, 'the expected digests are those of the full compression function'
+        inst = np.zeros((batch, 256, 1), dtype=np.uint8)
+        wit = np.zeros((batch, 512, 1), dtype=np.uint8)
+        bad = 0
+        for lane in range(batch):
+            rng = np.random.default_rng(self.seed + lane + lane_offset)
+            msg = rng.integers(0, 256, size=55, dtype=np.uint8).tobytes()
+            block = msg + b'\x80' + (8 * len(msg)).to_bytes(8, 'big')
+            wit[lane, :, 0] = self._block_bits(block)
+            inst[lane, :, 0] = self._block_bits(hashlib.sha256(msg).digest() + bytes(32))[:256]
+            if corrupt_every and (lane + lane_offset) % corrupt_every == 0:
+                inst[lane, (lane + lane_offset) % 256, 0] ^= 1
+                bad += 1
+        return inst, wit, bad
+
+
 class R1csSynthetic:
     """The C5 workload: M rows over n_base + M variables over BN254.  Row i is
     (sum of 3 coef*var) * (sum of 3 coef*var) = z_i with the six variables drawn from the variables that
@@ -355,6 +468,7 @@ class StructuredArith:
         last result is compared -- the same calls, but a dependency chain N iterations deep instead of N independent ones:
         the shape that leaves a GPU nothing but the witnesses to run in parallel."""
         self.N, self.seed, self.p, self.chained = N, seed, p, chained
+        self.closed_form = True
         self.mod_le = int_to_le(p)
         self.width = 8 * ((p.bit_length() + 63) // 64)
         self.n_instance = 1 if chained else N
