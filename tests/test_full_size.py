@@ -253,8 +253,9 @@ def test_sha256_compression_against_hashlib_and_the_oracle(path):
         ref = oracle_lane(wl.mod_le, [int(x) for x in inst[lane, :, 0]], [int(x) for x in wit[lane, :, 0]], msgs, 1, trace=False)
         assert ev.get_violations(lane) == ref.violations, lane
     # the digest wires themselves (a session without the epilogue): hashlib's bits
+    # (nothing is freed, so every wire stays readable: 121,586 of them, the HBM-table kernel)
     probe = zk.Evaluator()
-    probe.set_option('bool_path', path)
+    probe.set_option('bool_path', 'hbm')
     probe.declare_inputs(0, wl.n_witness)
     for m in wl.relation_messages(with_epilogue=False, free_last=False):
         probe.ingest_message(m)

@@ -111,7 +111,9 @@ def interpret(prog, consts, inst_bits, wit_bits):
                         if kind in (K_XOR, K_AND):
                             reads.add(b)
                     if kind in (K_XOR, K_AND, K_NOT, K_COPY, K_CONST, K_INSTANCE, K_WITNESS):
-                        writes.append(dst)
+                        assert dst < real + 32, 'an entry writes a constant slot'
+                        if dst < real:           # (the padding entries write the scratch slots, any number of them one slot)
+                            writes.append(dst)
                 assert len(set(writes)) == len(writes), 'two entries of a packet write one slot'
                 assert not (reads & set(writes)), 'a packet reads a slot it writes: its entries are not independent'
                 for e in packet:

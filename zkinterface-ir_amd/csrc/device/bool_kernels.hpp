@@ -565,6 +565,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
           // (entries as the 8-byte words they are: {dst, a, b, kind} little-endian; 0 = a no-op)
           const u64* __restrict__ w = reinterpret_cast<const u64*>(args.ops) + first + tid;
           auto entry = [](u64 x) { return LdsOp{(unsigned short)x, (unsigned short)(x >> 16), (unsigned short)(x >> 32), (unsigned short)(x >> 48)}; };
+          // one packet: every lane an and / xor (not and copy are xor with ONES / ZERO, padding is ZERO xor ZERO into a scratch
+          // slot: lds_program.cpp) -- two reads, one select, one write, no branch; the few lanes that hold an input, a
+          // constant or an assert run theirs afterwards
+          auto packet = [&](u64 x) {
+            const u32 kind = (u32)(x >> 48), dst = (u32)x & 0xFFFFu, a = (u32)(x >> 16) & 0xFFFFu, b = (u32)(x >> 32) & 0xFFFFu;
+            const bool gate = kind == OP_AND || kind == OP_XOR;
+            const u32 va = T[gate ? a : 0u], vb = T[gate ? b : 0u];
+            if (gate) T[dst] = kind == OP_AND ? (va & vb) : (va ^ vb);
+            if (__ballot(!gate && kind != OP_NOP) != 0ull) {
+              if (!gate) lds_exec(entry(x), T, args, col, valid_mask);
+            }
+          };
           u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // four packets in hand, four on their way (the compiler owns 64 registers here)
           if (0 < rows) c0 = w[0 * kLdsPacketOps];
           if (1 < rows) c1 = w[1 * kLdsPacketOps];
@@ -576,10 +588,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
             if (p0 + 5 < rows) n1 = w[(size_t)(p0 + 5) * kLdsPacketOps];
             if (p0 + 6 < rows) n2 = w[(size_t)(p0 + 6) * kLdsPacketOps];
             if (p0 + 7 < rows) n3 = w[(size_t)(p0 + 7) * kLdsPacketOps];
-            lds_exec(entry(c0), T, args, col, valid_mask);
-            lds_exec(entry(c1), T, args, col, valid_mask);
-            lds_exec(entry(c2), T, args, col, valid_mask);
-            lds_exec(entry(c3), T, args, col, valid_mask);
+            packet(c0);
+            packet(c1);
+            packet(c2);
+            packet(c3);
             c0 = n0;
             c1 = n1;
             c2 = n2;

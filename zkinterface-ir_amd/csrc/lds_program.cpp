@@ -125,11 +125,22 @@ LdsProgram build_lds_program(const Schedule& s, const std::vector<uint32_t>& blo
         ln.insert(ln.end(), {first, L.count, zkgpu::kLdsChunkSequential | zkgpu::kLdsChunkBarrier, 0u});
         continue;
       }
-      const LdsOp pad{scratch, 0, 0, (unsigned short)TK_NOP};
+      // The 64 lanes of a packet run in lockstep: an entry kind of its own per lane would make the wave execute every kind's
+      // code one after the other.  As in the rows, `not a` is stored as a xor ONES, a copy as a xor ZERO and the padding as
+      // ZERO xor ZERO into a scratch slot: a packet is and / xor entries (one select) plus, rarely, inputs, constants and
+      // asserts, which the kernel runs in a second pass over the lanes that hold them.
       const uint32_t first = (uint32_t)lo.size();
       for (uint32_t q = 0; q < L.strand_levels; ++q) {
-        for (uint32_t k = lp[q]; k < lp[q + 1]; ++k) lo.push_back(encode(s.ops[L.first + k]));
-        while ((lo.size() - first) % zkgpu::kLdsPacketOps) lo.push_back(pad);
+        for (uint32_t k = lp[q]; k < lp[q + 1]; ++k) {
+          LdsOp o = encode(s.ops[L.first + k]);
+          if (o.kind == TK_NOT) { o.kind = TK_XOR; o.b = ones; }
+          else if (o.kind == TK_COPY) { o.kind = TK_XOR; o.b = zero; }
+          lo.push_back(o);
+        }
+        while ((lo.size() - first) % zkgpu::kLdsPacketOps) {
+          const unsigned short lane = (unsigned short)((lo.size() - first) % zkgpu::kLdsPacketOps);
+          lo.push_back(LdsOp{(unsigned short)(scratch + lane % zkgpu::kLdsScratchSlots), zero, zero, (unsigned short)TK_XOR});
+        }
       }
       ln.insert(ln.end(), {first, ((uint32_t)lo.size() - first) / zkgpu::kLdsPacketOps,
                            zkgpu::kLdsChunkSequential | zkgpu::kLdsChunkWave | zkgpu::kLdsChunkBarrier, 0u});
