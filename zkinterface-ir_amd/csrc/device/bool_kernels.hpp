@@ -559,7 +559,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
       // generic chunk: inputs, constants, asserts, NOP padding, or a sequential (narrow-level) segment
       if (flags & kLdsChunkWave) {
         // a run of narrow levels: wave 0 walks its packets of 64 entries, lane l executing entry l (lds_layout.hpp).  The
-        // entries of four packets are fetched while the four before them run: the program stream is the only thing that
+        // entries of eight packets are fetched while the eight before them run: the program stream is the only thing that
         // comes from memory, and a wave's LDS accesses complete in order, so nothing else is waited for between levels.
         if (tid < (u32)kLdsPacketOps) {
           // (entries as the 8-byte words they are: {dst, a, b, kind} little-endian; 0 = a no-op)
@@ -577,25 +577,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kLdsCompilerVg
               if (!gate) lds_exec(entry(x), T, args, col, valid_mask);
             }
           };
-          u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;   // four packets in hand, four on their way (the compiler owns 64 registers here)
-          if (0 < rows) c0 = w[0 * kLdsPacketOps];
-          if (1 < rows) c1 = w[1 * kLdsPacketOps];
-          if (2 < rows) c2 = w[2 * kLdsPacketOps];
-          if (3 < rows) c3 = w[3 * kLdsPacketOps];
-          for (u32 p0 = 0; p0 < rows; p0 += 4) {
-            u64 n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-            if (p0 + 4 < rows) n0 = w[(size_t)(p0 + 4) * kLdsPacketOps];
-            if (p0 + 5 < rows) n1 = w[(size_t)(p0 + 5) * kLdsPacketOps];
-            if (p0 + 6 < rows) n2 = w[(size_t)(p0 + 6) * kLdsPacketOps];
-            if (p0 + 7 < rows) n3 = w[(size_t)(p0 + 7) * kLdsPacketOps];
-            packet(c0);
-            packet(c1);
-            packet(c2);
-            packet(c3);
-            c0 = n0;
-            c1 = n1;
-            c2 = n2;
-            c3 = n3;
+          // eight packets in hand, eight on their way (the compiler owns 64 registers here): the program stream is the only
+          // thing that comes from memory
+          u64 c[8], n[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) c[q] = (u32)q < rows ? w[(size_t)q * kLdsPacketOps] : 0ull;
+          for (u32 p0 = 0; p0 < rows; p0 += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) n[q] = p0 + 8 + q < rows ? w[(size_t)(p0 + 8 + q) * kLdsPacketOps] : 0ull;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) packet(c[q]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) c[q] = n[q];
           }
         }
       } else if ((flags >> 9) & 1) {
