@@ -13,7 +13,7 @@ zk = entry.load_package()
 from zkinterface_ir_amd import workloads  # noqa: E402
 
 wl = workloads.BoolLayered(W=int(os.environ.get('C4_WIDTH', 16384)), D=int(os.environ.get('C4_DEPTH', 640)))
-msgs = wl.relation_messages()
+msgs = [b"".join(wl.relation_messages())] if os.environ.get("ONE_BUFFER") else wl.relation_messages()
 for threads in [int(t) for t in os.environ.get('THREADS', '8').split(',')]:
     ev = zk.Evaluator()
     ev.set_option('schedule_threads', str(threads))
