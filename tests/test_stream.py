@@ -280,3 +280,33 @@ def test_streamed_gf2_relation_against_the_oracle_and_the_unstreamed_lds_program
 def cpu_checkers_outputs(wl, inst, wit):
     import cpu_checkers
     return cpu_checkers.bool_layered_outputs(wl, inst, wit)
+
+
+def test_a_byte_stream_of_several_messages_is_decoded_ahead_with_the_same_outcome():
+    """zkgpu_ingest_messages on a buffer that holds several messages decodes message k + 1 on a helper thread while message
+    k is recorded (capi.cpp MessageDecoder).  Outcome by outcome what ingesting them one call at a time gives: the same
+    tape, the same latch when a message in the middle does not decode (the reference panics there, evaluator.rs:193), and
+    nothing recorded behind it."""
+    wl = workloads.ArithLayered(W=256, D=60, n_instance0=16, n_out=8)
+    msgs = wl.relation_messages()
+    msgs = msgs + workloads.ArithLayered(W=64, D=2, n_instance0=4, n_out=2).relation_messages()[:0]
+    parts = [sw.write_relation(wl.mod_le, 'arithmetic', 'simple', [], [('witness', 1000 + k)] + [('mul', 2000 + 3 * k + j, 1000 + k, 1000 + k) for j in range(3)])
+             for k in range(6)]
+
+    def session(bufs):
+        ev = zk.Evaluator()
+        ev.declare_inputs(wl.n_instance, wl.n_witness + 6)
+        for b in bufs:
+            ev.ingest_message(b)
+        return ev
+    one_by_one, at_once = session(msgs + parts), session([b''.join(msgs + parts)])
+    assert at_once.host_violations() == one_by_one.host_violations() == []
+    for x, y in zip(at_once.tape(), one_by_one.tape()):
+        assert np.array_equal(x, y)
+    # a message that does not decode, in the middle: everything before it is recorded, the error latches, nothing behind it
+    broken = bytearray(parts[2])
+    broken[40:48] = b'\xff' * 8
+    bad = msgs + parts[:2] + [bytes(broken)] + parts[3:]
+    a, b = session(bad), session([b''.join(bad)])
+    assert a.host_violations() == b.host_violations() and a.host_violations() != []
+    assert a.tape_len == b.tape_len == session(msgs + parts[:2]).tape_len
