@@ -188,7 +188,7 @@ def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_b
     for env, opt in (('ZKI_STREAM', 'stream'), ('ZKI_FUSE', 'fuse'), ('ZKI_OPW', 'level_ops_per_wave'), ('ZKI_HOT_WAVES', 'hot_waves'),
                      ('ZKI_GRAPH', 'graph'), ('ZKI_XCD_MAP', 'xcd_map'), ('ZKI_SORT_BY_OPERAND', 'sort_by_operand'),
                      ('ZKI_STRAND_WIDTH', 'strand_width'), ('ZKI_BANK_AWARE', 'bank_aware'), ('ZKI_FERMAT', 'fermat'),
-                     ('ZKI_PAIR', 'pair'), ('ZKI_STRAND_LDS', 'strand_lds'), ('ZKI_BOOL_NARROW', 'bool_narrow_width')):
+                     ('ZKI_PAIR', 'pair'), ('ZKI_STRAND_LDS', 'strand_lds'), ('ZKI_STRAND_PREFETCH', 'strand_prefetch'), ('ZKI_BOOL_NARROW', 'bool_narrow_width')):
         if os.environ.get(env):
             ev.set_option(opt, os.environ[env])
     ev.declare_inputs(wl.n_instance, wl.n_witness)
@@ -388,8 +388,13 @@ def compact_line(full, detail_path):
         line['cpu_baseline'] = head['cpu_baseline']
     if 'roofline_hbm' in full:
         line['roofline_hbm'] = compact_roofline(full['roofline_hbm'])
+    def brief(d):   # a variant of a workload the line already carries in full
+        r = d.get('roofline') or {}
+        return {'ms_per_step': d['ms_per_step'], 'value': d['value'], 'counts': [d['config'].get('satisfied'), d['config'].get('failed')],
+                'classes': d['config'].get('combinations_by_coefficient_class'),
+                'roofline': {'kernel': r.get('kernel'), 'bound': r.get('bound'), 'frac': r.get('frac')}}
     if 'secondary' in full:
-        line['secondary'] = {k: wl(v) for k, v in full['secondary'].items() if v}
+        line['secondary'] = {k: (brief(v) if k == 'c5_small' else wl(v)) for k, v in full['secondary'].items() if v}
         line['secondary_wall_s'] = full.get('secondary_wall_s')
     cfg = full.get('config', {})
     keep = ('workload', 'batch_per_gpu', 'backend_ops_per_witness', 'program_entries', 'levels', 'launches_per_step',
@@ -404,20 +409,24 @@ def compact_line(full, detail_path):
     return _r(line)
 
 
-def bench_c5(args, zk, workloads, ctx, steps, warmup, cpu_budget_s=15.0):
+def bench_c5(args, zk, workloads, ctx, steps, warmup, cpu_budget_s=15.0, coef_kind='random'):
     """BASELINE configs[4]: 2^20-row R1CS over BN254 (3+3+1 terms per row), witness batch 1024 per GPU.
-    step = the row check <a,w>*<b,w> = <c,w> of every row for every lane + the count reduction."""
+    step = the row check <a,w>*<b,w> = <c,w> of every row for every lane + the count reduction.
+    coef_kind 'small': the same rows with coefficients 1 / -1 / 16-bit signed integers (workloads.R1csSynthetic), which the
+    row kernel takes by its unit / small coefficient classes -- a variant next to the BASELINE line, never instead of it."""
     world, rank, dist, torch, red_dev, dist_on = ctx['world'], ctx['rank'], ctx['dist'], ctx['torch'], ctx['red_dev'], ctx['dist_on']
     M = (args.width or (1 << 20)) if args.workload == 'c5' else (1 << 20)
     batch = (args.batch_per_gpu or 1024) if args.workload == 'c5' else 1024
     t0 = time.time()
-    wl = workloads.R1csSynthetic(M=M)
+    wl = workloads.R1csSynthetic(M=M, coef_kind=coef_kind)
+    small = coef_kind != 'random'
     ev = zk.Evaluator()
     ev.declare_inputs(0, wl.n_witness)
     ev.ingest_message(wl.base_relation())
     ev.finalize(retain_all=True)
     row_ptr, tv, tc, cb = wl.csr()
     ev.r1cs_load_csr(row_ptr, tv, tc, cb, wl.width, wl.M)
+    classes = ev.r1cs_class_counts()
     t1 = time.time()
     lane_offset = rank * batch
     w = wl.witnesses(batch, lane_offset)
@@ -477,15 +486,17 @@ def bench_c5(args, zk, workloads, ctx, steps, warmup, cpu_budget_s=15.0):
             'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed * 1e3 / steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'u64x4 (GF(p) Montgomery limbs, exact integer)', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[4]: %d-row R1CS (3+3+1 terms, random coefficients) over BN254, '
-                                   'witness batch=%d per GPU, %d GPU(s)' % (M, batch, world),
+            'config': {'workload': ('the rows of BASELINE configs[4] with coefficients 1 / -1 / 16-bit signed integers: ' if small else
+                                    'BASELINE configs[4]: ') + '%d-row R1CS (3+3+1 terms, %s coefficients) over BN254, '
+                                   'witness batch=%d per GPU, %d GPU(s)' % (M, 'small' if small else 'random', batch, world),
+                       'combinations_by_coefficient_class': classes,
                        'batch_per_gpu': batch, 'variables': wl.n_base + 1 + M, 'dependency_levels': wl.n_levels, 'rows': n_rows,
                        'wire_table_GB': round(ev.table_bytes / 1e9, 2), 'satisfied': total[0], 'failed': total[1],
                        'host_seconds': {'build_s': round(t1 - t0, 2), 'witness_generation_s': round(t2 - t1, 2)}},
-            'roofline': make_roofline('c5', 'r1cs_row_kernel<8, false>', 1, kernel_ms, 7.0 * wl.width * M * batch,
-                                      {'entries': n_rows, 'launches': 1, 'batch': batch}),
+            'roofline': make_roofline('c5_small' if small else 'c5', 'r1cs_row_kernel<8, false, %s>' % ('true' if small else 'false'), 1,
+                                      kernel_ms, 7.0 * wl.width * M * batch, {'entries': n_rows, 'launches': 1, 'batch': batch}),
         }
-        if not args.no_cpu_baseline and world == 1:  # rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and cpu_budget_s > 0:  # rank 0 at N=1 only
             # the row check on the host cores for a bounded sample of the same lanes (oracle/cpu_opt.cpp:
             # the mathematical definition -- the reference itself holds no row checker)
             sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -498,7 +509,7 @@ def bench_c5(args, zk, workloads, ctx, steps, warmup, cpu_budget_s=15.0):
                                    'sample_witnesses': sample, 'sample_seconds': secs,
                                    'sample': '%d witnesses of the same %d-row system, 4x64 Montgomery row check on %d '
                                              'threads, %.1f s wall (witness generation excluded)' % (sample, n_rows, threads, secs)}
-    if rank == 0 and world == 1 and not args.no_first_verdict:
+    if rank == 0 and world == 1 and not args.no_first_verdict and not (small and args.workload != 'c5'):
         # relation + constraint system in -> first verdict out on a fresh session (the witness generation of the product
         # rows, level by level, is part of it: the batch arrives as base variables)
         w0 = wl.witnesses(batch, lane_offset)
@@ -851,6 +862,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-hbm-variant', action='store_true', help='c2: skip the 4096-witnesses-in-flight variant')
     ap.add_argument('--chained', action='store_true', help='structured: every iteration depends on the one before')
+    ap.add_argument('--coefs', default='random', choices=['random', 'small'],
+                    help='c5: random field elements (BASELINE configs[4]) or 1 / -1 / 16-bit signed integers (the coefficient classes)')
     ap.add_argument('--no-first-verdict', action='store_true', help='c2: skip the relation-in -> first-verdict-out sessions')
     ap.add_argument('--no-secondary', action='store_true', help='c2 on one GPU: skip the c4 / c5 / structured lines')
     ap.add_argument('--full-line', action='store_true', help='print everything on the line (default: the compact line; the rest in the detail file)')
@@ -899,7 +912,7 @@ def main():
            'backend': backend, 'n_dev': n_dev, 'dev_index': dev_index}
 
     if args.workload == 'c5':
-        out = bench_c5(args, zk, workloads, ctx, args.steps, args.warmup)
+        out = bench_c5(args, zk, workloads, ctx, args.steps, args.warmup, coef_kind=args.coefs)
     else:
         out = bench_tape(args.workload, args, zk, workloads, ctx, args.steps, args.warmup, True)
     default_c2 = args.workload == 'c2' and not (args.width or args.depth or args.batch_per_gpu or args.lane_group)
@@ -909,6 +922,7 @@ def main():
         sec = {}
         sec['c4'] = bench_tape('c4', args, zk, workloads, ctx, 20, 3, False, cpu_budget_s=4.0)
         sec['c5'] = bench_c5(args, zk, workloads, ctx, 5, 1, cpu_budget_s=4.0)
+        sec['c5_small'] = bench_c5(args, zk, workloads, ctx, 5, 1, cpu_budget_s=0, coef_kind='small')
         sec['structured'] = bench_tape('structured', args, zk, workloads, ctx, 20, 3, False, cpu_budget_s=4.0)
         # the same calls as a dependency chain (every iteration reads the previous result): strands
         args.chained = True

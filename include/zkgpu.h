@@ -315,6 +315,12 @@ uint64_t zkgpu_table_bytes(const zkgpu_session* s);
 int zkgpu_r1cs_from_tape(zkgpu_session* s, int use_correction);
 /* out[0]=rows out[1]=variables out[2]=terms out[3]=distinct coefficients */
 int zkgpu_r1cs_info(const zkgpu_session* s, uint64_t out[4]);
+/* How many of the rows' 3 x rows combinations the row kernel takes by which path: out[0] any coefficients (Montgomery
+ * products with the pool), out[1] every coefficient 1 or -1 (additions), out[2] every coefficient a signed integer
+ * below 2^31 in magnitude (N word products per term instead of N^2; what FromR1CSConverter expansions mostly hold,
+ * from_r1cs.rs:110-125).  Option "r1cs_coef_classes" = "0" (before the rows are made) sends every combination down
+ * the first path. */
+int zkgpu_r1cs_class_counts(const zkgpu_session* s, uint64_t out[3]);
 /* row_ptr: 3 entries per row (start of A, B, C in the term arrays) + final end; var_of_op[i] = variable of
  * tape op i (0xFFFF...F for assert_zero).  Any pointer may be NULL. */
 int zkgpu_r1cs_export(const zkgpu_session* s, uint32_t* row_ptr, uint64_t* term_var, uint32_t* term_coef,

@@ -713,13 +713,22 @@ def test_r1cs_batched_matches_evaluation_counts():
     assert [(int(x) == zk.NO_FAIL) for x in ff] == [(int(x) == zk.NO_FAIL) for x in first]
 
 
-@pytest.mark.parametrize('p', [101, circuits.BN254_R])
-def test_r1cs_csr_rows_with_coefficients(p):
+SECP256K1_P = 2 ** 256 - 2 ** 32 - 977   # top bit set: twice a canonical value does not fit the eight words
+
+
+@pytest.mark.parametrize('p,coef_kind,classes', [
+    (101, 'random', True), (circuits.BN254_R, 'random', True),
+    # coefficients 1 / -1 / small signed integers: the unit and small coefficient classes of the row kernel
+    # (device/args.hpp kR1csClass*), against the same Python integers; and the same rows with the classes turned off
+    (101, 'small', True), (circuits.BN254_R, 'small', True), (circuits.BN254_R, 'small', False), (2 ** 61 - 1, 'small', True),
+    (SECP256K1_P, 'small', True), (circuits.P512, 'small', True)])
+def test_r1cs_csr_rows_with_coefficients(p, coef_kind, classes):
     """caller-supplied CSR (3+3 term products with random coefficients): witness generation by the
     row kernel level by level, values against Python integers, then the check; one false row."""
-    wl = workloads.R1csSynthetic(M=300, n_base=24, n_coefs=50, seed=5, p=p)
+    wl = workloads.R1csSynthetic(M=300, n_base=24, n_coefs=50, seed=5, p=p, coef_kind=coef_kind)
     batch = 67
     ev = zk.Evaluator()
+    ev.set_option('r1cs_coef_classes', '1' if classes else '0')
     ev.declare_inputs(0, wl.n_witness)
     ev.ingest_message(wl.base_relation())
     ev.finalize(retain_all=True)
@@ -762,9 +771,12 @@ def test_r1cs_csr_rows_with_coefficients(p):
     assert counts == (0, batch)            # the appended false row fails in every lane
     assert all(int(x) == wl.M + 1 for x in ff)
     # the CPU row check (oracle/cpu_opt.cpp, the cpu_baseline of bench.py --workload c5) sees the same first failing row
-    from oracle_lib import r1cs_check
-    ff_cpu, _ = r1cs_check(row_ptr, tv, tc, cb, wl.mod_le, w, wl.n_base + 1 + wl.M, wl.M, 4)
-    assert np.array_equal(ff_cpu, ff)
+    if wl.width <= 32:     # (that checker is written for four 64-bit limbs)
+        from oracle_lib import r1cs_check
+        ff_cpu, _ = r1cs_check(row_ptr, tv, tc, cb, wl.mod_le, w, wl.n_base + 1 + wl.M, wl.M, 4)
+        assert np.array_equal(ff_cpu, ff)
+    cc = ev.r1cs_class_counts()
+    assert (cc['unit'] > 0 and cc['small'] > 0) == (coef_kind == 'small' and classes), cc
 
 
 def test_synth_workspace_round_trips_through_files_and_oracle(tmp_path):

@@ -69,8 +69,10 @@ def test_arithmetic_kernels_at_bn254_width():
     res = kernel_resources.resources('kernels_arith.hip', ['-DZKGPU_W=8'])
     hot = res['zkgpu::replay_fused_kernel<8, 0>']
     assert hot['vgprs'] <= 64 and hot['agprs'] == 0 and hot['scratch'] == 0 and hot['occupancy'] == 8 and hot['sgpr_spill'] == 0, hot
-    row = res['zkgpu::r1cs_row_kernel<8, false>']
+    row = res['zkgpu::r1cs_row_kernel<8, false, false>']
     assert row['scratch'] == 0 and row['vgpr_spill'] == 0 and row['sgpr_spill'] == 0, row
+    # (the instantiation with the coefficient classes is a separate one: the BASELINE rows keep the registers of their path)
+    assert res['zkgpu::r1cs_row_kernel<8, false, true>']['scratch'] == 0
     for name, k in res.items():
         # (the input streams' descriptors sit behind one pointer, device/args.hpp InputAux: in the kernarg block they made
         # the cold kernels spill 28 SGPRs and the strands of a structured relation 13 % slower)

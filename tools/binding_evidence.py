@@ -148,7 +148,7 @@ def main():
                       'traffic_source': 'profiles/pmc_traffic_c5.json'})
             sources.append('profiles/pmc_traffic_c5.json')
         dump(d, 'binding_c5.json', {
-            'workload': 'c5', 'kernel': 'r1cs_row_kernel<8, false>', 'binding': 'valu',
+            'workload': 'c5', 'kernel': 'r1cs_row_kernel<8, false, false>', 'binding': 'valu',
             'program': {'entries': rows, 'launches': 1, 'batch': batch}, 'constants': c,
             'reading': 'a row = 664 word products (v_mad_u64_u32 + v_addc_co_u32 each) + the rest; at the instruction rates measured '
                        'on this chip (v_mad_u64_u32 26.6 T lane-ops/s, add-with-carry 68 T, other 32-bit integer ops about 35 T) that '

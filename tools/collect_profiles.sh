@@ -95,7 +95,7 @@ elif [ $WHAT = pmc_c45 ]; then
   # same program size -- what is left is the program stream and the barriers
   ZKI_C4_WIRING=identity ZKI_BENCH_DETAIL=gpurun_out/$TAG/${TAG}_bench_c4_identity_detail.json $B --workload c4 --steps 10 --warmup 2 --no-cpu-baseline --no-first-verdict > $OUT/${TAG}_bench_c4_identity_wiring.json 2> $OUT/bench_c4_identity.err
   C5="--workload c5 --steps 2 --warmup 1 --timed-steps-only"
-  K5='r1cs_row_kernel<8, false>'
+  K5='r1cs_row_kernel<8, false, false>'
   pmc c5_f FETCH_SIZE -- $C5
   pmc c5_w WRITE_SIZE -- $C5
   python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c5_f.csv /tmp/pmc_c5_w.csv $OUT/pmc_traffic_c5.json 1000 "$K5" c5 > /dev/null

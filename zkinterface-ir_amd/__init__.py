@@ -122,6 +122,7 @@ def lib():
         'zkgpu_table_bytes': (u64, [vp]),
         'zkgpu_r1cs_from_tape': (ci, [vp, ci]),
         'zkgpu_r1cs_info': (ci, [vp, u64p]),
+        'zkgpu_r1cs_class_counts': (ci, [vp, u64p]),
         'zkgpu_r1cs_export': (ci, [vp, vp, vp, vp, vp]),
         'zkgpu_r1cs_coef_bytes': (sz, [vp, u32, ctypes.c_char_p, sz]),
         'zkgpu_r1cs_load_csr': (ci, [vp, u32, vp, vp, vp, vp, u32, u32, u32]),
@@ -543,6 +544,12 @@ class Evaluator:
         out = (ctypes.c_uint64 * 4)()
         self._ck(self.L.zkgpu_r1cs_info(self.h, out))
         return dict(zip(['rows', 'vars', 'terms', 'coefs'], list(out)))
+
+    def r1cs_class_counts(self):
+        """combinations of the rows by coefficient class (include/zkgpu.h zkgpu_r1cs_class_counts)"""
+        out = (ctypes.c_uint64 * 3)()
+        self._ck(self.L.zkgpu_r1cs_class_counts(self.h, out))
+        return dict(zip(['full', 'unit', 'small'], [int(x) for x in out]))
 
     def r1cs_export(self):
         """(rows, var_of_op): rows = list of (A, B, C), each a list of (variable, coefficient int)"""

@@ -116,7 +116,7 @@ struct zkgpu_session {
   uint32_t stream_window = 0;        // option "stream": tape entries per window, 0 = schedule everything at finalize
   uint32_t sched_threads = 0;
   bool bank_aware = true;
-  bool strand_lds = true;
+  bool strand_lds = true, strand_prefetch = true;
   uint32_t bool_narrow_width = 0;   // 0 = the scheduler's default
   uint32_t strand_width = 0;   // 0 = the scheduler's default
   std::unique_ptr<StreamState> stream;
@@ -126,6 +126,7 @@ struct zkgpu_session {
   size_t n_pinned = 0;
   R1cs r1cs;                         // constraint system derived from the tape or loaded as CSR
   bool r1cs_ready = false, r1cs_on_device = false, r1cs_loaded_csr = false;
+  bool r1cs_coef_classes = true;     // option "r1cs_coef_classes": combinations of coefficients 1 / -1 / small integers take the cheap row paths
   std::vector<R1csRowDev> r1cs_rows_dev;
   std::vector<R1csTermDev> r1cs_terms_dev;
   std::vector<uint32_t> r1cs_coef_words;
@@ -218,6 +219,7 @@ ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
   opt.threads = s->sched_threads;
   opt.bank_aware = s->bank_aware;
   opt.strand_lds = s->strand_lds;
+  opt.strand_prefetch = s->strand_prefetch;
   if (s->bool_narrow_width) opt.bool_narrow_width = s->bool_narrow_width;
   if (s->strand_width) opt.strand_width = s->strand_width;
   return opt;
@@ -895,20 +897,41 @@ namespace {
 // coefficient pool -> Montgomery words; coefficient 1 -> 0xFFFFFFFF (no multiply), 0 -> term dropped
 struct CoefMap {
   std::vector<uint32_t> index;  // per host coefficient: device index, 0xFFFFFFFF (one) or 0xFFFFFFFE (zero)
+  std::vector<uint32_t> small;  // ... as a signed integer, sign << 31 | magnitude, where the magnitude is below 2^31
+                                // (the smaller of c and p - c); 0: not such a coefficient
   std::vector<uint32_t> words;
 };
 CoefMap device_coefs(const std::vector<Value>& coefs, const FieldHost& f) {
   CoefMap m;
   m.index.resize(coefs.size());
+  m.small.assign(coefs.size(), 0);
+  uint32_t pw[kFieldWords] = {0};
+  memcpy(pw, f.p, sizeof(uint32_t) * std::min<size_t>(f.nwords, kFieldWords));
   for (size_t i = 0; i < coefs.size(); ++i) {
     uint32_t r[kFieldWords], mont[kFieldWords];
     f.reduce(coefs[i], r);
-    bool zero = true, one = r[0] == 1;
+    bool zero = true, one = r[0] == 1, single = true;
     for (int k = 0; k < kFieldWords; ++k) {
       zero &= r[k] == 0;
       if (k) one &= r[k] == 0;
+      if (k) single &= r[k] == 0;
     }
     if (zero) { m.index[i] = 0xFFFFFFFEu; continue; }
+    // p - c in one word?
+    uint32_t neg0 = 0;
+    bool neg_single = true;
+    {
+      uint64_t b = 0;
+      for (int k = 0; k < kFieldWords; ++k) {
+        const uint64_t y = (uint64_t)pw[k] - r[k] - b;
+        b = (y >> 63) & 1;
+        if (k == 0) neg0 = (uint32_t)y;
+        else neg_single &= (uint32_t)y == 0;
+      }
+    }
+    const bool pos_ok = single && r[0] < 0x80000000u, neg_ok = neg_single && neg0 != 0 && neg0 < 0x80000000u;
+    if (pos_ok && (!neg_ok || r[0] <= neg0)) m.small[i] = r[0];
+    else if (neg_ok) m.small[i] = 0x80000000u | neg0;
     if (one) { m.index[i] = 0xFFFFFFFFu; continue; }
     f.to_mont(r, mont);
     m.index[i] = (uint32_t)(m.words.size() / f.nwords);
@@ -929,8 +952,11 @@ void build_device_rows(zkgpu_session* s, SlotOf&& slot_of_var) {
     d.first = (uint32_t)s->r1cs_terms_dev.size();
     uint32_t n[3] = {0, 0, 0};
     bool b_is_one = false;
+    uint32_t cls[3] = {0, 0, 0};
     for (int part = 0; part < 3; ++part) {
       const uint32_t t0 = r.row_ptr[3 * row + part], t1 = r.row_ptr[3 * row + part + 1];
+      const size_t first_term = s->r1cs_terms_dev.size();
+      bool all_unit = true, all_small = true, any_minus = false;
       for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t c = cm.index[r.terms[t].coef];
         if (c == 0xFFFFFFFEu) continue;  // zero coefficient
@@ -939,14 +965,29 @@ void build_device_rows(zkgpu_session* s, SlotOf&& slot_of_var) {
         td.coef = c;
         s->r1cs_terms_dev.push_back(td);
         ++n[part];
+        const uint32_t sm = cm.small[r.terms[t].coef];
+        all_small &= sm != 0;
+        all_unit &= (sm & 0x7FFFFFFFu) == 1;
+        any_minus |= sm == 0x80000001u;
       }
       if (part == 1 && n[1] == 1) {
         const R1csTermDev& last = s->r1cs_terms_dev.back();
         b_is_one = last.slot == 0xFFFFFFFFu && last.coef == 0xFFFFFFFFu;
       }
+      // the coefficient class of the combination (device/args.hpp).  All coefficients 1: class full, whose terms of
+      // coefficient 1 are plain additions already (and what zkgpu_r1cs_assign expects of C).
+      if (s->r1cs_coef_classes && n[part] && all_small && !(all_unit && !any_minus) && !(part == 1 && b_is_one)) {
+        cls[part] = all_unit ? kR1csClassUnit : kR1csClassSmall;
+        size_t k = first_term;
+        for (uint32_t t = t0; t < t1; ++t) {
+          if (cm.index[r.terms[t].coef] == 0xFFFFFFFEu) continue;
+          s->r1cs_terms_dev[k++].coef = cm.small[r.terms[t].coef];
+        }
+      }
     }
     if (n[0] > 255 || n[1] > 255 || n[2] > 255) throw std::runtime_error("R1CS row with more than 255 terms in one combination");
-    d.counts = n[0] | (n[1] << 8) | (n[2] << 16) | ((b_is_one ? 1u : 0u) << 24);
+    d.counts = n[0] | (n[1] << 8) | (n[2] << 16) | ((b_is_one ? 1u : 0u) << 24) |
+               (cls[0] << (24 + kR1csClassShiftA)) | (cls[1] << (24 + kR1csClassShiftB)) | (cls[2] << (24 + kR1csClassShiftC));
     s->r1cs_rows_dev.push_back(d);
   }
   s->r1cs_coef_words = cm.words;
@@ -1526,7 +1567,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     // the scheduler of a streamed ingest took its options when the first window was cut: a later change would be ignored
     // silently by the windows already scheduled -- refuse it instead
     if (s->stream && (k == "fuse" || k == "pair" || k == "fermat" || k == "propagate_copies" || k == "sort_by_operand" ||
-                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "bool_narrow_width" || k == "schedule_threads"))
+                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "strand_prefetch" || k == "bool_narrow_width" || k == "schedule_threads"))
       throw std::runtime_error(k + ": the streamed schedule has started (option \"stream\"); set scheduling options before the first Relation message");
     if (k == "bool_path") {
       if (v == "auto") s->bool_path = 0;
@@ -1573,6 +1614,11 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->bank_aware = v != "0";
     } else if (k == "strand_lds") {
       s->strand_lds = v != "0";
+    } else if (k == "strand_prefetch") {
+      s->strand_prefetch = v != "0";
+    } else if (k == "r1cs_coef_classes") {
+      if (s->r1cs_ready) throw std::runtime_error("r1cs_coef_classes: set it before the rows are made (zkgpu_r1cs_from_tape / zkgpu_r1cs_load_csr)");
+      s->r1cs_coef_classes = v != "0";
     } else if (k == "bool_narrow_width") {
       s->bool_narrow_width = (uint32_t)std::max(3, std::min(2048, atoi(v.c_str())));
     } else if (k == "schedule_threads") {
@@ -1905,6 +1951,16 @@ int zkgpu_r1cs_info(const zkgpu_session* s, uint64_t out[4]) {
   out[1] = s->r1cs.n_vars;
   out[2] = s->r1cs.terms.size();
   out[3] = s->r1cs.coefs.size();
+  return 0;
+}
+
+int zkgpu_r1cs_class_counts(const zkgpu_session* s, uint64_t out[3]) {
+  if (!s || !s->r1cs_ready) return 1;
+  out[0] = out[1] = out[2] = 0;
+  for (const R1csRowDev& d : s->r1cs_rows_dev) {
+    const uint32_t flags = d.counts >> 24;
+    for (uint32_t shift : {kR1csClassShiftA, kR1csClassShiftB, kR1csClassShiftC}) ++out[std::min<uint32_t>((flags >> shift) & 3, 2)];
+  }
   return 0;
 }
 

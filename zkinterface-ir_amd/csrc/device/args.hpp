@@ -181,9 +181,19 @@ struct R1csRow {
 };
 struct R1csTerm {
   u32 slot;  // 0xFFFFFFFF: the constant one
-  u32 coef;  // 0xFFFFFFFF: coefficient 1
+  u32 coef;  // index into the coefficient pool, 0xFFFFFFFF: coefficient 1.  In a combination of class unit / small:
+             // sign << 31 | magnitude of the coefficient as a signed integer (magnitude < 2^31)
 };
 constexpr u32 kR1csBIsOne = 1u;
+// Coefficient classes of a row's three combinations (row flags bits 1-2: A, 3-4: B, 5-6: C), set by the host
+// (capi.cpp build_device_rows) -- what FromR1CSConverter expansions and hand-written R1CS mostly hold
+// (from_r1cs.rs:110-125) are coefficients like 1, -1, 2, 2^k:
+//   full  -- any coefficients: Montgomery products with pool entries (the terms whose coefficient is 1 are added)
+//   unit  -- every coefficient is +1 or -1 (at least one -1): additions and subtractions only
+//   small -- every coefficient is a signed integer below 2^31 in magnitude: N word products per term instead of N^2
+//            and two Montgomery word rounds per combination (r1cs_lincomb_small)
+constexpr u32 kR1csClassFull = 0u, kR1csClassUnit = 1u, kR1csClassSmall = 2u;
+constexpr u32 kR1csClassShiftA = 1u, kR1csClassShiftB = 3u, kR1csClassShiftC = 5u;
 
 struct R1csArgs {
   const R1csRow* rows;
@@ -195,7 +205,8 @@ struct R1csArgs {
   u32 n_slots;
   u32 batch;
   u32* first_fail;       // CHECK: min failing row per lane
-  u32 one_coef;          // index of the Montgomery form of 1 in `coefs` (the host appends it to the pool)
+  u32 one_coef;          // index of the Montgomery form of 1 in `coefs` (the host appends it to the pool); behind it
+                         // the Montgomery forms of 2^64 and 2^128 (what undoes the word rounds of small-class sums)
 };
 
 // quotient wires of the R1CS conversion (r1cs_correction_kernel)
@@ -222,7 +233,7 @@ struct R1csCorrArgs {
   void launch_replay_strand_w##W(int cls, dim3 grid, hipStream_t st, const ReplayArgs2& a, const u32* level_ptr,   \
                                  u32 n_levels, size_t lds_bytes, const FieldParams& fp);                           \
   void launch_replay_w##W(bool bitops, dim3 grid, hipStream_t st, const ReplayArgs& a, const FieldParams& fp);     \
-  void launch_r1cs_w##W(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp);         \
+  void launch_r1cs_w##W(bool assign, bool classes, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp);         \
   void launch_dump_w##W(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,  \
                         u32 batch, u32* out, const FieldParams& fp);                                               \
   void launch_r1cs_corr_w##W(dim3 grid, hipStream_t st, const R1csCorrArgs& a, const FieldParams& fp);

@@ -76,9 +76,12 @@ void launch_plain(uint32_t nwords, bool bitops, dim3 grid, hipStream_t st, const
     default: throw std::runtime_error("Engine: unsupported limb count");
   }
 }
-void launch_r1cs(uint32_t nwords, bool assign, dim3 grid, hipStream_t st, const zkgpu::R1csArgs& a, const zkgpu::FieldParams& fp) {
+static_assert(zki::kR1csClassFull == zkgpu::kR1csClassFull && zki::kR1csClassUnit == zkgpu::kR1csClassUnit &&
+              zki::kR1csClassSmall == zkgpu::kR1csClassSmall && zki::kR1csClassShiftA == zkgpu::kR1csClassShiftA &&
+              zki::kR1csClassShiftB == zkgpu::kR1csClassShiftB && zki::kR1csClassShiftC == zkgpu::kR1csClassShiftC, "r1cs.hpp and device/args.hpp");
+void launch_r1cs(uint32_t nwords, bool assign, bool classes, dim3 grid, hipStream_t st, const zkgpu::R1csArgs& a, const zkgpu::FieldParams& fp) {
   switch (nwords) {
-#define X(W) case W: zkgpu::launch_r1cs_w##W(assign, grid, st, a, fp); break;
+#define X(W) case W: zkgpu::launch_r1cs_w##W(assign, classes, grid, st, a, fp); break;
     ZK_WIDTHS(X)
 #undef X
     default: throw std::runtime_error("Engine: unsupported limb count");
@@ -915,11 +918,26 @@ void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<
     const uint32_t n = (rows[r].counts & 0xFF) + ((rows[r].counts >> 8) & 0xFF) + ((rows[r].counts >> 16) & 0xFF);
     if ((uint64_t)rows[r].first + n > terms.size()) throw std::runtime_error("Engine: R1CS row " + std::to_string(r) + " reaches past the term list");
   }
-  for (size_t t = 0; t < terms.size(); ++t) {
-    if (terms[t].slot != 0xFFFFFFFFu && terms[t].slot >= n_table_slots)
-      throw std::runtime_error("Engine: R1CS term " + std::to_string(t) + " names a wire-table slot out of range");
-    if (terms[t].coef != 0xFFFFFFFFu && terms[t].coef >= n_coefs)
-      throw std::runtime_error("Engine: R1CS term " + std::to_string(t) + " names a coefficient out of range");
+  r1cs_classes_ = false;
+  for (size_t r = 0; r < rows.size(); ++r) {
+    const uint32_t cnt[3] = {rows[r].counts & 0xFF, (rows[r].counts >> 8) & 0xFF, (rows[r].counts >> 16) & 0xFF};
+    const uint32_t flags = rows[r].counts >> 24;
+    const uint32_t cls[3] = {(flags >> zkgpu::kR1csClassShiftA) & 3, (flags >> zkgpu::kR1csClassShiftB) & 3, (flags >> zkgpu::kR1csClassShiftC) & 3};
+    uint32_t t = rows[r].first;
+    for (int part = 0; part < 3; ++part)
+      for (uint32_t k = 0; k < cnt[part]; ++k, ++t) {
+        if (terms[t].slot != 0xFFFFFFFFu && terms[t].slot >= n_table_slots)
+          throw std::runtime_error("Engine: R1CS term " + std::to_string(t) + " names a wire-table slot out of range");
+        const uint32_t c = terms[t].coef;
+        if (cls[part] == zkgpu::kR1csClassFull) {
+          if (c != 0xFFFFFFFFu && c >= n_coefs) throw std::runtime_error("Engine: R1CS term " + std::to_string(t) + " names a coefficient out of range");
+        } else {
+          r1cs_classes_ = true;
+          const uint32_t mag = c & 0x7FFFFFFFu;
+          if (cls[part] > zkgpu::kR1csClassSmall || mag == 0 || (cls[part] == zkgpu::kR1csClassUnit && mag != 1))
+            throw std::runtime_error("Engine: R1CS term " + std::to_string(t) + " does not fit the coefficient class of its combination");
+        }
+      }
   }
   dfree(d_r1cs_rows_);
   dfree(d_r1cs_terms_);
@@ -933,6 +951,37 @@ void Engine::r1cs_upload(const std::vector<R1csRowDev>& rows, const std::vector<
   std::vector<uint32_t> pool(coef_words);
   pool.insert(pool.end(), fpar.one, fpar.one + nwords_);
   r1cs_one_coef_ = (uint32_t)n_coefs;
+  // ... and behind it the Montgomery forms of 2^64 and 2^128 (R mod p doubled 64 and 128 times): what a product of
+  // small-class sums is multiplied by when it is stored (r1cs_row_kernel, ASSIGN)
+  {
+    std::vector<uint32_t> x(fpar.one, fpar.one + nwords_);
+    auto twice = [&]() {
+      uint64_t c = 0;
+      for (uint32_t i = 0; i < nwords_; ++i) {
+        const uint64_t y = 2ull * x[i] + c;
+        x[i] = (uint32_t)y;
+        c = y >> 32;
+      }
+      bool ge = c != 0;
+      if (!ge) {
+        ge = true;
+        for (uint32_t i = nwords_; i-- > 0;)
+          if (x[i] != fpar.p[i]) { ge = x[i] > fpar.p[i]; break; }
+      }
+      if (ge) {
+        uint64_t b = 0;
+        for (uint32_t i = 0; i < nwords_; ++i) {
+          const uint64_t y = (uint64_t)x[i] - fpar.p[i] - b;
+          x[i] = (uint32_t)y;
+          b = (y >> 63) & 1;
+        }
+      }
+    };
+    for (int k = 0; k < 2; ++k) {
+      for (int i = 0; i < 64; ++i) twice();
+      pool.insert(pool.end(), x.begin(), x.end());
+    }
+  }
   HIP_OK(hipMalloc(&d_r1cs_coefs_, std::max<size_t>(pool.size() * 4, 64)));
   if (!rows.empty()) HIP_OK(hipMemcpy(d_r1cs_rows_, rows.data(), rows.size() * sizeof(R1csRowDev), hipMemcpyHostToDevice));
   if (!terms.empty()) HIP_OK(hipMemcpy(d_r1cs_terms_, terms.data(), terms.size() * sizeof(R1csTermDev), hipMemcpyHostToDevice));
@@ -979,7 +1028,7 @@ void Engine::r1cs_run(bool assign, uint32_t first_row, uint32_t n_rows) {
   a.first_fail = (zkgpu::u32*)d_r1cs_fail_;
   a.one_coef = r1cs_one_coef_;
   const dim3 grid((n_rows + 3) / 4, lane_blocks_);
-  launch_r1cs(nwords_, assign, grid, st, a, fp);
+  launch_r1cs(nwords_, assign, r1cs_classes_, grid, st, a, fp);
   HIP_OK(hipGetLastError());
 }
 

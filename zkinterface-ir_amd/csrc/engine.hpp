@@ -202,6 +202,7 @@ class Engine {
   void* ev_r1cs_begin_ = nullptr;
   void* ev_r1cs_end_ = nullptr;
   uint32_t r1cs_rows_ = 0, r1cs_one_coef_ = 0;
+  bool r1cs_classes_ = false;   // some combination of the rows is of class unit / small (device/args.hpp)
   uint32_t extra_slots_ = 0, table_slots_ = 0;
   float last_r1cs_ms_ = 0.f;
   void* d_lds_ops_ = nullptr;       // 8-byte program entries of the LDS-resident GF(2) kernel (generic chunks)

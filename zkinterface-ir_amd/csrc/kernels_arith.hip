@@ -41,9 +41,16 @@ void ZKGPU_FN(launch_replay_w)(bool bitops, dim3 grid, hipStream_t st, const Rep
   else replay_kernel<ZKGPU_W, false, false><<<grid, 256, 0, st>>>(a, fp);
 }
 
-void ZKGPU_FN(launch_r1cs_w)(bool assign, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp) {
-  if (assign) r1cs_row_kernel<ZKGPU_W, true><<<grid, 256, 0, st>>>(a, fp);
-  else r1cs_row_kernel<ZKGPU_W, false><<<grid, 256, 0, st>>>(a, fp);
+// classes: some row of the launch has a combination of class unit / small (args.hpp) -- the instantiation without them
+// is the one the rows of random coefficients run on, with the registers of that path alone
+void ZKGPU_FN(launch_r1cs_w)(bool assign, bool classes, dim3 grid, hipStream_t st, const R1csArgs& a, const FieldParams& fp) {
+  if (classes) {
+    if (assign) r1cs_row_kernel<ZKGPU_W, true, true><<<grid, 256, 0, st>>>(a, fp);
+    else r1cs_row_kernel<ZKGPU_W, false, true><<<grid, 256, 0, st>>>(a, fp);
+  } else {
+    if (assign) r1cs_row_kernel<ZKGPU_W, true, false><<<grid, 256, 0, st>>>(a, fp);
+    else r1cs_row_kernel<ZKGPU_W, false, false><<<grid, 256, 0, st>>>(a, fp);
+  }
 }
 
 void ZKGPU_FN(launch_dump_w)(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump,

@@ -38,11 +38,16 @@ R1cs r1cs_from_tape(const Tape& tape, const FieldHost& field, const Value& modul
 // device form of one row (device/r1cs_kernels.hpp)
 struct R1csRowDev {
   uint32_t first;   // first term
-  uint32_t counts;  // nA | nB << 8 | nC << 16 | flags << 24 (1 = B is the constant one)
+  uint32_t counts;  // nA | nB << 8 | nC << 16 | flags << 24: 1 = B is the constant one; bits 1-2 / 3-4 / 5-6: the
+                    // coefficient class of A / B / C
 };
 struct R1csTermDev {
   uint32_t slot;    // wire-table slot; 0xFFFFFFFF = the constant one
-  uint32_t coef;    // index into the Montgomery coefficient pool; 0xFFFFFFFF = coefficient 1
+  uint32_t coef;    // index into the Montgomery coefficient pool; 0xFFFFFFFF = coefficient 1.  In a combination of class
+                    // unit / small: the coefficient as a signed integer, sign << 31 | magnitude
 };
+// coefficient classes of a combination (== zkgpu::kR1csClass* of device/args.hpp, which says what each one costs)
+constexpr uint32_t kR1csClassFull = 0, kR1csClassUnit = 1, kR1csClassSmall = 2;
+constexpr uint32_t kR1csClassShiftA = 1, kR1csClassShiftB = 3, kR1csClassShiftC = 5;
 
 }  // namespace zki

@@ -275,6 +275,7 @@ struct StreamScheduler::Impl {
   void levelise();
   void fuse_and_pair();
   void place_strand_sources();
+  void prefetch_strand_inputs(size_t first_launch);
   std::vector<uint32_t> window_sources;   // constant / instance / witness / carry ops of the window (levelise)
   void order_by_level();
   void assign_slots();
@@ -1559,6 +1560,139 @@ void StreamScheduler::Impl::emit_launches() {
   }
 }
 
+// Strands, last step: what a strand reads out of the WIRE TABLE -- values made before it, e.g. the Switch weights of a loop
+// body, computed level-wide in front of the chain -- costs the entry that reads it a trip to L2 or HBM in the middle of the
+// dependency chain (measured: ~1,300 cycles per iteration of the chained structured relation, profiles/r04_strand_stamps.txt).
+// The strand has waves to spare, so such an operand is COPIED into LDS one to three levels earlier by an entry of its own
+// (kind copy, wire table -> kSlotInLds) on a spare wave of a level that has a product to hide it behind, and the reader is
+// pointed at the LDS value.  Entries only: tape handles, levels and the slot allocation are what they were; the copies use
+// LDS values above the strand's own, recycled once their reader has run.
+void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
+  if (!s.fused || !opt.strand_lds || !opt.strand_prefetch) return;
+  const uint32_t value_bytes = ((field.nwords + 3) / 4) * 64 * 16;
+  const uint32_t lds_cap = std::min<uint32_t>(1024, kStrandLdsBytes / std::max<uint32_t>(value_bytes, 1));
+  int64_t shift = 0;   // entries inserted in front of the launch being looked at
+  for (size_t li = first_launch; li < s.launches.size(); ++li) {
+    Launch& L = s.launches[li];
+    L.first = (uint32_t)(L.first + shift);
+    if (!L.sequential || L.strand_levels < 2) continue;
+    const uint32_t nl = L.strand_levels;
+    std::vector<uint32_t> lp(s.strand_level_ptr.begin() + L.level_ptr, s.strand_level_ptr.begin() + L.level_ptr + nl + 1);
+    std::vector<DevOp2> ent(s.ops2.begin() + L.first, s.ops2.begin() + L.first + L.count);
+    // slot operands of an entry (pointers into it), by kind
+    auto operands = [](DevOp2& d, uint32_t* out[5]) {
+      const uint32_t k = d.kind & 0xFF, ea = (d.kind >> 8) & 3, eb = (d.kind >> 10) & 3, pair = (d.kind >> 12) & 3;
+      int n = 0;
+      switch (k) {
+        case TK_ADD: case TK_MUL:
+          out[n++] = &d.a0;
+          if (ea) out[n++] = &d.a1;
+          out[n++] = &d.b0;
+          if (eb) out[n++] = &d.b1;
+          if (pair) out[n++] = &d.pad1;
+          break;
+        case TK_ADDC: case TK_MULC: case TK_COPY: case TK_NZ: case TK_NOT: case TK_ASSERT: out[n++] = &d.a0; break;
+        case TK_AND: case TK_XOR:
+          if (!(d.a0 & kOperandIsSource)) out[n++] = &d.a0;
+          if (!(d.b0 & kOperandIsSource)) out[n++] = &d.b0;
+          break;
+        default: break;
+      }
+      return n;
+    };
+    auto writes = [](const DevOp2& d, uint32_t out[2]) {
+      const uint32_t k = d.kind & 0xFF;
+      int n = 0;
+      if (k != TK_ASSERT && k != TK_NOP) out[n++] = d.dst;
+      if ((k == TK_ADD || k == TK_MUL) && ((d.kind >> 12) & 3)) out[n++] = d.pad0;
+      return n;
+    };
+    auto heavy_entry = [](const DevOp2& d) {
+      const uint32_t k = d.kind & 0xFF;
+      return k == TK_MUL || k == TK_MULC || k == TK_INSTANCE || k == TK_WITNESS || k == TK_CARRY ||
+             (k == TK_ADD && (((d.kind >> 8) & 3) == 2 || ((d.kind >> 10) & 3) == 2 || ((d.kind >> 12) & 3) == 2));
+    };
+    std::vector<uint8_t> written(std::max(n_slots, s.n_slots) + 1, 0);   // wire-table slots the strand itself writes: never prefetched
+    std::vector<uint32_t> count(nl, 0), heavy(nl, 0);
+    for (uint32_t q = 0; q < nl; ++q)
+      for (uint32_t k = lp[q]; k < lp[q + 1]; ++k) {
+        uint32_t w[2];
+        const int nw = writes(ent[k], w);
+        for (int j = 0; j < nw; ++j)
+          if (!(w[j] & kSlotInLds) && w[j] < written.size()) written[w[j]] = 1;
+        ++count[q];
+        heavy[q] += heavy_entry(ent[k]);
+      }
+    struct Ring {
+      uint32_t slot = kInf;       // wire-table slot it holds
+      uint32_t loaded = 0, needed = 0;   // level of the copy, level of its last reader so far
+    };
+    std::vector<Ring> ring;
+    const uint32_t ring_cap = L.lds_slots < lds_cap ? std::min<uint32_t>(32, lds_cap - L.lds_slots) : 0;
+    std::vector<std::vector<DevOp2>> extra(nl);
+    uint32_t ring_used = 0;
+    for (uint32_t q = 1; q < nl && ring_cap; ++q)
+      for (uint32_t k = lp[q]; k < lp[q + 1]; ++k) {
+        uint32_t* ops[5];
+        const int n = operands(ent[k], ops);
+        for (int j = 0; j < n; ++j) {
+          const uint32_t slot = *ops[j];
+          if ((slot & kSlotInLds) || slot >= written.size() || written[slot]) continue;
+          // in LDS already (an earlier reader of the strand brought it)?
+          uint32_t r = kInf;
+          for (uint32_t x = 0; x < ring.size(); ++x)
+            if (ring[x].slot == slot && ring[x].loaded < q) r = x;
+          if (r == kInf) {
+            // a level for the copy: the nearest of the three in front of the reader that has a product and a wave to spare
+            uint32_t t = kInf;
+            for (uint32_t back = 1; back <= 3 && back <= q; ++back)
+              if (heavy[q - back] && count[q - back] + extra[q - back].size() < 4) { t = q - back; break; }
+            if (t == kInf) continue;
+            // a ring value whose reader has run before level t (its LDS value may be overwritten at t)
+            for (uint32_t x = 0; x < ring.size() && r == kInf; ++x)
+              if (ring[x].needed < t) r = x;
+            if (r == kInf) {
+              if (ring.size() >= ring_cap) continue;
+              ring.emplace_back();
+              r = (uint32_t)ring.size() - 1;
+            }
+            ring[r].slot = slot;
+            ring[r].loaded = t;
+            ring[r].needed = q;
+            ring_used = std::max(ring_used, r + 1);
+            DevOp2 c{kSlotInLds | (L.lds_slots + r), TK_COPY, slot, 0, 0, 0, 0, 0};
+            extra[t].push_back(c);
+          }
+          ring[r].needed = std::max(ring[r].needed, q);
+          *ops[j] = kSlotInLds | (L.lds_slots + r);
+        }
+      }
+    size_t n_extra = 0;
+    for (const auto& e : extra) n_extra += e.size();
+    if (getenv("ZKI_SCHED_PROFILE"))
+      fprintf(stderr, "[schedule] strand of %u levels, %u entries, %u LDS values: %zu wire-table operands copied ahead (ring %u of %u)\n",
+              nl, L.count, L.lds_slots, n_extra, ring_used, ring_cap);
+    if (!n_extra) continue;   // (operands were only rewritten when a copy was made: nothing changed)
+    // the launch's entries with the copies behind the entries of their level, and its level bounds
+    std::vector<DevOp2> out;
+    out.reserve(ent.size() + n_extra);
+    std::vector<uint32_t> nlp(nl + 1, 0);
+    for (uint32_t q = 0; q < nl; ++q) {
+      out.insert(out.end(), ent.begin() + lp[q], ent.begin() + lp[q + 1]);
+      out.insert(out.end(), extra[q].begin(), extra[q].end());
+      nlp[q + 1] = (uint32_t)out.size();
+    }
+    s.ops2.erase(s.ops2.begin() + L.first, s.ops2.begin() + L.first + L.count);
+    s.ops2.insert(s.ops2.begin() + L.first, out.begin(), out.end());
+    std::copy(nlp.begin(), nlp.end(), s.strand_level_ptr.begin() + L.level_ptr);
+    L.count = (uint32_t)out.size();
+    L.ops_per_wave = std::max<uint32_t>(L.count, 1);
+    L.lds_slots += ring_used;
+    s.n_strand_prefetches += n_extra;
+    shift += (int64_t)n_extra;
+  }
+}
+
 StreamScheduler::StreamScheduler(const FieldHost& field, const ScheduleOptions& opt) : impl_(new Impl()) {
   Impl& m = *impl_;
   m.field = field;
@@ -1663,6 +1797,7 @@ WindowResult StreamScheduler::add_window(const TapeWindow& w) {
     lap();
     m.emit_entries();
     m.emit_launches();
+    m.prefetch_strand_inputs(r.first_launch);
     lap();
     m.s.n_levels = m.base + m.n_wlevels;
     if (profile)

@@ -71,6 +71,7 @@ struct ScheduleOptions {
   uint32_t threads = 0;             // worker threads for the per-level ordering (0 = min(8, hardware threads))
   bool bank_aware = true;           // GF(2): order the ops and number the slots so that one LDS instruction hits 32 banks
   bool strand_lds = true;           // strands keep the values that never leave them in LDS (kSlotInLds)
+  bool strand_prefetch = true;      // ... and copy what they read out of the wire table into LDS a few levels ahead (needs strand_lds)
 };
 
 struct Schedule {
@@ -81,6 +82,7 @@ struct Schedule {
   uint64_t n_copies_elided = 0;
   uint64_t n_ladders = 0;           // exponent ladders replaced by one entry each
   uint64_t n_paired = 0;            // producers evaluated inside a pair entry (counted in n_absorbed too)
+  uint64_t n_strand_prefetches = 0; // copy entries that bring a strand's wire-table operands into LDS ahead of their reader
   std::vector<Launch> launches;
   std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)
   std::vector<uint32_t> level_of;   // per tape op
@@ -119,6 +121,7 @@ struct Schedule {
     c.n_copies_elided = n_copies_elided;
     c.n_ladders = n_ladders;
     c.n_paired = n_paired;
+    c.n_strand_prefetches = n_strand_prefetches;
     c.launches = launches;
     c.strict_instance = strict_instance;
     c.strict_witness = strict_witness;

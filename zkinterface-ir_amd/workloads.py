@@ -381,8 +381,11 @@ class R1csSynthetic:
     make every 97th lane unsatisfied).  Rows are emitted sorted by dependency level so that the
     witness generation of one level is a single independent launch."""
 
-    def __init__(self, M=1 << 20, n_base=4096, n_coefs=1 << 16, seed=0xC5, p=BN254_R):
-        self.M, self.n_base, self.p, self.seed = M, n_base, p, seed
+    def __init__(self, M=1 << 20, n_base=4096, n_coefs=1 << 16, seed=0xC5, p=BN254_R, coef_kind='random'):
+        """coef_kind: 'random' -- coefficients are random field elements (BASELINE configs[4]); 'small' -- what
+        FromR1CSConverter expansions and hand-written systems mostly hold (from_r1cs.rs:110-125): 1 (35 %), -1 (25 %) and
+        signed integers of up to 16 bits (40 %), same rows and variables"""
+        self.M, self.n_base, self.p, self.seed, self.coef_kind = M, n_base, p, seed, coef_kind
         self.width = 8 * ((p.bit_length() + 63) // 64)
         self.mod_le = int_to_le(p)
         self.n_witness = n_base + 1  # + the expected-output variable E
@@ -393,6 +396,16 @@ class R1csSynthetic:
         picks = np.where(picks >= n_base, picks + 1, picks)              # skip E's id
         self.coef_idx = rng.integers(0, n_coefs, size=(M, 6), dtype=np.int64)
         self.coefs = random_field_elements(seed + 17, (n_coefs,), p)[:, :self.width]
+        if coef_kind == 'small':
+            crng = np.random.default_rng(seed + 18)
+            u = crng.random(n_coefs)
+            mag = crng.integers(2, 1 << 16, size=n_coefs)
+            sign = crng.integers(0, 2, size=n_coefs)
+            vals = [1 if u[i] < 0.35 else (p - 1) if u[i] < 0.60 else (int(mag[i]) % p if sign[i] else (p - int(mag[i])) % p) or 1
+                    for i in range(n_coefs)]
+            self.coefs = np.frombuffer(b''.join(v.to_bytes(self.width, 'little') for v in vals), dtype=np.uint8).reshape(n_coefs, self.width).copy()
+        elif coef_kind != 'random':
+            raise ValueError('coef_kind: random or small')
         # dependency levels (sequential by construction: row i only sees earlier z)
         level = [0] * (n_base + 1 + M)
         pl = picks.tolist()
@@ -445,6 +458,8 @@ class R1csSynthetic:
 
     def witnesses(self, batch, lane_offset=0):
         w = random_field_elements(self.seed + 0x2000 + lane_offset * self.n_witness * 4, (batch, self.n_witness), self.p)
+        if self.width > w.shape[-1]:   # (a field wider than the 256 bits the generator makes: values below 2^256)
+            w = np.concatenate([w, np.zeros(w.shape[:-1] + (self.width - w.shape[-1],), dtype=np.uint8)], axis=-1)
         w = np.ascontiguousarray(w[..., :self.width])
         w[:, self.n_base] = 0
         return w
