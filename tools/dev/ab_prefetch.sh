@@ -1,10 +1,10 @@
 mkdir -p gpurun_out/r04
-timeout -k 10 600 python -m pytest tests/test_strands.py tests/test_gpu_parity.py tests/test_field_segments.py tests/test_any_modulus.py -m gpu -x -q > gpurun_out/r04/pytest_gpu_8.log 2>&1; echo pytest rc $?; tail -3 gpurun_out/r04/pytest_gpu_8.log
-for pf in 1 0 1 0; do ZKI_STRAND_PREFETCH=$pf python bench.py --workload structured --chained --no-cpu-baseline --no-first-verdict --steps 10 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('chained prefetch $pf ms_per_step', d['ms_per_step'], d['config']['satisfied'])"; done
+timeout -k 10 600 python -m pytest tests/test_strands.py tests/test_gpu_parity.py tests/test_field_segments.py tests/test_any_modulus.py -m gpu -x -q > gpurun_out/r04/pytest_gpu_10.log 2>&1; echo pytest rc $?; tail -3 gpurun_out/r04/pytest_gpu_10.log
+for pf in 1 1; do ZKI_STRAND_PREFETCH=$pf python bench.py --workload structured --chained --no-cpu-baseline --no-first-verdict --steps 10 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('chained prefetch $pf ms_per_step', d['ms_per_step'], d['config']['satisfied'])"; done
 (cd zkinterface-ir_amd && touch csrc/kernels_arith.hip && make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-result -DZKGPU_STRAND_STAMPS" 2>&1 | grep -v warning | head -5)
-for pf in 0 1; do
+for pf in 1; do
   ZKI_STRAND_PREFETCH=$pf ZKGPU_STRAND_STAMPS=/tmp/stamps$pf.bin python bench.py --workload structured --chained --no-cpu-baseline --no-first-verdict --steps 2 --warmup 1 > /dev/null 2>&1
-  echo "== strand_prefetch=$pf" >> gpurun_out/r04/strand_stamps.txt
-  python tools/strand_stamps.py /tmp/stamps$pf.bin 40 >> gpurun_out/r04/strand_stamps.txt 2>&1
+  echo "== strand_prefetch=$pf" >> gpurun_out/r04/strand_stamps_fast.txt
+  python tools/strand_stamps.py /tmp/stamps$pf.bin 40 >> gpurun_out/r04/strand_stamps_fast.txt 2>&1
 done
-tail -4 gpurun_out/r04/strand_stamps.txt
+tail -4 gpurun_out/r04/strand_stamps_fast.txt

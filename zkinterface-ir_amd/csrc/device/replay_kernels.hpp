@@ -422,6 +422,32 @@ __device__ __forceinline__ void fused_addmul(const TapeOp2& op, uint4* __restric
   slot_store<N, LDS>(T, dst_slot, lane, r);
 }
 
+// The chain of a strand: an Add/Mul entry (not a pair) whose operands and result all live in LDS.  fused_addmul reaches
+// every operand through a branch of its own (LDS or wire table), and hipcc closes each with a wait: the four loads of an
+// entry then run one after the other, ~100 cycles each for a wave that has its SIMD to itself.  Here all four are issued
+// together (an operand the entry does not have reads its neighbour again) and waited for once.
+template <int N>
+__device__ __forceinline__ bool strand_entry_in_lds(const TapeOp2& op) {
+  const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3, pair = (op.kind >> 12) & 3;
+  const u32 all = op.dst & op.a0 & op.b0 & (ea ? op.a1 : ~0u) & (eb ? op.b1 : ~0u);
+  return (kind == OP_ADD || kind == OP_MUL) && pair == 0 && (all & kSlotInLds) != 0;
+}
+template <int N>
+__device__ __forceinline__ void strand_addmul_lds(const TapeOp2& op, const FieldParams& fp, u32 lane) {
+  const u32 kind = op.kind & 0xFF, ea = (op.kind >> 8) & 3, eb = (op.kind >> 10) & 3;
+  Fp<N> x0 = lds_value_load<N>(op.a0 & ~kSlotInLds, lane);
+  const Fp<N> x1 = lds_value_load<N>((ea ? op.a1 : op.a0) & ~kSlotInLds, lane);
+  Fp<N> y0 = lds_value_load<N>(op.b0 & ~kSlotInLds, lane);
+  const Fp<N> y1 = lds_value_load<N>((eb ? op.b1 : op.b0) & ~kSlotInLds, lane);
+  u32 pv[N];
+  if constexpr (N <= 12) p_words_resident<N>(pv, fp);
+  else p_words<N>(pv, fp);
+  if (ea) x0 = ea == 1 ? fp_add<N>(x0, x1, fp, pv) : fp_mul<N>(x0, x1, fp, pv);
+  if (eb) y0 = eb == 1 ? fp_add<N>(y0, y1, fp, pv) : fp_mul<N>(y0, y1, fp, pv);
+  const Fp<N> r = kind == OP_ADD ? fp_add<N>(x0, y0, fp, pv) : fp_mul<N>(x0, y0, fp, pv);
+  lds_value_store<N>(op.dst & ~kSlotInLds, lane, r);
+}
+
 // one entry of any kind (the body of the kFusedMisc / kFusedAll instantiations)
 template <int N, int CLS, bool LDS = false>
 __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict__ T, const ReplayArgs2& args, u32 lane_g,
@@ -522,7 +548,8 @@ __global__ __launch_bounds__(256) void replay_strand_kernel(const ReplayArgs2 ar
         t1 = __builtin_readcyclecounter();
       }
 #endif
-      fused_entry<N, CLS, true>(op, T, args, lane_g, lane_valid, fp);
+      if (strand_entry_in_lds<N>(op)) strand_addmul_lds<N>(op, fp, lane);
+      else fused_entry<N, CLS, true>(op, T, args, lane_g, lane_valid, fp);
     }
 #ifdef ZKGPU_STRAND_STAMPS
     if (stamp) {
