@@ -133,6 +133,12 @@ int zkgpu_schedule_info(const zkgpu_session* s, uint64_t out[8]);
  * Any pointer may be NULL. */
 int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launches4, uint32_t* const_words,
                         uint32_t* slot_of);
+/* A sequential launch of the fused program is a STRAND: one workgroup per 64 witnesses walks its levels with a barrier
+ * between them, entry i of a level going to wave (i - first entry of the level) % 4, a wave running its entries in order.
+ * out (cap words; NULL to ask): the level bounds of launch `launch` as entry offsets relative to its first entry (levels + 1
+ * numbers), then one word with the LDS-resident values of the strand (slots 0x40000000 | k, k below it).  Returns the
+ * number of words (0: not a strand).  For static checks of the schedule (tests/test_strands.py). */
+size_t zkgpu_schedule_strand_levels(const zkgpu_session* s, uint32_t launch, uint32_t* out, size_t cap);
 
 /* GF(2) relations: the program of the LDS-resident kernel (csrc/device/lds_layout.hpp) for this schedule, with blocks
  * of `block_rows` rows (4, 6, 8, 9, 10, 12; 0 = the size the engine would pick).  Host work only (no GPU is touched):

@@ -43,3 +43,10 @@ def batch_arrays(inst_rows, wit_rows, width):
     inst = b''.join(le_values(r, width) for r in inst_rows)
     wit = b''.join(le_values(r, width) for r in wit_rows)
     return inst, wit
+
+
+def working_entries(ev):
+    """entries of the device program that do something: a strand pads with no-ops to keep the entries of a dependency chain
+    on one wave (csrc/schedule.cpp, levels that need no barrier between them), and `device_ops` counts those too"""
+    ops = ev.schedule_dump()[0]
+    return int(((ops[:, 1] & 0xFF) != 0).sum())

@@ -210,3 +210,51 @@ def from_device_form(v, p, words_per_const, canonical=None):
     if (p == 2 and not canonical) or v is None or canonical:
         return v
     return v * pow(1 << (32 * words_per_const), -1, p) % p
+
+
+# ---- strands: a static check of what the kernel's execution model needs ------------------------------------------------
+def strand_hazards(ops, first, level_ptr):
+    """A strand (replay_strand_kernel) runs the entries of a level on four waves at once -- entry i of the level on wave
+    i % 4, a wave its own entries in order -- with a barrier between levels.  `simulate` runs them one after the other, so
+    its result is the kernel's only if no entry of a level touches what an entry of ANOTHER wave of that level writes.
+    Returns the list of violations (empty: the sequential run is what the GPU computes)."""
+    K = OP
+    one_operand = (K['addc'], K['mulc'], K['copy'], K['nz'], K['not'], K['assert'])
+
+    def reads(o):
+        kind, ea, eb, pair = int(o[1]) & 0xFF, (int(o[1]) >> 8) & 3, (int(o[1]) >> 10) & 3, (int(o[1]) >> 12) & 3
+        if kind in (K['add'], K['mul']):
+            r = [int(o[2]), int(o[4])]
+            if ea:
+                r.append(int(o[3]))
+            if eb:
+                r.append(int(o[5]))
+            if pair:
+                r.append(int(o[7]))
+            return r
+        if kind in one_operand:
+            return [int(o[2])]
+        if kind in (K['and'], K['xor']):
+            return [int(x) for x in (o[2], o[4]) if not int(x) & 0x80000000]
+        return []
+
+    def writes(o):
+        kind, pair = int(o[1]) & 0xFF, (int(o[1]) >> 12) & 3
+        if kind in (K['assert'], 0):
+            return []
+        return [int(o[0])] + ([int(o[6])] if pair and kind in (K['add'], K['mul']) else [])
+
+    bad = []
+    for l in range(len(level_ptr) - 1):
+        b, e = first + int(level_ptr[l]), first + int(level_ptr[l + 1])
+        writer = {}
+        for i in range(b, e):
+            for w in writes(ops[i]):
+                if w in writer and writer[w] != (i - b) % 4:
+                    bad.append('level %d: entries of waves %d and %d both write slot %#x' % (l, writer[w], (i - b) % 4, w))
+                writer[w] = (i - b) % 4
+        for i in range(b, e):
+            for r in reads(ops[i]):
+                if r in writer and writer[r] != (i - b) % 4:
+                    bad.append('level %d: wave %d reads slot %#x that wave %d writes' % (l, (i - b) % 4, r, writer[r]))
+    return bad

@@ -201,7 +201,8 @@ def test_switch_ladder_becomes_one_entry_only_over_a_prime_field():
             assert ev.host_violations() == []
             n_tape = ev.n_value_ops
             ev.finalize(retain_all=retain)
-            sizes[(p, name)] = (ev.schedule_info()['device_ops'], ev.schedule_info()['levels'], n_tape)
+            # (entries that do something: a strand pads with no-ops to keep a chain on one wave, csrc/schedule.cpp)
+            sizes[(p, name)] = (int(((ev.schedule_dump()[0][:, 1] & 0xFF) != 0).sum()), ev.schedule_info()['levels'], n_tape)
     big = circuits.BN254_R
     assert sizes[(big, 'on')][2] == sizes[(big, 'off')][2] == 965          # the recording is the reference's trace
     assert sizes[(big, 'on')][0] < 120 and sizes[(big, 'on')][1] < 60
@@ -238,7 +239,8 @@ def test_trait_level_ladder_hint():
         ev.finalize()
         return ev
     plain, hinted = record(False), record(True)
-    assert plain.schedule_info()['device_ops'] > 200 and hinted.schedule_info()['device_ops'] < 12
+    from helpers import working_entries
+    assert working_entries(plain) > 200 and working_entries(hinted) < 12
     for ev in (plain, hinted):
         ops, launches, consts, _ = ev.schedule_dump()
         info = ev.schedule_info()
@@ -280,7 +282,8 @@ def test_bogus_and_overlapping_ladder_hints_leave_the_schedule_alone():
         weight = ev.backend_add_constant(ev.backend_mul_constant(acc, minus_one), bytes([1]))
         ev.backend_assert_zero(ev.backend_add_constant(weight, minus_one), 0)
         ev.finalize()
-        return ev.schedule_info()['device_ops']
+        from helpers import working_entries
+        return working_entries(ev)
     plain = record('none')
     assert record('good') < 12 < plain
     for mode in ('wrong_base', 'short_range', 'overlap', 'boolean'):

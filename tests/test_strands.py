@@ -47,6 +47,44 @@ def test_chained_relation_schedules_into_strands_and_computes_the_oracle_verdict
         assert (ref.violations == []) == (lane % 2 == 1)
 
 
+def _strands_of(ev):
+    ops, launches, _, _ = ev.schedule_dump()
+    out = []
+    for k, l in enumerate(launches):
+        sl = ev.strand_levels(k)
+        if sl is not None:
+            out.append((ops, int(l[0]), int(l[1]), sl[0], sl[1]))
+    return out
+
+
+@pytest.mark.parametrize('strand_width,prefetch', [(3, '1'), (17, '1'), (64, '1'), (64, '0')])
+def test_no_entry_of_a_level_touches_what_another_wave_of_it_writes(strand_width, prefetch):
+    """the strand kernel runs a level's entries on four waves at once; program_sim runs them in turn: the static rule that
+    makes the two the same (program_sim.strand_hazards), on the chained relation and on independent iterations, with the
+    copies that bring wire-table operands into LDS ahead of their readers (option strand_prefetch) and without"""
+    seen = 0
+    for wl in (workloads.StructuredArith(N=40, chained=True), workloads.StructuredArith(N=12, chained=False)):
+        ev = zk.Evaluator()
+        ev.set_option('strand_width', str(strand_width))
+        ev.set_option('strand_prefetch', prefetch)
+        ev.declare_inputs(wl.n_instance, wl.n_witness)
+        for m in wl.relation_messages():
+            ev.ingest_message(m)
+        ev.finalize()
+        copies_total = 0
+        for ops, first, count, level_ptr, lds_slots in _strands_of(ev):
+            assert int(level_ptr[0]) == 0 and int(level_ptr[-1]) == count and all(np.diff(level_ptr.astype(np.int64)) > 0)
+            lds = [int(x) & 0xFFFF for x in ops[first:first + count, 0] if int(x) & 0x40000000]
+            assert all(k < lds_slots for k in lds)
+            assert program_sim.strand_hazards(ops, first, level_ptr) == []
+            copies_in = sum(1 for o in ops[first:first + count] if int(o[1]) & 0xFF == 5 and int(o[0]) & 0x40000000 and not int(o[2]) & 0x40000000)
+            copies_total += copies_in
+            seen += 1
+        if wl.chained and strand_width >= 17:    # (the Switch weights of the chain are made level-wide in front of it)
+            assert (copies_total > 0) == (prefetch == '1'), copies_total
+    assert seen >= 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('strand_width,stream', [(17, '0'), (3, '0'), (64, '0'), (17, '48')])
 def test_chained_relation_on_gpu(strand_width, stream):

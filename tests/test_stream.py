@@ -106,10 +106,12 @@ def test_switch_ladders_are_never_cut_and_still_become_one_entry():
         ev.declare_inputs(3, 4)
         ev.ingest_message(rel)
         ev.finalize()
-        sizes[window] = ev.schedule_info()['device_ops']
+        sizes[window] = int(((ev.schedule_dump()[0][:, 1] & 0xFF) != 0).sum())    # entries that do something
         if window:
             assert ev.stream_info()['windows'] >= 3
-    assert sizes[100] < 200 and sizes[0] < 120       # 965 recorded calls either way
+    # 965 recorded calls either way (a strand adds entries for itself: copies of wire-table operands into LDS ahead of
+    # their readers; the no-ops that keep a chain on one wave are not counted)
+    assert sizes[100] < 200 and sizes[0] < 120
 
 
 def test_trait_level_recording_with_drops_streams_too():
@@ -143,9 +145,10 @@ def test_trait_level_recording_with_drops_streams_too():
         assert (ff is None) == ((want + p - 5) % p == 0)
         _, ff, _ = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], p, [], [0, 5])
         assert ff is None                      # x = 0: acc stays 5, 5 + (p - 5) = 0
+        info['working_entries'] = int(((ops[:, 1] & 0xFF) != 0).sum())    # (without the no-ops that keep a chain on one wave)
         results[drops] = info
     assert results[True]['slots'] < 20 < results[False]['slots']
-    assert results[True]['device_ops'] < results[False]['device_ops']
+    assert results[True]['working_entries'] < results[False]['working_entries']
 
 
 # ---------------------------------------------------------------- GPU tier

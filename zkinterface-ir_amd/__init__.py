@@ -122,6 +122,7 @@ def lib():
         'zkgpu_table_bytes': (u64, [vp]),
         'zkgpu_r1cs_from_tape': (ci, [vp, ci]),
         'zkgpu_r1cs_info': (ci, [vp, u64p]),
+        'zkgpu_schedule_strand_levels': (ctypes.c_size_t, [vp, ctypes.c_uint32, vp, ctypes.c_size_t]),
         'zkgpu_r1cs_class_counts': (ci, [vp, u64p]),
         'zkgpu_r1cs_export': (ci, [vp, vp, vp, vp, vp]),
         'zkgpu_r1cs_coef_bytes': (sz, [vp, u32, ctypes.c_char_p, sz]),
@@ -372,6 +373,17 @@ class Evaluator:
         keys = ['levels', 'launches', 'slots', 'max_width', 'sequential_launches', 'device_ops', 'const_words',
                 'words_per_const']
         return dict(zip(keys, list(out)))
+
+    def strand_levels(self, launch):
+        """(level bounds relative to the launch's first entry, LDS-resident values) of a strand, None for any other launch
+        (include/zkgpu.h zkgpu_schedule_strand_levels)"""
+        import numpy as np
+        n = self.L.zkgpu_schedule_strand_levels(self.h, launch, None, 0)
+        if not n:
+            return None
+        out = np.zeros(n, dtype=np.uint32)
+        self.L.zkgpu_schedule_strand_levels(self.h, launch, out.ctypes.data, n)
+        return out[:-1].copy(), int(out[-1])
 
     def schedule_dump(self):
         import numpy as np

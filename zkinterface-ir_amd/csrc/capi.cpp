@@ -116,7 +116,7 @@ struct zkgpu_session {
   uint32_t stream_window = 0;        // option "stream": tape entries per window, 0 = schedule everything at finalize
   uint32_t sched_threads = 0;
   bool bank_aware = true;
-  bool strand_lds = true, strand_prefetch = true;
+  bool strand_lds = true, strand_prefetch = true, strand_merge = true;
   uint32_t bool_narrow_width = 0;   // 0 = the scheduler's default
   uint32_t strand_width = 0;   // 0 = the scheduler's default
   std::unique_ptr<StreamState> stream;
@@ -220,6 +220,7 @@ ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
   opt.bank_aware = s->bank_aware;
   opt.strand_lds = s->strand_lds;
   opt.strand_prefetch = s->strand_prefetch;
+  opt.strand_merge = s->strand_merge;
   if (s->bool_narrow_width) opt.bool_narrow_width = s->bool_narrow_width;
   if (s->strand_width) opt.strand_width = s->strand_width;
   return opt;
@@ -1432,6 +1433,20 @@ int zkgpu_schedule_dump(const zkgpu_session* s, uint32_t* ops4, uint32_t* launch
   return 0;
 }
 
+size_t zkgpu_schedule_strand_levels(const zkgpu_session* s, uint32_t launch, uint32_t* out, size_t cap) {
+  if (!s || !s->finalized) return 0;
+  const Schedule& sc = seg_sched(s, inspected(s));
+  if (!sc.fused || launch >= sc.launches.size()) return 0;
+  const Launch& L = sc.launches[launch];
+  if (!L.sequential || !L.strand_levels) return 0;
+  const size_t n = (size_t)L.strand_levels + 2;
+  if (out && cap >= n) {
+    for (uint32_t k = 0; k <= L.strand_levels; ++k) out[k] = sc.strand_level_ptr[L.level_ptr + k];
+    out[L.strand_levels + 1] = L.lds_slots;
+  }
+  return n;
+}
+
 int zkgpu_set_inputs(zkgpu_session* s, const uint8_t* instances, const uint8_t* witnesses, uint32_t batch) {
   return guarded(s, [&] {
     need_engine(s);
@@ -1567,7 +1582,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     // the scheduler of a streamed ingest took its options when the first window was cut: a later change would be ignored
     // silently by the windows already scheduled -- refuse it instead
     if (s->stream && (k == "fuse" || k == "pair" || k == "fermat" || k == "propagate_copies" || k == "sort_by_operand" ||
-                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "strand_prefetch" || k == "bool_narrow_width" || k == "schedule_threads"))
+                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "strand_prefetch" || k == "strand_merge" || k == "bool_narrow_width" || k == "schedule_threads"))
       throw std::runtime_error(k + ": the streamed schedule has started (option \"stream\"); set scheduling options before the first Relation message");
     if (k == "bool_path") {
       if (v == "auto") s->bool_path = 0;
@@ -1616,6 +1631,8 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->strand_lds = v != "0";
     } else if (k == "strand_prefetch") {
       s->strand_prefetch = v != "0";
+    } else if (k == "strand_merge") {
+      s->strand_merge = v != "0";
     } else if (k == "r1cs_coef_classes") {
       if (s->r1cs_ready) throw std::runtime_error("r1cs_coef_classes: set it before the rows are made (zkgpu_r1cs_from_tape / zkgpu_r1cs_load_csr)");
       s->r1cs_coef_classes = v != "0";

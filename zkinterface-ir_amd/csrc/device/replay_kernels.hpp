@@ -381,6 +381,28 @@ __device__ __forceinline__ TapeOp2 load_entry_scalar(const TapeOp2* ops, u32 i) 
   return op;
 }
 
+// ... without the two words only a pair entry has (fetched ahead of their use by the strand kernel, which keeps an entry
+// in SGPRs while another one runs), and those two words
+__device__ __forceinline__ TapeOp2 load_entry_scalar6(const TapeOp2* ops, u32 i) {
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* q = (cu32*)(unsigned long long)(ops + __builtin_amdgcn_readfirstlane(i));
+  TapeOp2 op;
+  op.dst = q[0];
+  op.kind = q[1];
+  op.a0 = q[2];
+  op.a1 = q[3];
+  op.b0 = q[4];
+  op.b1 = q[5];
+  op.pad0 = op.pad1 = 0;
+  return op;
+}
+__device__ __forceinline__ void load_entry_pair_words(const TapeOp2* ops, u32 i, TapeOp2& op) {
+  typedef const u32 __attribute__((address_space(4))) cu32;
+  cu32* q = (cu32*)(unsigned long long)(ops + __builtin_amdgcn_readfirstlane(i));
+  op.pad0 = q[6];
+  op.pad1 = q[7];
+}
+
 // Replay of the fused schedule: an Add/Mul operand may be `add(a0,a1)` / `mul(a0,a1)` evaluated in
 // registers -- the absorbed producer's value never goes to the wire table (one 32-B store and one
 // 32-B load less per fused pair).  All gathers of an op are issued before the arithmetic.
@@ -529,24 +551,30 @@ __global__ __launch_bounds__(256) void replay_strand_kernel(const ReplayArgs2 ar
   uint4* __restrict__ T = args.table + (size_t)lb * args.n_slots * Layout<N>::kRecord + lane;
   typedef const u32 __attribute__((address_space(4))) cu32;
   cu32* lp = (cu32*)(unsigned long long)level_ptr;
-  u32 b = lp[0];
+  u32 b = lp[0], e = lp[1];
 #ifdef ZKGPU_STRAND_STAMPS   // developer build (tools/strand_stamps.py): where the time of a level goes
   unsigned long long* const stamps = ((InputAuxS*)(unsigned long long)args.aux)->stamps;
   const bool stamp = stamps != nullptr && blockIdx.x == 0 && n_levels >= kStampLevels;
 #endif
+  // The entry a wave runs next -- its next one of this level, or its first of the next level -- is fetched (scalar loads)
+  // while the current one runs or the barrier is waited for: a level of a dependency chain is one entry long, and the
+  // ~150-250 cycles of an entry fetch were paid once per level in front of it.
+  TapeOp2 next_op = {};
+  if (b + wave < e) next_op = load_entry_scalar6(args.ops, b + wave);
   for (u32 l = 0; l < n_levels; ++l) {
-    const u32 e = lp[l + 1];
+    const u32 e2 = l + 1 < n_levels ? lp[l + 2] : e;   // the end of the next level (none: nothing to fetch there)
 #ifdef ZKGPU_STRAND_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0;
     if (stamp) t0 = t1 = t2 = __builtin_readcyclecounter();
 #endif
+    if (b + wave >= e && e + wave < e2) next_op = load_entry_scalar6(args.ops, e + wave);   // idle in this level
     for (u32 i = b + wave; i < e; i += 4) {
-      const TapeOp2 op = load_entry_scalar(args.ops, i);
+      TapeOp2 op = next_op;
+      if ((op.kind >> 12) & 3) load_entry_pair_words(args.ops, i, op);   // (a pair entry: rare in a strand)
+      const u32 j = i + 4 < e ? i + 4 : e + wave;
+      if (i + 4 < e || j < e2) next_op = load_entry_scalar6(args.ops, j);
 #ifdef ZKGPU_STRAND_STAMPS
-      if (stamp) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        t1 = __builtin_readcyclecounter();
-      }
+      if (stamp) t1 = __builtin_readcyclecounter();
 #endif
       if (strand_entry_in_lds<N>(op)) strand_addmul_lds<N>(op, fp, lane);
       else fused_entry<N, CLS, true>(op, T, args, lane_g, lane_valid, fp);
@@ -558,6 +586,7 @@ __global__ __launch_bounds__(256) void replay_strand_kernel(const ReplayArgs2 ar
     }
 #endif
     b = e;
+    e = e2;
     __syncthreads();   // every wave of the workgroup reaches it once per level (the level bounds are wave-uniform)
 #ifdef ZKGPU_STRAND_STAMPS
     if (stamp && l < kStampLevels && lane == 0) {

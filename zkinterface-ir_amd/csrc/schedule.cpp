@@ -1568,7 +1568,7 @@ void StreamScheduler::Impl::emit_launches() {
 // pointed at the LDS value.  Entries only: tape handles, levels and the slot allocation are what they were; the copies use
 // LDS values above the strand's own, recycled once their reader has run.
 void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
-  if (!s.fused || !opt.strand_lds || !opt.strand_prefetch) return;
+  if (!s.fused || !opt.strand_lds || !(opt.strand_prefetch || opt.strand_merge)) return;
   const uint32_t value_bytes = ((field.nwords + 3) / 4) * 64 * 16;
   const uint32_t lds_cap = std::min<uint32_t>(1024, kStrandLdsBytes / std::max<uint32_t>(value_bytes, 1));
   int64_t shift = 0;   // entries inserted in front of the launch being looked at
@@ -1628,7 +1628,7 @@ void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
       uint32_t loaded = 0, needed = 0;   // level of the copy, level of its last reader so far
     };
     std::vector<Ring> ring;
-    const uint32_t ring_cap = L.lds_slots < lds_cap ? std::min<uint32_t>(32, lds_cap - L.lds_slots) : 0;
+    const uint32_t ring_cap = opt.strand_prefetch && L.lds_slots < lds_cap ? std::min<uint32_t>(32, lds_cap - L.lds_slots) : 0;
     std::vector<std::vector<DevOp2>> extra(nl);
     uint32_t ring_used = 0;
     for (uint32_t q = 1; q < nl && ring_cap; ++q)
@@ -1672,23 +1672,98 @@ void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
     if (getenv("ZKI_SCHED_PROFILE"))
       fprintf(stderr, "[schedule] strand of %u levels, %u entries, %u LDS values: %zu wire-table operands copied ahead (ring %u of %u)\n",
               nl, L.count, L.lds_slots, n_extra, ring_used, ring_cap);
-    if (!n_extra) continue;   // (operands were only rewritten when a copy was made: nothing changed)
     // the launch's entries with the copies behind the entries of their level, and its level bounds
     std::vector<DevOp2> out;
     out.reserve(ent.size() + n_extra);
-    std::vector<uint32_t> nlp(nl + 1, 0);
+    std::vector<uint32_t> nlp(1, 0);
     for (uint32_t q = 0; q < nl; ++q) {
       out.insert(out.end(), ent.begin() + lp[q], ent.begin() + lp[q + 1]);
       out.insert(out.end(), extra[q].begin(), extra[q].end());
-      nlp[q + 1] = (uint32_t)out.size();
+      nlp.push_back((uint32_t)out.size());
     }
+    // Levels that need no barrier between them.  Entry i of a level runs on wave i % 4, a wave its entries in order, and
+    // a wave's LDS accesses happen in order: level B can join the level A in front of it (one barrier and one wait for the
+    // program entry less per level joined -- ~400 of the ~1,300 cycles a level of the chained structured relation costs
+    // beyond its arithmetic) when (i) no entry of B touches what A writes or writes what A reads, or (ii) ONE entry of B
+    // does, only entries of A that run on wave 0, and only through LDS values: that entry then follows them on wave 0
+    // (the next position that is a multiple of 4, the gap filled with B's other entries or with no-ops), the others run
+    // beside them as they would have.  A chain of single entries becomes one level that wave 0 walks alone.
+    size_t n_merged = 0, n_nops = 0;
+    if (opt.strand_merge && nlp.size() > 2) {
+      constexpr size_t kMaxJoined = 64;   // entries of a joined level
+      auto in = [](const std::vector<uint32_t>& v, uint32_t x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+      std::vector<DevOp2> merged;
+      std::vector<uint32_t> mlp(1, 0);
+      merged.reserve(out.size() + 16);
+      std::vector<DevOp2> cur(out.begin() + nlp[0], out.begin() + nlp[1]);
+      const DevOp2 nop{0, TK_NOP, 0, 0, 0, 0, 0, 0};
+      for (size_t q = 1; q + 1 < nlp.size(); ++q) {
+        std::vector<DevOp2> B(out.begin() + nlp[q], out.begin() + nlp[q + 1]);
+        // what the entries of cur read and write, those of wave 0 and those of the other waves apart
+        std::vector<uint32_t> wr[2], rd[2];
+        for (size_t k = 0; k < cur.size(); ++k) {
+          uint32_t* ops[5];
+          const int n = operands(cur[k], ops);
+          for (int j = 0; j < n; ++j) rd[k % 4 != 0].push_back(*ops[j]);
+          uint32_t w[2];
+          const int nw = writes(cur[k], w);
+          for (int j = 0; j < nw; ++j) wr[k % 4 != 0].push_back(w[j]);
+        }
+        std::vector<size_t> dep;
+        bool joinable = cur.size() + B.size() + 3 <= kMaxJoined;
+        for (size_t k = 0; k < B.size() && joinable; ++k) {
+          bool hit = false;
+          uint32_t* ops[5];
+          const int n = operands(B[k], ops);
+          uint32_t w[2];
+          const int nw = writes(B[k], w);
+          for (int side = 0; side < 2; ++side) {
+            for (int j = 0; j < n; ++j)
+              if (in(wr[side], *ops[j])) { hit = true; joinable &= side == 0 && (*ops[j] & kSlotInLds); }
+            for (int j = 0; j < nw; ++j)
+              if (in(wr[side], w[j]) || in(rd[side], w[j])) { hit = true; joinable &= side == 0 && (w[j] & kSlotInLds); }
+          }
+          if (hit) dep.push_back(k);
+        }
+        joinable &= dep.size() <= 1;
+        if (joinable) {
+          size_t next = 0;
+          auto skip_dep = [&]() { while (!dep.empty() && next == dep[0]) ++next; };
+          if (!dep.empty()) {
+            for (skip_dep(); cur.size() % 4 != 0; skip_dep()) {
+              if (next < B.size()) cur.push_back(B[next++]);
+              else { cur.push_back(nop); ++n_nops; }
+            }
+            cur.push_back(B[dep[0]]);
+          }
+          for (skip_dep(); next < B.size(); skip_dep()) cur.push_back(B[next++]);
+          ++n_merged;
+        } else {
+          merged.insert(merged.end(), cur.begin(), cur.end());
+          mlp.push_back((uint32_t)merged.size());
+          cur.swap(B);
+        }
+      }
+      merged.insert(merged.end(), cur.begin(), cur.end());
+      mlp.push_back((uint32_t)merged.size());
+      if (n_merged) {
+        out.swap(merged);
+        nlp.swap(mlp);
+      }
+    }
+    if (getenv("ZKI_SCHED_PROFILE") && n_merged)
+      fprintf(stderr, "[schedule]   %zu of its levels joined the level in front of them (%zu no-op entries)\n", n_merged, n_nops);
+    if (!n_extra && !n_merged) continue;   // nothing changed
+    n_extra += n_nops;
     s.ops2.erase(s.ops2.begin() + L.first, s.ops2.begin() + L.first + L.count);
     s.ops2.insert(s.ops2.begin() + L.first, out.begin(), out.end());
     std::copy(nlp.begin(), nlp.end(), s.strand_level_ptr.begin() + L.level_ptr);
     L.count = (uint32_t)out.size();
     L.ops_per_wave = std::max<uint32_t>(L.count, 1);
     L.lds_slots += ring_used;
-    s.n_strand_prefetches += n_extra;
+    L.strand_levels = (uint32_t)nlp.size() - 1;
+    s.n_strand_prefetches += n_extra - n_nops;
+    s.n_strand_levels_joined += n_merged;
     shift += (int64_t)n_extra;
   }
 }

@@ -72,6 +72,7 @@ struct ScheduleOptions {
   bool bank_aware = true;           // GF(2): order the ops and number the slots so that one LDS instruction hits 32 banks
   bool strand_lds = true;           // strands keep the values that never leave them in LDS (kSlotInLds)
   bool strand_prefetch = true;      // ... and copy what they read out of the wire table into LDS a few levels ahead (needs strand_lds)
+  bool strand_merge = true;         // ... and levels that need no barrier between them are one level (needs strand_lds)
 };
 
 struct Schedule {
@@ -82,6 +83,7 @@ struct Schedule {
   uint64_t n_copies_elided = 0;
   uint64_t n_ladders = 0;           // exponent ladders replaced by one entry each
   uint64_t n_paired = 0;            // producers evaluated inside a pair entry (counted in n_absorbed too)
+  uint64_t n_strand_levels_joined = 0;   // strand levels that run behind the level in front of them without a barrier
   uint64_t n_strand_prefetches = 0; // copy entries that bring a strand's wire-table operands into LDS ahead of their reader
   std::vector<Launch> launches;
   std::vector<uint32_t> slot_of;    // per tape op: slot of its value (kNoWire for asserts)
@@ -122,6 +124,7 @@ struct Schedule {
     c.n_ladders = n_ladders;
     c.n_paired = n_paired;
     c.n_strand_prefetches = n_strand_prefetches;
+    c.n_strand_levels_joined = n_strand_levels_joined;
     c.launches = launches;
     c.strict_instance = strict_instance;
     c.strict_witness = strict_witness;
