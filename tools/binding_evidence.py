@@ -154,6 +154,28 @@ def main():
                        'on this chip (v_mad_u64_u32 26.6 T lane-ops/s, add-with-carry 68 T, other 32-bit integer ops about 35 T) that '
                        'is valu_pipe_ms_per_step of VALU pipe per check; the gathers (7 x 32 B per row and witness) come from HBM',
             'sources': sources, 'collected': {'tag': tag, 'ms_per_step_at_collection': bench['ms_per_step']}})
+    # ---- C5 rows with small coefficients (bench.py --coefs small; the default run's secondary.c5_small)
+    bench = load(d, '%s_bench_c5_small.json' % tag)
+    sq = load(d, '%s_pmc_c5_small_sq_counters.json' % tag)
+    tr = load(d, 'pmc_traffic_c5_small.json')
+    if bench and tr:
+        cfg = bench['config']
+        rows, batch = cfg.get('rows', (1 << 20) + 1), cfg.get('batch_per_gpu', 1024)
+        c = {'memory_side': 'hbm', 'traffic_bytes_per_launch': tr['traffic_bytes_per_launch'], 'traffic_launches_per_step': 1,
+             'traffic_source': 'profiles/pmc_traffic_c5_small.json'}
+        sources = ['profiles/pmc_traffic_c5_small.json']
+        if sq:
+            waves = max(sq.get('SQ_WAVES', 1), 1)
+            c.update({'valu_insts_per_wave': sq['SQ_INSTS_VALU'] / waves,
+                      'waves_parked_on_memory_frac': sq.get('SQ_WAIT_ANY', 0) / max(sq.get('SQ_WAVE_CYCLES', 1), 1)})
+            sources.append('profiles/%s_pmc_c5_small_sq_counters.json' % tag)
+        dump(d, 'binding_c5_small.json', {
+            'workload': 'c5_small', 'kernel': 'r1cs_row_kernel<8, false, true>', 'binding': 'hbm',
+            'program': {'entries': rows, 'launches': 1, 'batch': batch}, 'constants': c,
+            'reading': 'the rows of C5 with coefficients 1 / -1 / 16-bit signed integers: additions, or N word products per term and '
+                       'two word rounds per combination, and one product per row -- what is left is the gathers (7 x 32 B per row '
+                       'and witness)',
+            'sources': sources, 'collected': {'tag': tag, 'ms_per_step_at_collection': bench['ms_per_step']}})
     print('written:', [f for f in sorted(os.listdir(d)) if f.startswith('binding_')])
 
 

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Collect the evidence `profiles/` holds for one round, on the GPU box, in three calls (each under gpurun's limit):
+# Collect the evidence `profiles/` holds for one round, on the GPU box, in four calls (each under gpurun's limit):
 #   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02 bench'   bench lines + rocprofv3 kernel stats
 #   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02 pmc_c2'  --pmc passes of the C2 kernel (+ the 4096-lane variant)
 #   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02 pmc_c45' --pmc passes of the GF(2) and R1CS kernels
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r02 pmc_c5s' --pmc passes of the R1CS kernel on small coefficients
 # Counters are collected in runs of their own with --kernel-trace only (FETCH_SIZE and WRITE_SIZE never share a pass);
 # tools/pmc_traffic.py applies the gfx950 corrections of MI355X_MICROARCH.md, tools/binding_evidence.py writes
 # profiles/binding_<workload>.json from the summaries.  Copy gpurun_out/<tag>/* into profiles/ afterwards.
@@ -101,6 +102,15 @@ elif [ $WHAT = pmc_c45 ]; then
   python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c5_f.csv /tmp/pmc_c5_w.csv $OUT/pmc_traffic_c5.json 1000 "$K5" c5 > /dev/null
   pmc c5_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- $C5
   python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c5_sq.csv "$K5" 1000 > $OUT/${TAG}_pmc_c5_sq_counters.json
+elif [ $WHAT = pmc_c5s ]; then
+  # the rows of C5 with small coefficients (bench.py --coefs small): the instantiation with the coefficient classes
+  C5S="--workload c5 --coefs small --steps 2 --warmup 1 --timed-steps-only"
+  K5S='r1cs_row_kernel<8, false, true>'
+  pmc c5s_f FETCH_SIZE -- $C5S
+  pmc c5s_w WRITE_SIZE -- $C5S
+  python3 $ROOT/tools/pmc_traffic.py /tmp/pmc_c5s_f.csv /tmp/pmc_c5s_w.csv $OUT/pmc_traffic_c5_small.json 1000 "$K5S" c5_small > /dev/null
+  pmc c5s_sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -- $C5S
+  python3 $ROOT/tools/pmc_summary.py /tmp/pmc_c5s_sq.csv "$K5S" 1000 > $OUT/${TAG}_pmc_c5_small_sq_counters.json
 fi
 echo "[collect] $WHAT done"
 ls $OUT
