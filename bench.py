@@ -372,9 +372,11 @@ def compact_line(full, detail_path):
         fv = cfg.get('relation_in_to_first_verdict')
         if fv:
             o['first_verdict_s'] = {k: v['total_s'] for k, v in fv.items()}
-        for k in ('break_even_batch', 'host_seconds'):
-            if cfg.get(k) is not None:
-                o[k] = cfg[k]
+        if cfg.get('break_even_batch') is not None:
+            o['break_even_batch'] = cfg['break_even_batch']
+        if cfg.get('host_seconds'):     # (the other stages are in the detail file)
+            keep = ('ingest_and_record_s', 'schedule_s', 'build_s', 'witness_generation_s')
+            o['host_seconds'] = {k: v for k, v in cfg['host_seconds'].items() if head or k in keep}
         o['counts'] = [cfg.get('satisfied'), cfg.get('failed')]
         for k in ('batch_8192',):
             if k in d:

@@ -187,6 +187,15 @@ size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size
  * "strand_width" = N (levels with fewer than N entries do not get a launch of their own: consecutive ones form a strand
  * that one workgroup per lane block walks with a barrier between levels -- the dependency chains of a structured
  * relation; default 17, 3 = only the levels round 1 walked with a single wave),
+ * "strand_lds" = 0|1 (a strand keeps the values that never leave it in the workgroup's LDS; default 1),
+ * "strand_prefetch" = 0|1 (what a strand reads out of the wire table is copied into LDS one to three levels ahead, by
+ * entries of their own on waves that idle; default 1), "strand_merge" = 0|1 (levels of a strand that need no barrier
+ * between them run as one level, a dependent entry behind its producer on the same wave; default 1) -- both need
+ * "strand_lds",
+ * "bool_narrow_width" = 3..2048 (GF(2), LDS-resident kernel: a level of fewer ops than this runs as packets of 64 entries
+ * walked by one wave, without a barrier or padded rows; default 257),
+ * "r1cs_coef_classes" = 0|1 (the row kernel's cheap paths for combinations whose coefficients are all 1 / -1 or small
+ * signed integers, see zkgpu_r1cs_class_counts; set before the rows are made; default 1),
  * "bank_aware" = 0|1 (GF(2): order the ops of a level and number the wire-table slots so that the 32 lanes one LDS
  * instruction serves read and write 32 different banks -- and / xor operands are swapped where that helps; default 1),
  * "graph" = 0|1 (replay the captured hipGraph of the whole launch sequence instead of issuing it launch by launch;
