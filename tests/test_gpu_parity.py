@@ -1032,3 +1032,82 @@ def test_inputs_handed_over_while_the_previous_batch_replays():
         ev.synchronize()
         for p in (pin_i, pin_bad, pin_good):
             hip.hipHostFree(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('p', [circuits.BN254_R, 2 ** 61 - 1, SECP256K1_P, 101])
+def test_r1cs_small_coefficient_class_at_its_bounds(p):
+    """the small-coefficient path of the row kernel sums |c| * v as an integer of N + 2 words: 255 terms of magnitude
+    2^31 - 1 on values p - 1 is the largest it can meet (device/r1cs_kernels.hpp r1cs_lincomb_small); all signs; products
+    of two such sums; a full-class combination beside a small one (the scales of the two sides of a check differ);
+    assignment (the scale undone by a product) and check, against Python integers"""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    width = 8 * ((p.bit_length() + 63) // 64)
+    n_base, batch = 260, 70
+    big = (2 ** 31 - 1) % p or 1
+    pool = [1, big, (p - big) % p or 1, p - 1, 2, (p // 3) | 1 if p > 2 ** 40 else 5]
+    ONE, BIG, MBIG, MONE, TWO, WIDE = range(6)
+    cb = np.frombuffer(b''.join(v.to_bytes(width, 'little') for v in pool), dtype=np.uint8).reshape(len(pool), width)
+    Z = n_base          # extra variables z0.. start here
+    rows = [
+        ([(k, BIG) for k in range(255)], [(2 ** 64 - 1, ONE)], [(Z + 0, ONE)]),                          # z0 = sum big * v
+        ([(k, MBIG) for k in range(255)], [(k, BIG) for k in range(200)], [(Z + 1, ONE)]),                # z1 = (-sum) * (sum)
+        ([(k, MONE if k % 2 else ONE) for k in range(40)], [(7, TWO), (8, MBIG)], [(Z + 2, ONE)]),        # unit x small
+        ([(3, WIDE), (4, BIG)], [(5, MBIG), (6, TWO), (9, ONE)], [(Z + 3, ONE)]),                         # full x small
+    ]
+    n_assign = len(rows)
+    # rows that only the check sees: true by construction, and one that is false wherever variable 11 is not 0
+    rows += [
+        ([(k, BIG) for k in range(255)], [(2 ** 64 - 1, ONE)], [(k, BIG) for k in range(255)]),          # small = small
+        ([(Z + 0, ONE)], [(2 ** 64 - 1, ONE)], [(k, BIG) for k in range(255)]),                          # full (one variable) = small
+        ([(k, MBIG) for k in range(255)], [(k, BIG) for k in range(200)], [(Z + 1, ONE)]),               # small * small = full
+        ([(3, WIDE), (4, BIG)], [(5, MBIG), (6, TWO), (9, ONE)], [(Z + 3, TWO), (Z + 3, MONE)]),         # full * small = small (2z - z)
+        ([(10, TWO), (11, BIG)], [(2 ** 64 - 1, ONE)], [(10, TWO), (11, MBIG)]),                         # false unless v11 = 0
+    ]
+    starts, tv, tc = [], [], []
+    for parts in rows:
+        for part in parts:
+            starts.append(len(tv))
+            tv += [v for v, _ in part]
+            tc += [c for _, c in part]
+    starts.append(len(tv))
+    ev = zk.Evaluator()
+    ev.declare_inputs(0, n_base)
+    from zkinterface_ir_amd.sieve_writer import write_relation
+    ev.ingest_message(write_relation(p.to_bytes((p.bit_length() + 7) // 8, 'little'), 'arithmetic', 'simple', [],
+                                     [('witness', k) for k in range(n_base)]))
+    ev.finalize(retain_all=True)
+    ev.r1cs_load_csr(np.array(starts, dtype=np.uint32), np.array(tv, dtype=np.uint64), np.array(tc, dtype=np.uint32), cb, width, n_assign)
+    cc = ev.r1cs_class_counts()
+    assert cc['small'] >= 9 and cc['unit'] >= 1, cc
+    vals = [[int(rng.integers(0, 2 ** 62)) ** 5 % p for _ in range(n_base)] for _ in range(batch)]
+    for lane in range(batch):
+        if lane % 3 == 0:
+            vals[lane] = [p - 1] * n_base          # the largest sums
+        if lane % 5 == 0:
+            vals[lane][11] = 0                     # the false row holds here
+    w = np.zeros((batch, n_base, width), dtype=np.uint8)
+    for lane in range(batch):
+        for k in range(n_base):
+            w[lane, k] = np.frombuffer(vals[lane][k].to_bytes(width, 'little'), dtype=np.uint8)
+    ev.set_inputs(None, w.tobytes(), batch)
+    ev.replay()
+    for r in range(n_assign):          # one row per call: z0 is read by no later assigned row, but keep the order
+        ev.r1cs_assign(r, 1)
+
+    def comb(part, v):
+        return sum(pool[c] * (1 if var == 2 ** 64 - 1 else v[var]) for var, c in part) % p
+    got = ev.r1cs_get_vars([Z + k for k in range(n_assign)], batch)
+    for lane in range(batch):
+        v = list(vals[lane])
+        for r in range(n_assign):
+            v.append(comb(rows[r][0], v) * comb(rows[r][1], v) % p)
+        assert got[lane] == v[n_base:], lane
+    ev.r1cs_check()
+    ff, counts = ev.r1cs_results(batch)
+    false_row = len(rows) - 1
+    # the last row: 2 v10 + big v11 = 2 v10 - big v11  <=>  2 big v11 = 0  <=>  v11 = 0 (p odd, big != 0 mod p ... or p | 2 big)
+    for lane in range(batch):
+        holds = (2 * pool[BIG] * vals[lane][11]) % p == 0
+        assert (int(ff[lane]) == zk.NO_FAIL) == holds and (holds or int(ff[lane]) == false_row), (lane, int(ff[lane]))
