@@ -22,6 +22,8 @@ int main(int argc, char** argv) {
   }
   zkgpu_session* s = zkgpu_session_new();
   if (!s) return 2;
+  /* one statement, one witness: schedule the tape window by window while the relation is still being read */
+  if (!record_only) zkgpu_set_option(s, "stream", "1");
   if (vem) { /* the Validator (as prover) and the Stats see every message next to the Evaluator */
     zkgpu_set_option(s, "validate", "prover");
     zkgpu_set_option(s, "metrics", "1");

@@ -691,21 +691,25 @@ def metrics(paths_or_buffers):
     return ev.stats_json()
 
 
-def valid_eval_metrics(paths_or_buffers):
+def valid_eval_metrics(paths_or_buffers, stream=True):
     """`zki_sieve valid-eval-metrics` (cli.rs:333-363): every message is read once and fed to the Validator
     (as prover), the Evaluator and the Stats; returns (validator violations, evaluator violations, stats JSON).
     The evaluation itself is the GPU replay of `evaluate`."""
     ev = Evaluator()
     ev.set_option('validate', 'prover')
     ev.set_option('metrics', '1')
+    ev.set_option('stream', '1' if stream else '0')
     _ingest_any(ev, paths_or_buffers)
     return ev.validator_violations(), _finish_evaluate(ev), ev.stats_json()
 
 
-def evaluate(paths_or_buffers):
+def evaluate(paths_or_buffers, stream=True):
     """`zki_sieve evaluate` (cli.rs:315-320) for one statement: returns the violation list
-    (empty list = "The statement is TRUE!")."""
+    (empty list = "The statement is TRUE!").  stream: one statement, one witness -- what counts is relation in -> verdict
+    out, so the windows of the tape are scheduled (and, GF(2), the LDS program built) by the worker thread while the rest
+    of the relation is still being read (option "stream"; the verdict is the same either way, tests/test_stream.py)."""
     ev = Evaluator()
+    ev.set_option('stream', '1' if stream else '0')
     _ingest_any(ev, paths_or_buffers)
     return _finish_evaluate(ev)
 
