@@ -1,0 +1,79 @@
+// Helper threads next to the thread they work for.
+//
+// The decoder thread hands the recorder arrays of gates that the recorder frees and the decoder's next message reuses;
+// the scheduling worker and the task pool walk the tape the recorder wrote.  Producer and consumer of the same cache lines:
+// on the MI355X boxes (2 x EPYC 9575F: 16 CCDs of 8 cores, an L3 each) a decoder that the kernel places on ANOTHER CCD than
+// the recorder decodes the 1.3 GB C4 relation in 0.7-1.0 s instead of 0.28 s -- every line it writes is owned by the other
+// CCD's L3 -- and ingest takes 0.9 s instead of 0.41, slower than without the helper (0.63); on the same CCD, or its SMT
+// siblings, 0.41 s (profiles/r04_tuning_sweeps.txt, "ingest": taskset matrix).  A helper is therefore confined to the CPUs
+// that share the last-level cache with the thread that starts it (sysfs cache/index3/shared_cpu_list; the NUMA node's CPUs
+// where that cannot be read), intersected with the process's own mask; left alone when fewer than two CPUs remain or
+// ZKI_THREAD_AFFINITY=0.  The caller's own affinity is never touched.
+#pragma once
+#include <pthread.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <thread>
+
+namespace zki {
+
+struct NearbyCpus {
+  cpu_set_t set;
+  bool valid = false;
+};
+
+inline NearbyCpus cpus_near_caller() {
+  NearbyCpus out;
+  CPU_ZERO(&out.set);
+  const char* env = getenv("ZKI_THREAD_AFFINITY");
+  if (env && env[0] == '0') return out;
+  const int cpu = sched_getcpu();
+  if (cpu < 0) return out;
+  char path[160], list[4096];
+  bool have = false;
+  snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  if (FILE* f = fopen(path, "r")) {
+    have = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+  }
+  // no L3 entry: the caller's NUMA node (/sys/devices/system/cpu/cpu<N>/node<M> exists for exactly one M)
+  for (int m = 0; m < 64 && !have; ++m) {
+    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/node%d/cpulist", cpu, m);
+    FILE* f = fopen(path, "r");
+    if (!f) continue;
+    have = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+  }
+  if (!have) return out;
+  cpu_set_t allowed;
+  if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
+  int count = 0;
+  for (char* p = list; *p;) {   // "0-63,128-191"
+    char* end;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') {
+      b = strtol(p + 1, &end, 10);
+      p = end;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (c >= 0 && CPU_ISSET(c, &allowed)) {
+        CPU_SET(c, &out.set);
+        ++count;
+      }
+    while (*p == ',' || *p == ' ' || *p == '\n') ++p;
+  }
+  out.valid = count >= 2;
+  return out;
+}
+
+inline void keep_near(std::thread& t, const NearbyCpus& near) {
+  if (near.valid && t.joinable()) pthread_setaffinity_np(t.native_handle(), sizeof near.set, &near.set);
+}
+
+}  // namespace zki

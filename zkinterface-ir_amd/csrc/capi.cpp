@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/zkgpu.h"
+#include "affinity.hpp"
 #include "engine.hpp"
 #include "lds_program.hpp"
 #include "evaluator.hpp"
@@ -335,6 +336,7 @@ void stream_cut(void* arg) {
     if (s->backend.field().is_two && s->bool_path != 1) s->stream->upload = false;
     s->stream->sched.reset(new StreamScheduler(s->backend.field(), schedule_options(s, false)));
     s->stream->worker = std::thread(stream_worker, s);
+    keep_near(s->stream->worker, cpus_near_caller());
   }
   stream_enqueue(s, s->backend.tape().cuts.back(), false);
 }
@@ -700,7 +702,10 @@ struct DecodedMessage {
 class MessageDecoder {
  public:
   MessageDecoder(const uint8_t* data, const std::vector<std::pair<size_t, size_t>>& parts) : data_(data), parts_(parts) {
-    if (parts_.size() > 1) worker_ = std::thread([this] { run(); });
+    if (parts_.size() > 1) {
+      worker_ = std::thread([this] { run(); });
+      keep_near(worker_, cpus_near_caller());
+    }
   }
   ~MessageDecoder() {
     {
