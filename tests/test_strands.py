@@ -57,8 +57,8 @@ def _strands_of(ev):
     return out
 
 
-@pytest.mark.parametrize('strand_width,prefetch', [(3, '1'), (17, '1'), (64, '1'), (64, '0')])
-def test_no_entry_of_a_level_touches_what_another_wave_of_it_writes(strand_width, prefetch):
+@pytest.mark.parametrize('strand_width,prefetch,merge', [(3, '1', '1'), (17, '1', '1'), (64, '1', '1'), (64, '0', '1'), (64, '1', '0'), (64, '0', '0')])
+def test_no_entry_of_a_level_touches_what_another_wave_of_it_writes(strand_width, prefetch, merge):
     """the strand kernel runs a level's entries on four waves at once; program_sim runs them in turn: the static rule that
     makes the two the same (program_sim.strand_hazards), on the chained relation and on independent iterations, with the
     copies that bring wire-table operands into LDS ahead of their readers (option strand_prefetch) and without"""
@@ -67,11 +67,12 @@ def test_no_entry_of_a_level_touches_what_another_wave_of_it_writes(strand_width
         ev = zk.Evaluator()
         ev.set_option('strand_width', str(strand_width))
         ev.set_option('strand_prefetch', prefetch)
+        ev.set_option('strand_merge', merge)
         ev.declare_inputs(wl.n_instance, wl.n_witness)
         for m in wl.relation_messages():
             ev.ingest_message(m)
         ev.finalize()
-        copies_total = 0
+        copies_total = nops_total = 0
         for ops, first, count, level_ptr, lds_slots in _strands_of(ev):
             assert int(level_ptr[0]) == 0 and int(level_ptr[-1]) == count and all(np.diff(level_ptr.astype(np.int64)) > 0)
             lds = [int(x) & 0xFFFF for x in ops[first:first + count, 0] if int(x) & 0x40000000]
@@ -79,9 +80,14 @@ def test_no_entry_of_a_level_touches_what_another_wave_of_it_writes(strand_width
             assert program_sim.strand_hazards(ops, first, level_ptr) == []
             copies_in = sum(1 for o in ops[first:first + count] if int(o[1]) & 0xFF == 5 and int(o[0]) & 0x40000000 and not int(o[2]) & 0x40000000)
             copies_total += copies_in
+            nops_total += sum(1 for o in ops[first:first + count] if int(o[1]) & 0xFF == 0)
             seen += 1
         if wl.chained and strand_width >= 17:    # (the Switch weights of the chain are made level-wide in front of it)
             assert (copies_total > 0) == (prefetch == '1'), copies_total
+        if merge == '0':
+            assert nops_total == 0      # (no-ops only ever pad a joined level)
+        elif wl.chained and strand_width >= 17:
+            assert nops_total > 0
     assert seen >= 1
 
 
