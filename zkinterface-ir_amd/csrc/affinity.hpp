@@ -1,14 +1,15 @@
-// Helper threads next to the thread they work for.
+// A helper thread next to the thread it works for.
 //
-// The decoder thread hands the recorder arrays of gates that the recorder frees and the decoder's next message reuses;
-// the scheduling worker and the task pool walk the tape the recorder wrote.  Producer and consumer of the same cache lines:
-// on the MI355X boxes (2 x EPYC 9575F: 16 CCDs of 8 cores, an L3 each) a decoder that the kernel places on ANOTHER CCD than
-// the recorder decodes the 1.3 GB C4 relation in 0.7-1.0 s instead of 0.28 s -- every line it writes is owned by the other
-// CCD's L3 -- and ingest takes 0.9 s instead of 0.41, slower than without the helper (0.63); on the same CCD, or its SMT
-// siblings, 0.41 s (profiles/r04_tuning_sweeps.txt, "ingest": taskset matrix).  A helper is therefore confined to the CPUs
-// that share the last-level cache with the thread that starts it (sysfs cache/index3/shared_cpu_list; the NUMA node's CPUs
-// where that cannot be read), intersected with the process's own mask; left alone when fewer than two CPUs remain or
-// ZKI_THREAD_AFFINITY=0.  The caller's own affinity is never touched.
+// The decoder thread hands the recorder arrays of gates that the recorder frees and the decoder's next message reuses:
+// producer and consumer of the same cache lines.  On the MI355X boxes (2 x EPYC 9575F: 16 CCDs of 8 cores, an L3 each) a
+// decoder on ANOTHER CCD than the recorder decodes the 1.3 GB C4 relation in 0.7-1.0 s instead of 0.28 s -- every line it
+// writes is held by the other CCD's L3 -- and ingest takes 0.9 s instead of 0.41, slower than without the helper (0.63); on
+// the same CCD, or its SMT siblings, 0.41 s (profiles/r04_tuning_sweeps.txt, "ingest": taskset matrix).  The decoder
+// therefore FOLLOWS its consumer: the consumer notes the CPU it runs on each time it takes a message, and the decoder
+// confines itself to the CPUs that share the last-level cache with that CPU (sysfs cache/index3/shared_cpu_list,
+// intersected with the process's own mask) whenever that set changes.  Left alone when the set cannot be read, has fewer
+// than two CPUs, or ZKI_THREAD_AFFINITY=0.  The consumer's own affinity is never touched; the scheduling worker and the
+// task pool only read what the recorder appends (no line goes back and forth) and are placed by the kernel.
 #pragma once
 #include <pthread.h>
 #include <sched.h>
@@ -25,12 +26,11 @@ struct NearbyCpus {
   bool valid = false;
 };
 
-inline NearbyCpus cpus_near_caller() {
+inline NearbyCpus cpus_near(int cpu) {
   NearbyCpus out;
   CPU_ZERO(&out.set);
   const char* env = getenv("ZKI_THREAD_AFFINITY");
   if (env && env[0] == '0') return out;
-  const int cpu = sched_getcpu();
   if (cpu < 0) return out;
   char path[160], list[4096];
   bool have = false;
@@ -72,8 +72,28 @@ inline NearbyCpus cpus_near_caller() {
   return out;
 }
 
+inline NearbyCpus cpus_near_caller() { return cpus_near(sched_getcpu()); }
+
 inline void keep_near(std::thread& t, const NearbyCpus& near) {
   if (near.valid && t.joinable()) pthread_setaffinity_np(t.native_handle(), sizeof near.set, &near.set);
 }
+
+// the calling thread moves to the CPUs around `cpu` unless it is among them already; remembers the last set it chose
+class FollowCpu {
+ public:
+  void follow(int cpu) {
+    if (cpu < 0 || (have_ && CPU_ISSET(cpu, &current_.set))) return;
+    const NearbyCpus near = cpus_near(cpu);
+    if (!near.valid) return;
+    if (pthread_setaffinity_np(pthread_self(), sizeof near.set, &near.set) == 0) {
+      current_ = near;
+      have_ = true;
+    }
+  }
+
+ private:
+  NearbyCpus current_;
+  bool have_ = false;
+};
 
 }  // namespace zki

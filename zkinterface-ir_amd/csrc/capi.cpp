@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -336,7 +337,6 @@ void stream_cut(void* arg) {
     if (s->backend.field().is_two && s->bool_path != 1) s->stream->upload = false;
     s->stream->sched.reset(new StreamScheduler(s->backend.field(), schedule_options(s, false)));
     s->stream->worker = std::thread(stream_worker, s);
-    keep_near(s->stream->worker, cpus_near_caller());
   }
   stream_enqueue(s, s->backend.tape().cuts.back(), false);
 }
@@ -702,10 +702,8 @@ struct DecodedMessage {
 class MessageDecoder {
  public:
   MessageDecoder(const uint8_t* data, const std::vector<std::pair<size_t, size_t>>& parts) : data_(data), parts_(parts) {
-    if (parts_.size() > 1) {
-      worker_ = std::thread([this] { run(); });
-      keep_near(worker_, cpus_near_caller());
-    }
+    consumer_cpu_.store(sched_getcpu());
+    if (parts_.size() > 1) worker_ = std::thread([this] { run(); });
   }
   ~MessageDecoder() {
     {
@@ -718,6 +716,7 @@ class MessageDecoder {
   // message k (asked for in order)
   DecodedMessage next(size_t k) {
     if (!worker_.joinable()) return decode(k);
+    consumer_cpu_.store(sched_getcpu(), std::memory_order_relaxed);   // (the decoder follows: affinity.hpp)
     std::unique_lock<std::mutex> lk(mu_);
     cv_.wait(lk, [&] { return !ready_.empty(); });
     DecodedMessage d = std::move(ready_.front());
@@ -741,12 +740,14 @@ class MessageDecoder {
     return d;
   }
   void run() {
+    FollowCpu place;
     for (size_t k = 0; k < parts_.size(); ++k) {
       {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [&] { return stop_ || ready_.size() < 2; });   // (two decoded messages ahead at most: ~10 MB)
         if (stop_) return;
       }
+      place.follow(consumer_cpu_.load(std::memory_order_relaxed));
       DecodedMessage d = decode(k);
       {
         std::lock_guard<std::mutex> g(mu_);
@@ -761,6 +762,7 @@ class MessageDecoder {
   std::mutex mu_;
   std::condition_variable cv_;
   std::deque<DecodedMessage> ready_;
+  std::atomic<int> consumer_cpu_{-1};
   bool stop_ = false;
 };
 

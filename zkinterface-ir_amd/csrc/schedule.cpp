@@ -1,5 +1,4 @@
 #include "schedule.hpp"
-#include "affinity.hpp"
 
 #include "sieve/bignum.hpp"
 
@@ -96,11 +95,7 @@ void locality_order(uint32_t* ops, size_t cnt, Gathered&& gathered) {
 class TaskPool {
  public:
   explicit TaskPool(uint32_t workers) {
-    const NearbyCpus near = cpus_near_caller();   // (affinity.hpp: not on the other socket)
-    for (uint32_t t = 0; t < workers; ++t) {
-      threads_.emplace_back([this] { work(); });
-      keep_near(threads_.back(), near);
-    }
+    for (uint32_t t = 0; t < workers; ++t) threads_.emplace_back([this] { work(); });
   }
   ~TaskPool() {
     {
