@@ -228,7 +228,9 @@ size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size
  * inside the exponent ladder of a Switch weight.  The cuts depend on the tape alone, so the program is the same however
  * the relation was split into messages.  What a window may fuse or recycle rests on the drop records of the wires (the
  * bundled Evaluator gives them; zkgpu_backend_drop).  Set before the first Relation message; ignored with retain_all.
- * Default 0),
+ * Default: a relation over GF(2) is streamed (its program is the same either way), any other field is scheduled at
+ * finalize -- a streamed schedule of an arithmetic relation replays 1-36 % slower (windows limit fusion and strands),
+ * which a single statement does not notice and a batch session does: the one-statement entry points set "1"),
  * "schedule_threads" = N (threads ordering the levels of a window, default min(8, hardware threads)),
  * "hot_waves" = 0 | 3..7 (cap on the resident waves per SIMD of the Add/Mul kernel, by an unused LDS allocation;
  * 0 = no cap, the default -- a tuning handle, every cap measured slower on C2),

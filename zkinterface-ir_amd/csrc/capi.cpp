@@ -116,6 +116,7 @@ struct zkgpu_session {
   uint32_t level_ops_per_wave = 1;
   uint32_t hot_waves = 0;
   uint32_t stream_window = 0;        // option "stream": tape entries per window, 0 = schedule everything at finalize
+  bool stream_explicit = false;      // the caller set "stream" (otherwise GF(2) relations stream: stream_by_default)
   uint32_t sched_threads = 0;
   bool bank_aware = true;
   bool strand_lds = true, strand_prefetch = true, strand_merge = true;
@@ -766,6 +767,20 @@ class MessageDecoder {
   bool stop_ = false;
 };
 
+// "stream" not set by the caller: a relation over GF(2) is streamed anyway -- its windows end at the seams between
+// dependency levels and the program of the LDS-resident kernel comes out byte for byte as at finalize
+// (tests/test_stream.py, tests/test_full_size.py), so there is nothing to lose and 0.4 s of the C4 relation's 1.1 s to first
+// verdict to gain; for the other fields a streamed schedule replays 1-36 % slower (windows limit fusion and strands:
+// profiles/r04_tuning_sweeps.txt) and stays the caller's choice.  Called in front of the first thing recorded.
+void stream_by_default(zkgpu_session* s, const Value& modulus) {
+  if (s->stream_explicit || s->stream_window || s->finalized || s->backend.field_set() || s->backend.tape().size()) return;
+  size_t n = modulus.size();
+  while (n > 0 && modulus[n - 1] == 0) --n;
+  if (n != 1 || modulus[0] != 2) return;
+  s->stream_window = 131072u;
+  s->backend.set_window(s->stream_window, stream_cut, s);
+}
+
 void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
   const bool side_consumers = s->validator || s->stats;
   const auto parts = split_messages(data, len);
@@ -816,6 +831,7 @@ void ingest_stream(zkgpu_session* s, const uint8_t* data, size_t len) {
         }
         if (differs) switch_field(s, msg.relation.header, mask::contains_feature(msg.relation.gate_mask, mask::BOOL));
       }
+      if (msg.kind == Message::IsRelation) stream_by_default(s, msg.relation.header.field_characteristic);
       const auto t_rec = std::chrono::steady_clock::now();
       s->ev.ingest_message(msg, s->backend);
       s->record_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rec).count();
@@ -1078,6 +1094,7 @@ int zkgpu_backend_set_field(zkgpu_session* s, const uint8_t* modulus_le, size_t 
         return;
       }
     }
+    stream_by_default(s, modulus);
     s->backend.set_field(modulus, degree, is_boolean != 0);
   });
 }
@@ -1628,6 +1645,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       // tape entries per window; "1" = the default window of 131072 entries; before the first Relation message
       if (s->backend.tape().size() || s->finalized) throw std::runtime_error("stream must be set before the first Relation message");
       const long n = atol(v.c_str());
+      s->stream_explicit = true;
       s->stream_window = n <= 0 ? 0 : n == 1 ? 131072u : (uint32_t)std::max<long>(n, 16);
       s->backend.set_window(s->stream_window, s->stream_window ? stream_cut : nullptr, s);
     } else if (k == "strand_width") {
