@@ -80,3 +80,17 @@ def test_library_is_built_from_the_sources_in_the_tree():
 def test_library_on_the_gpu_box_is_built_from_the_sources_in_the_tree():
     import __graft_entry__ as entry
     assert entry.library_is_current()
+
+
+def test_helper_thread_placement_unit(tmp_path):
+    """tests/cpp/test_affinity.cpp: the CPUs that share a last-level cache with a CPU (csrc/affinity.hpp) hold that CPU and
+    nothing outside the process's mask; a thread that follows another ends up allowed next to it; the caller's own mask is
+    never touched; with ZKI_THREAD_AFFINITY=0 nothing is placed"""
+    import subprocess
+    csrc = os.path.join(ROOT, 'zkinterface-ir_amd', 'csrc')
+    exe = str(tmp_path / 'test_affinity')
+    subprocess.check_call(['g++', '-std=c++17', '-O2', '-pthread', '-I', csrc, os.path.join(ROOT, 'tests', 'cpp', 'test_affinity.cpp'), '-o', exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and 'bad=0' in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ZKI_THREAD_AFFINITY='0'))
+    assert r.returncode == 0 and 'not readable here' in r.stdout, r.stdout + r.stderr
