@@ -188,7 +188,7 @@ def finish_session(zk, wl, batch, lane_group, bool_path, streams, inst, wit, n_b
     for env, opt in (('ZKI_STREAM', 'stream'), ('ZKI_FUSE', 'fuse'), ('ZKI_OPW', 'level_ops_per_wave'), ('ZKI_HOT_WAVES', 'hot_waves'),
                      ('ZKI_GRAPH', 'graph'), ('ZKI_XCD_MAP', 'xcd_map'), ('ZKI_SORT_BY_OPERAND', 'sort_by_operand'),
                      ('ZKI_STRAND_WIDTH', 'strand_width'), ('ZKI_BANK_AWARE', 'bank_aware'), ('ZKI_FERMAT', 'fermat'),
-                     ('ZKI_PAIR', 'pair'), ('ZKI_STRAND_LDS', 'strand_lds'), ('ZKI_STRAND_PREFETCH', 'strand_prefetch'), ('ZKI_STRAND_MERGE', 'strand_merge'), ('ZKI_BOOL_NARROW', 'bool_narrow_width')):
+                     ('ZKI_PAIR', 'pair'), ('ZKI_STRAND_LDS', 'strand_lds'), ('ZKI_STRAND_PREFETCH', 'strand_prefetch'), ('ZKI_STRAND_MERGE', 'strand_merge'), ('ZKI_STRAND_REASSOC', 'strand_reassociate'), ('ZKI_STRAND_SPLIT', 'strand_split_inputs'), ('ZKI_BOOL_NARROW', 'bool_narrow_width')):
         if os.environ.get(env):
             ev.set_option(opt, os.environ[env])
     ev.declare_inputs(wl.n_instance, wl.n_witness)

@@ -6,7 +6,8 @@ levelisation, slot reuse, constant pool -- against the oracle without a GPU.
 It is not a product path and is never imported outside tests/."""
 
 OP = {'nop': 0, 'add': 1, 'mul': 2, 'addc': 3, 'mulc': 4, 'copy': 5, 'const': 6, 'instance': 7, 'witness': 8,
-      'assert': 9, 'and': 10, 'xor': 11, 'not': 12, 'nz': 13, 'carry': 14}
+      'assert': 9, 'and': 10, 'xor': 11, 'not': 12, 'nz': 13, 'carry': 14,
+      'input_raw': 15, 'input_conv': 16}    # (strands: an instance / witness entry in two halves, device/args.hpp)
 
 
 def is_canonical_field(p):
@@ -136,8 +137,16 @@ def simulate(ops, launches, const_words, words_per_const, n_slots, p, instances,
                 r = 1 - slots[a] if boolean else (R % p if slots[a] == 0 and not source_is_nonzero(code) else 0)
             elif kind == OP['const']:
                 r = consts[a]
-            elif kind in (OP['instance'], OP['witness'], OP['carry']):
-                stream = {OP['instance']: 0, OP['witness']: 1, OP['carry']: 2}[kind]
+            elif kind == OP['input_raw']:     # the words of the input as they lie in the buffer, into an LDS value
+                assert sequential and dst & K_SLOT_IN_LDS and a1 in (0, 1)
+                r = ('raw', a1, a)
+            elif kind in (OP['instance'], OP['witness'], OP['carry'], OP['input_conv']):
+                if kind == OP['input_conv']:  # ... and their conversion: position b of stream a1, read back from LDS value a
+                    assert slots[a] == ('raw', a1, b), 'the conversion reads an LDS value its fetch did not write'
+                    reads.add(a)
+                    stream, a = a1, b
+                else:
+                    stream = {OP['instance']: 0, OP['witness']: 1, OP['carry']: 2}[kind]
                 v = streams[stream][a]
                 mode = mode_of(stream, a)
                 # wider than the limbs of this field: reduced like any other value where only arithmetic reads it (the
@@ -219,7 +228,7 @@ def strand_hazards(ops, first, level_ptr):
     its result is the kernel's only if no entry of a level touches what an entry of ANOTHER wave of that level writes.
     Returns the list of violations (empty: the sequential run is what the GPU computes)."""
     K = OP
-    one_operand = (K['addc'], K['mulc'], K['copy'], K['nz'], K['not'], K['assert'])
+    one_operand = (K['addc'], K['mulc'], K['copy'], K['nz'], K['not'], K['assert'], K['input_conv'])
 
     def reads(o):
         kind, ea, eb, pair = int(o[1]) & 0xFF, (int(o[1]) >> 8) & 3, (int(o[1]) >> 10) & 3, (int(o[1]) >> 12) & 3

@@ -76,7 +76,12 @@ def test_arithmetic_kernels_at_bn254_width():
     for name, k in res.items():
         # (the input streams' descriptors sit behind one pointer, device/args.hpp InputAux: in the kernarg block they made
         # the cold kernels spill 28 SGPRs and the strands of a structured relation 13 % slower)
-        assert k['scratch'] == 0 and k['vgpr_spill'] == 0 and k['sgpr_spill'] == 0, (name, k)
+        # (the strand kernel keeps a program entry in SGPRs while another one runs: hipcc parks three wave-uniform conditions
+        # there -- lane < batch and the two forms of "the input buffers hold N-word values" --, six SGPRs in the lanes of one
+        # VGPR, written once per launch and read back only by the entries that load an input, never by the Add/Mul entries of
+        # the dependency chain; anything beyond that is a regression)
+        allowed = 6 if 'replay_strand_kernel' in name else 0
+        assert k['scratch'] == 0 and k['vgpr_spill'] == 0 and k['sgpr_spill'] <= allowed, (name, k)
 
 
 def test_any_modulus_kernels_private_memory():

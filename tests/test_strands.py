@@ -57,37 +57,56 @@ def _strands_of(ev):
     return out
 
 
-@pytest.mark.parametrize('strand_width,prefetch,merge', [(3, '1', '1'), (17, '1', '1'), (64, '1', '1'), (64, '0', '1'), (64, '1', '0'), (64, '0', '0')])
-def test_no_entry_of_a_level_touches_what_another_wave_of_it_writes(strand_width, prefetch, merge):
+_PASSES = ('strand_prefetch', 'strand_merge', 'strand_reassociate', 'strand_split_inputs')
+
+
+@pytest.mark.parametrize('strand_width,off', [(3, ()), (17, ()), (64, ())] + [(64, (p,)) for p in _PASSES] + [(64, _PASSES)])
+def test_no_entry_of_a_level_touches_what_another_wave_of_it_writes(strand_width, off):
     """the strand kernel runs a level's entries on four waves at once; program_sim runs them in turn: the static rule that
-    makes the two the same (program_sim.strand_hazards), on the chained relation and on independent iterations, with the
-    copies that bring wire-table operands into LDS ahead of their readers (option strand_prefetch) and without"""
+    makes the two the same (program_sim.strand_hazards), and the oracle's verdicts from the simulated program, on the chained
+    relation and on independent iterations, with each pass over the finished strand -- operands copied into LDS ahead of
+    their readers, levels joined without a barrier, products re-associated off the chain, inputs fetched ahead of their
+    conversion -- on, off alone, and all off"""
     seen = 0
     for wl in (workloads.StructuredArith(N=40, chained=True), workloads.StructuredArith(N=12, chained=False)):
         ev = zk.Evaluator()
         ev.set_option('strand_width', str(strand_width))
-        ev.set_option('strand_prefetch', prefetch)
-        ev.set_option('strand_merge', merge)
+        for p in _PASSES:
+            ev.set_option(p, '0' if p in off else '1')
         ev.declare_inputs(wl.n_instance, wl.n_witness)
         for m in wl.relation_messages():
             ev.ingest_message(m)
         ev.finalize()
-        copies_total = nops_total = 0
+        info = ev.schedule_info()
+        copies = nops = raws = convs = 0
         for ops, first, count, level_ptr, lds_slots in _strands_of(ev):
             assert int(level_ptr[0]) == 0 and int(level_ptr[-1]) == count and all(np.diff(level_ptr.astype(np.int64)) > 0)
             lds = [int(x) & 0xFFFF for x in ops[first:first + count, 0] if int(x) & 0x40000000]
             assert all(k < lds_slots for k in lds)
             assert program_sim.strand_hazards(ops, first, level_ptr) == []
-            copies_in = sum(1 for o in ops[first:first + count] if int(o[1]) & 0xFF == 5 and int(o[0]) & 0x40000000 and not int(o[2]) & 0x40000000)
-            copies_total += copies_in
-            nops_total += sum(1 for o in ops[first:first + count] if int(o[1]) & 0xFF == 0)
+            for o in ops[first:first + count]:
+                kind = int(o[1]) & 0xFF
+                copies += kind == 5 and bool(int(o[0]) & 0x40000000) and not int(o[2]) & 0x40000000
+                nops += kind == 0
+                raws += kind == program_sim.OP['input_raw']
+                convs += kind == program_sim.OP['input_conv']
             seen += 1
+        assert raws == convs
         if wl.chained and strand_width >= 17:    # (the Switch weights of the chain are made level-wide in front of it)
-            assert (copies_total > 0) == (prefetch == '1'), copies_total
-        if merge == '0':
-            assert nops_total == 0      # (no-ops only ever pad a joined level)
-        elif wl.chained and strand_width >= 17:
-            assert nops_total > 0
+            assert (copies > 0) == ('strand_prefetch' not in off), copies
+            assert (raws > 0) == ('strand_split_inputs' not in off), raws
+            if 'strand_merge' not in off:
+                assert nops > 0
+        if 'strand_merge' in off:
+            assert nops == 0      # (no-ops only ever pad a joined level)
+        # ... and the program computes the oracle's verdicts
+        ops, launches, consts, _ = ev.schedule_dump()
+        inst, wit, _bad = wl.inputs(2, corrupt_every=2)
+        for lane in range(2):
+            iv, wv = _ints(inst, lane, wl.n_instance), _ints(wit, lane, wl.n_witness)
+            ref = oracle_lane(wl.mod_le, iv, wv, wl.relation_messages(), wl.width, trace=False)
+            _, ff, noncanon = program_sim.simulate(ops, launches, consts, info['words_per_const'], info['slots'], wl.p, iv, wv)
+            assert not noncanon and expected_product_violations(ev, ff) == ref.violations, (lane, off)
     assert seen >= 1
 
 

@@ -119,7 +119,7 @@ struct zkgpu_session {
   bool stream_explicit = false;      // the caller set "stream" (otherwise GF(2) relations stream: stream_by_default)
   uint32_t sched_threads = 0;
   bool bank_aware = true;
-  bool strand_lds = true, strand_prefetch = true, strand_merge = true;
+  bool strand_lds = true, strand_prefetch = true, strand_merge = true, strand_reassociate = true, strand_split_inputs = true;
   uint32_t bool_narrow_width = 0;   // 0 = the scheduler's default
   uint32_t strand_width = 0;   // 0 = the scheduler's default
   std::unique_ptr<StreamState> stream;
@@ -224,6 +224,8 @@ ScheduleOptions schedule_options(const zkgpu_session* s, bool retain_all) {
   opt.strand_lds = s->strand_lds;
   opt.strand_prefetch = s->strand_prefetch;
   opt.strand_merge = s->strand_merge;
+  opt.strand_reassociate = s->strand_reassociate;
+  opt.strand_split_inputs = s->strand_split_inputs;
   if (s->bool_narrow_width) opt.bool_narrow_width = s->bool_narrow_width;
   if (s->strand_width) opt.strand_width = s->strand_width;
   return opt;
@@ -1606,7 +1608,7 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
     // the scheduler of a streamed ingest took its options when the first window was cut: a later change would be ignored
     // silently by the windows already scheduled -- refuse it instead
     if (s->stream && (k == "fuse" || k == "pair" || k == "fermat" || k == "propagate_copies" || k == "sort_by_operand" ||
-                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "strand_prefetch" || k == "strand_merge" || k == "bool_narrow_width" || k == "schedule_threads"))
+                      k == "bank_aware" || k == "strand_width" || k == "strand_lds" || k == "strand_prefetch" || k == "strand_merge" || k == "strand_reassociate" || k == "strand_split_inputs" || k == "bool_narrow_width" || k == "schedule_threads"))
       throw std::runtime_error(k + ": the streamed schedule has started (option \"stream\"); set scheduling options before the first Relation message");
     if (k == "bool_path") {
       if (v == "auto") s->bool_path = 0;
@@ -1658,6 +1660,10 @@ int zkgpu_set_option(zkgpu_session* s, const char* key, const char* value) {
       s->strand_prefetch = v != "0";
     } else if (k == "strand_merge") {
       s->strand_merge = v != "0";
+    } else if (k == "strand_reassociate") {
+      s->strand_reassociate = v != "0";
+    } else if (k == "strand_split_inputs") {
+      s->strand_split_inputs = v != "0";
     } else if (k == "r1cs_coef_classes") {
       if (s->r1cs_ready) throw std::runtime_error("r1cs_coef_classes: set it before the rows are made (zkgpu_r1cs_from_tape / zkgpu_r1cs_load_csr)");
       s->r1cs_coef_classes = v != "0";

@@ -58,6 +58,9 @@ enum OpKind : u32 {
   OP_NOT = 12,
   OP_NZ = 13,  // 1 if the operand is non-zero else 0: x^(p-1) over a prime field (scheduler-made, schedule.cpp)
   OP_CARRY = 14,  // dst = to_mont(carry[lane][a]): a wire of the previous field segment, as the integer it held
+  // strands only (schedule.cpp): an instance / witness entry in two halves, so that neither is the longest entry of its level
+  OP_INPUT_RAW = 15,   // LDS value dst = the words of stream a1 (0 instance, 1 witness), position a0, as they lie in the buffer
+  OP_INPUT_CONV = 16,  // dst = what OP_INSTANCE / OP_WITNESS makes of position b0 of stream a1, the words taken from LDS value a0
 };
 
 struct TapeOp {
@@ -132,7 +135,7 @@ struct ReplayArgs2 {
   u32* first_fail;
   u32* lane_flags;
   u32 xcd_chunks;
-  u32 op_stride;          // 1 or 4, see the kernel
+  u32 op_stride;          // 1 or 4, see the kernel; a strand launch: 1 = the input buffers hold values of exactly N words
   const InputAux* aux;    // as in ReplayArgs
 };
 constexpr u32 kStampLevels = 256;

@@ -224,16 +224,21 @@ __device__ __forceinline__ Fp<N> input_chunk(const void* __restrict__ base, u32 
 // words, R = 2^(32 N): x R mod p = ((..(top R + next) R + ..) R + low) R, i.e. to_mont(group) added to the running value
 // times R (a Montgomery product by R^2) -- and only where its bits matter (0xFF: it reaches an integer bit operation or
 // Evaluator::get as it is; 0x03: and / xor read the raw input, which their N-word operand cannot hold) is the lane flagged.
+// (input_op in its parts: the lane is flagged where the raw words of position `position` of stream `stream` must not be
+// what they are -- the mode byte comes from memory through two dependent loads --, and the conversion)
 template <int N, class Args>
-__device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& args, u32 lane_g, bool lane_valid, const FieldParams& fp) {
-  const u32 stream = kind == OP_INSTANCE ? 0u : kind == OP_WITNESS ? 1u : 2u;
-  bool too_wide;
-  const Fp<N> raw = stream_load<N>(stream, position, args, lane_g, lane_valid, too_wide);
+__device__ __forceinline__ void input_check(u32 stream, u32 position, const Fp<N>& raw, bool too_wide, const Args& args, u32 lane_g,
+                                            bool lane_valid, const FieldParams& fp) {
   InputAuxS* aux = (InputAuxS*)(unsigned long long)args.aux;
   const uint8_t* modes = stream == 0 ? aux->strict_inst : stream == 1 ? aux->strict_wit : aux->strict_carry;
   const u32 mode = modes[position];
   if (lane_valid && ((too_wide && (mode == 0xFF || mode == 0x03)) || (mode == 0xFF && fp_geq_p<N>(raw, fp))))
     atomicOr(&args.lane_flags[lane_g], kLaneFlagNonCanonical);
+}
+template <int N, class Args>
+__device__ __forceinline__ Fp<N> input_convert(u32 stream, u32 position, const Fp<N>& raw, bool too_wide, const Args& args, u32 lane_g,
+                                               bool lane_valid, const FieldParams& fp) {
+  InputAuxS* aux = (InputAuxS*)(unsigned long long)args.aux;
   if (__ballot(too_wide && lane_valid) == 0ull) return fp_to_mont<N>(raw, fp);   // of any value < R: the Montgomery form of its residue
   // some lane holds a value of more than N words (rare: one pass over the groups for the whole wave)
   const void* base = stream == 2 ? (const void*)aux->carry : (const void*)(stream ? args.wit : args.inst);
@@ -247,6 +252,15 @@ __device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& ar
   for (u32 c = groups - 1; c-- > 0;)
     acc = fp_add<N>(fp_mul<N>(acc, r2, fp), fp_to_mont<N>(input_chunk<N>(base, lane_g, n_vals, position, lane_valid, stride, c), fp), fp);
   return acc;
+}
+
+template <int N, class Args>
+__device__ __forceinline__ Fp<N> input_op(u32 kind, u32 position, const Args& args, u32 lane_g, bool lane_valid, const FieldParams& fp) {
+  const u32 stream = kind == OP_INSTANCE ? 0u : kind == OP_WITNESS ? 1u : 2u;
+  bool too_wide;
+  const Fp<N> raw = stream_load<N>(stream, position, args, lane_g, lane_valid, too_wide);
+  input_check<N>(stream, position, raw, too_wide, args, lane_g, lane_valid, fp);
+  return input_convert<N>(stream, position, raw, too_wide, args, lane_g, lane_valid, fp);
 }
 
 // An operand of an integer bit operation (`and` / `xor` over an odd field, evaluator.rs:924-933): the canonical integer of
@@ -497,6 +511,36 @@ __device__ __forceinline__ void fused_entry(const TapeOp2& op, uint4* __restrict
     case OP_INSTANCE:
     case OP_WITNESS:
     case OP_CARRY: r = input_op<N>(kind, op.a0, args, lane_g, lane_valid, fp); break;
+    case OP_INPUT_RAW:    // (strands: the fetch from HBM in one level ...
+      if constexpr (LDS) {
+        // a buffer whose values are wider than this field's N words (a session of several fields) is fetched by the
+        // conversion itself, the general way
+        if (args.op_stride == 1u /* (a strand launch: the buffers hold N-word values, device/args.hpp) */) {
+          bool too_wide;
+          r = stream_load<N>(op.a1, op.a0, args, lane_g, lane_valid, too_wide);
+          input_check<N>(op.a1, op.a0, r, too_wide, args, lane_g, lane_valid, fp);   // (here, off the chain: the flag only accumulates)
+        } else {
+          has_out = false;
+        }
+      } else {
+        has_out = false;
+      }
+      break;
+    case OP_INPUT_CONV:   // ... the conversion in a later one)
+      if constexpr (LDS) {
+        bool too_wide = false;
+        Fp<N> raw;
+        if (args.op_stride == 1u /* (a strand launch: the buffers hold N-word values, device/args.hpp) */) {
+          raw = slot_load<N, LDS>(T, op.a0, lane);   // checked by the entry that fetched it
+        } else {
+          raw = stream_load<N>(op.a1, op.b0, args, lane_g, lane_valid, too_wide);
+          input_check<N>(op.a1, op.b0, raw, too_wide, args, lane_g, lane_valid, fp);
+        }
+        r = input_convert<N>(op.a1, op.b0, raw, too_wide, args, lane_g, lane_valid, fp);
+      } else {
+        has_out = false;
+      }
+      break;
     case OP_ASSERT: {
       has_out = false;
       const bool nz = !fp_is_zero<N>(slot_load<N, LDS>(T, op.a0, lane)) ||

@@ -272,6 +272,15 @@ void Engine::validate_program(const Schedule& s, uint32_t n_instance, uint32_t n
       case TK_INSTANCE: slot(i, dst); if (a0 >= n_instance) fail(i, "an instance position"); break;
       case TK_WITNESS: slot(i, dst); if (a0 >= n_witness) fail(i, "a witness position"); break;
       case TK_CARRY: slot(i, dst); if (a0 >= n_carry) fail(i, "a carried value"); break;
+      // strands: an input in two halves (device/args.hpp OP_INPUT_RAW / OP_INPUT_CONV) -- the raw words go into an LDS value
+      case TK_INPUT_RAW:
+        slot(i, dst);
+        if (!(dst & zkgpu::kSlotInLds) || a1 > 1 || a0 >= (a1 ? n_witness : n_instance)) fail(i, "an input position or its LDS value");
+        break;
+      case TK_INPUT_CONV:
+        slot(i, dst); slot(i, a0);
+        if (!(a0 & zkgpu::kSlotInLds) || a1 > 1 || b0 >= (a1 ? n_witness : n_instance)) fail(i, "an input position or its LDS value");
+        break;
       case TK_ASSERT: slot(i, a0); source(i, src); break;
       case TK_NOP: break;
       default: fail(i, "an unknown kind");
@@ -683,8 +692,10 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
     a.aux = (const zkgpu::InputAux*)d_input_aux_;
     if (L.sequential) {
       // a strand: one workgroup per lane block walks the levels of the run, barrier between levels
+      // (a strand has no use for the grid fields: op_stride tells it whether the input buffers hold values of exactly N
+      // words -- what the two halves of a split input entry need to know without a trip to InputAux)
       a.xcd_chunks = 0;
-      a.op_stride = 1;
+      a.op_stride = in_stride_ / 4 == nwords_ ? 1u : 0u;
       launch_strand(nwords_, L.has_bitops ? zkgpu::kFusedAll : zkgpu::kFusedMisc, dim3(lbs), st, a,
                     (const uint32_t*)d_level_ptr_ + L.level_ptr, L.strand_levels, (size_t)L.lds_slots * ((nwords_ + 3) / 4) * 64 * 16, fp);
       return;

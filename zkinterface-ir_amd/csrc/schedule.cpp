@@ -1,5 +1,7 @@
 #include "schedule.hpp"
 
+#include <unordered_map>
+
 #include "sieve/bignum.hpp"
 
 #include <string.h>
@@ -1568,7 +1570,7 @@ void StreamScheduler::Impl::emit_launches() {
 // pointed at the LDS value.  Entries only: tape handles, levels and the slot allocation are what they were; the copies use
 // LDS values above the strand's own, recycled once their reader has run.
 void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
-  if (!s.fused || !opt.strand_lds || !(opt.strand_prefetch || opt.strand_merge)) return;
+  if (!s.fused || !opt.strand_lds || !(opt.strand_prefetch || opt.strand_merge || opt.strand_reassociate || opt.strand_split_inputs)) return;
   const uint32_t value_bytes = ((field.nwords + 3) / 4) * 64 * 16;
   const uint32_t lds_cap = std::min<uint32_t>(1024, kStrandLdsBytes / std::max<uint32_t>(value_bytes, 1));
   int64_t shift = 0;   // entries inserted in front of the launch being looked at
@@ -1591,7 +1593,7 @@ void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
           if (eb) out[n++] = &d.b1;
           if (pair) out[n++] = &d.pad1;
           break;
-        case TK_ADDC: case TK_MULC: case TK_COPY: case TK_NZ: case TK_NOT: case TK_ASSERT: out[n++] = &d.a0; break;
+        case TK_ADDC: case TK_MULC: case TK_COPY: case TK_NZ: case TK_NOT: case TK_ASSERT: case TK_INPUT_CONV: out[n++] = &d.a0; break;
         case TK_AND: case TK_XOR:
           if (!(d.a0 & kOperandIsSource)) out[n++] = &d.a0;
           if (!(d.b0 & kOperandIsSource)) out[n++] = &d.b0;
@@ -1609,9 +1611,120 @@ void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
     };
     auto heavy_entry = [](const DevOp2& d) {
       const uint32_t k = d.kind & 0xFF;
-      return k == TK_MUL || k == TK_MULC || k == TK_INSTANCE || k == TK_WITNESS || k == TK_CARRY ||
+      return k == TK_MUL || k == TK_MULC || k == TK_INSTANCE || k == TK_WITNESS || k == TK_CARRY || k == TK_INPUT_CONV ||
              (k == TK_ADD && (((d.kind >> 8) & 3) == 2 || ((d.kind >> 10) & 3) == 2 || ((d.kind >> 12) & 3) == 2));
     };
+    // Products re-associated off the dependency chain.  A fused entry (z * x) * y -- or (x * y) * z -- whose z was made in the
+    // level right in front of it while x and y have been there for two levels or more (a witness, a Switch weight) is two
+    // dependent products on the chain; x * y does not depend on the chain at all: it becomes an entry of its own on a spare
+    // wave of an earlier level (an LDS value above the strand's own) and the chain keeps z * (x * y), ONE product.  Field
+    // multiplication is associative and every value canonical, so the result is the same bits.
+    uint32_t reassoc_lds = 0;   // LDS values the products taken off the chain live in
+    size_t n_reassoc = 0, n_split = 0;
+    if ((opt.strand_reassociate || opt.strand_split_inputs) && L.lds_slots < lds_cap) {
+      const uint32_t cap = std::min<uint32_t>(16, lds_cap - L.lds_slots);
+      struct Slot { uint32_t loaded = 0, needed = 0; };
+      std::vector<Slot> rs;
+      std::unordered_map<uint32_t, uint32_t> last_write;   // slot -> level of its latest write (levels in front of q)
+      std::vector<std::vector<DevOp2>> add(nl);
+      std::vector<uint32_t> cnt(nl, 0);
+      for (uint32_t q = 0; q < nl; ++q) cnt[q] = lp[q + 1] - lp[q];
+      auto avail = [&](uint32_t slot) -> int64_t {   // -1: there before the strand
+        auto it = last_write.find(slot);
+        if (it == last_write.end()) return (slot & kSlotInLds) ? INT64_MAX : -1;   // (an LDS value nobody wrote: leave it alone)
+        return it->second;
+      };
+      auto lds_value = [&](uint32_t t, uint32_t q) -> uint32_t {   // an LDS value written at level t, last read at level q
+        uint32_t r = kInf;
+        for (uint32_t j = 0; j < rs.size() && r == kInf; ++j)
+          if (rs[j].needed < t) r = j;
+        if (r == kInf) {
+          if (rs.size() >= cap) return kInf;
+          rs.emplace_back();
+          r = (uint32_t)rs.size() - 1;
+        }
+        rs[r].loaded = t;
+        rs[r].needed = q;
+        reassoc_lds = std::max(reassoc_lds, r + 1);
+        return kSlotInLds | (L.lds_slots + r);
+      };
+      for (uint32_t q = 0; q < nl; ++q) {
+        // An input of the strand -- fetch from HBM, canonical check, conversion (a product) -- is the longest entry a level
+        // of a chain can hold (3,600 cycles on the chained structured relation, beside two products of 1,300).  It is taken
+        // apart: the words as they lie in the buffer go into an LDS value on a spare wave of an earlier level (the one with
+        // the most room of the three in front), the conversion stays where the input was.
+        for (uint32_t k = lp[q]; k < lp[q + 1] && q >= 1 && opt.strand_split_inputs; ++k) {
+          DevOp2& e = ent[k];
+          const uint32_t kind = e.kind & 0xFF;
+          if (kind != TK_INSTANCE && kind != TK_WITNESS) continue;
+          uint32_t t = kInf, room = 0;
+          for (uint32_t back = 1; back <= 3 && back <= q; ++back) {
+            const uint32_t used = cnt[q - back] + (uint32_t)add[q - back].size();
+            if (used < 4 && 4 - used > room) { t = q - back; room = 4 - used; }
+          }
+          if (t == kInf) continue;
+          const uint32_t m = lds_value(t, q);
+          if (m == kInf) continue;
+          const uint32_t stream = kind == TK_WITNESS ? 1u : 0u, position = e.a0;
+          add[t].push_back(DevOp2{m, TK_INPUT_RAW, position, stream, 0, 0, 0, 0});
+          e.kind = TK_INPUT_CONV;
+          e.a0 = m;
+          e.a1 = stream;
+          e.b0 = position;
+          ++n_split;
+        }
+        for (uint32_t k = lp[q]; k < lp[q + 1] && q >= 2 && opt.strand_reassociate; ++k) {
+          DevOp2& e = ent[k];
+          const uint32_t kind = e.kind & 0xFF, ea = (e.kind >> 8) & 3, eb = (e.kind >> 10) & 3, pair = (e.kind >> 12) & 3;
+          if (kind != TK_MUL || pair || !((ea == 2 && eb == 0) || (ea == 0 && eb == 2))) continue;
+          // the three factors: i0 * i1 is the inner product, o the outer factor
+          const uint32_t i0 = ea == 2 ? e.a0 : e.b0, i1 = ea == 2 ? e.a1 : e.b1, o = ea == 2 ? e.b0 : e.a0;
+          const int64_t av[3] = {avail(i0), avail(i1), avail(o)};
+          const int64_t late = (int64_t)q - 1;
+          const int n_late = (av[0] == late) + (av[1] == late) + (av[2] == late);
+          if (n_late != 1 || av[0] > late || av[1] > late || av[2] > late) continue;
+          // z: the late factor; x, y: the other two
+          uint32_t z, x, y;
+          if (av[0] == late) { z = i0; x = i1; y = o; }
+          else if (av[1] == late) { z = i1; x = i0; y = o; }
+          else continue;   // the outer factor is the late one: the inner product is off the chain already
+          const int64_t ready = std::max(avail(x), avail(y));
+          uint32_t t = kInf;
+          for (uint32_t back = 1; back <= 3 && back <= q; ++back) {
+            if ((int64_t)(q - back) <= ready) break;
+            if (cnt[q - back] + add[q - back].size() < 4) { t = q - back; break; }
+          }
+          if (t == kInf) continue;
+          const uint32_t m = lds_value(t, q);
+          if (m == kInf) continue;
+          add[t].push_back(DevOp2{m, TK_MUL, x, 0, y, 0, 0, 0});
+          e.kind = TK_MUL;
+          e.a0 = z;
+          e.a1 = 0;
+          e.b0 = m;
+          e.b1 = 0;
+          ++n_reassoc;
+        }
+        for (uint32_t k = lp[q]; k < lp[q + 1]; ++k) {
+          uint32_t w[2];
+          const int nw = writes(ent[k], w);
+          for (int j = 0; j < nw; ++j) last_write[w[j]] = q;
+        }
+      }
+      if (n_reassoc + n_split) {
+        std::vector<DevOp2> out;
+        out.reserve(ent.size() + n_reassoc + n_split);
+        std::vector<uint32_t> nlp(1, 0);
+        for (uint32_t q = 0; q < nl; ++q) {
+          out.insert(out.end(), ent.begin() + lp[q], ent.begin() + lp[q + 1]);
+          out.insert(out.end(), add[q].begin(), add[q].end());
+          nlp.push_back((uint32_t)out.size());
+        }
+        ent.swap(out);
+        lp.swap(nlp);
+      }
+    }
+    const uint32_t lds_base = L.lds_slots + reassoc_lds;   // the copies' LDS values come behind
     std::vector<uint8_t> written(std::max(n_slots, s.n_slots) + 1, 0);   // wire-table slots the strand itself writes: never prefetched
     std::vector<uint32_t> count(nl, 0), heavy(nl, 0);
     for (uint32_t q = 0; q < nl; ++q)
@@ -1628,7 +1741,7 @@ void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
       uint32_t loaded = 0, needed = 0;   // level of the copy, level of its last reader so far
     };
     std::vector<Ring> ring;
-    const uint32_t ring_cap = opt.strand_prefetch && L.lds_slots < lds_cap ? std::min<uint32_t>(32, lds_cap - L.lds_slots) : 0;
+    const uint32_t ring_cap = opt.strand_prefetch && lds_base < lds_cap ? std::min<uint32_t>(32, lds_cap - lds_base) : 0;
     std::vector<std::vector<DevOp2>> extra(nl);
     uint32_t ring_used = 0;
     for (uint32_t q = 1; q < nl && ring_cap; ++q)
@@ -1660,11 +1773,11 @@ void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
             ring[r].loaded = t;
             ring[r].needed = q;
             ring_used = std::max(ring_used, r + 1);
-            DevOp2 c{kSlotInLds | (L.lds_slots + r), TK_COPY, slot, 0, 0, 0, 0, 0};
+            DevOp2 c{kSlotInLds | (lds_base + r), TK_COPY, slot, 0, 0, 0, 0, 0};
             extra[t].push_back(c);
           }
           ring[r].needed = std::max(ring[r].needed, q);
-          *ops[j] = kSlotInLds | (L.lds_slots + r);
+          *ops[j] = kSlotInLds | (lds_base + r);
         }
       }
     size_t n_extra = 0;
@@ -1753,18 +1866,23 @@ void StreamScheduler::Impl::prefetch_strand_inputs(size_t first_launch) {
     }
     if (getenv("ZKI_SCHED_PROFILE") && n_merged)
       fprintf(stderr, "[schedule]   %zu of its levels joined the level in front of them (%zu no-op entries)\n", n_merged, n_nops);
-    if (!n_extra && !n_merged) continue;   // nothing changed
-    n_extra += n_nops;
+    if (getenv("ZKI_SCHED_PROFILE") && n_reassoc)
+      fprintf(stderr, "[schedule]   %zu products taken off the dependency chain (x * y of (z * x) * y)\n", n_reassoc);
+    if (getenv("ZKI_SCHED_PROFILE") && n_split) fprintf(stderr, "[schedule]   %zu inputs fetched a level or more ahead of their conversion\n", n_split);
+    if (!n_extra && !n_merged && !n_reassoc && !n_split) continue;   // nothing changed
+    const uint32_t old_count = L.count;
     s.ops2.erase(s.ops2.begin() + L.first, s.ops2.begin() + L.first + L.count);
     s.ops2.insert(s.ops2.begin() + L.first, out.begin(), out.end());
     std::copy(nlp.begin(), nlp.end(), s.strand_level_ptr.begin() + L.level_ptr);
     L.count = (uint32_t)out.size();
     L.ops_per_wave = std::max<uint32_t>(L.count, 1);
-    L.lds_slots += ring_used;
+    L.lds_slots += reassoc_lds + ring_used;
     L.strand_levels = (uint32_t)nlp.size() - 1;
-    s.n_strand_prefetches += n_extra - n_nops;
+    s.n_strand_prefetches += n_extra;
     s.n_strand_levels_joined += n_merged;
-    shift += (int64_t)n_extra;
+    s.n_strand_reassociated += n_reassoc;
+    s.n_strand_inputs_split += n_split;
+    shift += (int64_t)out.size() - (int64_t)old_count;
   }
 }
 

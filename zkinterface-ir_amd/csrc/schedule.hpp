@@ -73,6 +73,8 @@ struct ScheduleOptions {
   bool strand_lds = true;           // strands keep the values that never leave them in LDS (kSlotInLds)
   bool strand_prefetch = true;      // ... and copy what they read out of the wire table into LDS a few levels ahead (needs strand_lds)
   bool strand_merge = true;         // ... and levels that need no barrier between them are one level (needs strand_lds)
+  bool strand_reassociate = true;   // ... and (z * x) * y with z fresh off the chain and x, y long there keeps z * (x * y) (needs strand_lds)
+  bool strand_split_inputs = true;  // ... and an input's fetch runs a level or more ahead of its conversion (needs strand_lds)
 };
 
 struct Schedule {
@@ -83,6 +85,8 @@ struct Schedule {
   uint64_t n_copies_elided = 0;
   uint64_t n_ladders = 0;           // exponent ladders replaced by one entry each
   uint64_t n_paired = 0;            // producers evaluated inside a pair entry (counted in n_absorbed too)
+  uint64_t n_strand_inputs_split = 0;    // inputs of a strand fetched ahead of their conversion
+  uint64_t n_strand_reassociated = 0;    // products of a strand computed off its dependency chain
   uint64_t n_strand_levels_joined = 0;   // strand levels that run behind the level in front of them without a barrier
   uint64_t n_strand_prefetches = 0; // copy entries that bring a strand's wire-table operands into LDS ahead of their reader
   std::vector<Launch> launches;
@@ -125,6 +129,8 @@ struct Schedule {
     c.n_paired = n_paired;
     c.n_strand_prefetches = n_strand_prefetches;
     c.n_strand_levels_joined = n_strand_levels_joined;
+    c.n_strand_reassociated = n_strand_reassociated;
+    c.n_strand_inputs_split = n_strand_inputs_split;
     c.launches = launches;
     c.strict_instance = strict_instance;
     c.strict_witness = strict_witness;

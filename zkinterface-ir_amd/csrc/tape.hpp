@@ -21,6 +21,10 @@ enum TapeKind : uint8_t {
   TK_CARRY = 14,  // a value carried over from the previous field segment of the session (a: its index in the carry
                   // stream).  Not a backend call of the reference: the wire simply lived on when the modulus changed
                   // (evaluator.rs:232-237); a source like Instance / Witness, holding the UNREDUCED integer
+  // scheduler only (strands, schedule.cpp): an Instance / Witness entry taken apart -- the value as it lies in the input
+  // buffer copied into an LDS value of the strand (a: position, a1: 0 instance / 1 witness), and its conversion from there
+  // (a: that LDS value, a1: the stream, b: the position) one or more levels later
+  TK_INPUT_RAW = 15, TK_INPUT_CONV = 16,
 };
 const char* tape_kind_name(uint8_t k);  // names of SURVEY.md Appendix A ("copy", "mul", ...)
 
