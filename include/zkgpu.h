@@ -190,8 +190,11 @@ size_t zkgpu_input_modes(const zkgpu_session* s, int witness, uint8_t* out, size
  * "strand_lds" = 0|1 (a strand keeps the values that never leave it in the workgroup's LDS; default 1),
  * "strand_prefetch" = 0|1 (what a strand reads out of the wire table is copied into LDS one to three levels ahead, by
  * entries of their own on waves that idle; default 1), "strand_merge" = 0|1 (levels of a strand that need no barrier
- * between them run as one level, a dependent entry behind its producer on the same wave; default 1) -- both need
- * "strand_lds",
+ * between them run as one level, a dependent entry behind its producer on the same wave; default 1),
+ * "strand_reassociate" = 0|1 (a fused product (z * x) * y whose z comes out of the level in front while x and y have been
+ * there for two levels or more keeps z * (x * y), x * y on a spare wave of an earlier level; default 1),
+ * "strand_split_inputs" = 0|1 (an instance / witness value of a strand is fetched and checked a level or more ahead of its
+ * conversion; default 1) -- all four need "strand_lds",
  * "bool_narrow_width" = 3..2048 (GF(2), LDS-resident kernel: a level of fewer ops than this runs as packets of 64 entries
  * walked by one wave, without a barrier or padded rows; default 257),
  * "r1cs_coef_classes" = 0|1 (the row kernel's cheap paths for combinations whose coefficients are all 1 / -1 or small
