@@ -86,7 +86,7 @@ def check_probe_outputs(name, wl, outs, lane_offset):
     oracle-chain hashes, so a wrong but self-consistent device result cannot pass.  Returns how many lanes were checked."""
     hashes = golden_hashes(name)
     # (the fixtures were made for the default wiring, mix and sizes: any other relation has other outputs)
-    default = ((name == 'c2' and (wl.W, wl.D) == (4096, 256) and getattr(wl, 'default_mix', True)) or
+    default = ((name == 'c2' and (wl.W, wl.D) == (4096, 256) and getattr(wl, 'default_mix', True) and getattr(wl, 'p', 0).bit_length() == 254 and getattr(wl, 'p', 0) % 2 ** 32 == 0xf0000001) or
                (name == 'c4' and (wl.W, wl.D) == (16384, 640) and getattr(wl, 'wiring', 'random') == 'random'))
     if hashes is None or not default:
         return 0
@@ -554,7 +554,9 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
     lane_group = args.lane_group if named else 0
     if name == 'c2':
         mp = os.environ.get('ZKI_C2_MUL_PERCENT')  # developer sensitivity runs only; the metric is quoted on the default mix
-        wl = workloads.ArithLayered(W=width or 4096, D=depth or 256, mul_percent=int(mp) if mp else None)
+        mod = os.environ.get('ZKI_C2_MODULUS')     # developer runs only: the C2 shape over another characteristic, e.g. an even
+        wl = workloads.ArithLayered(W=width or 4096, D=depth or 256, mul_percent=int(mp) if mp else None,   # one (any-modulus kernels)
+                                    **({'p': int(mod, 0)} if mod else {}))
         batch = bpg or 1024
         bytes_table, bool_path = BYTES_PER_OP, None
     elif name == 'structured':
@@ -683,6 +685,10 @@ def bench_tape(name, args, zk, workloads, ctx, steps, warmup, headline, cpu_budg
             wl_name = ('BASELINE configs[1]: BN254 scalar field, %d-gate Add/Mul relation (W=%d x D=%d), '
                        'witness batch=%d per GPU, %d GPU(s)' % (gates, wl.W, wl.D, batch, world))
             kernel = 'replay_fused_kernel<8, 0>' if fused else 'replay_kernel<8, false, false>'
+            if ev.field_representation() == 2:      # (ZKI_C2_MODULUS: a characteristic the Montgomery kernels do not take)
+                kernel = 'replay_generic_kernel (canonical residues, Barrett; unfused)'
+                dtype = 'u32 x k (canonical residues, exact integer)'
+                wl_name = 'the C2 relation over the characteristic %#x (developer run): ' % wl.p + wl_name
         elif structured:
             metric = ('backend-ops/sec (whole node), 256-bit field, For/Call/Switch relation of ~1M backend calls, batched '
                       'witnesses (one unit = one value-returning ZKBackend call of the reference evaluator)')
