@@ -37,7 +37,9 @@ def _width(p):
 def test_arithmetic_of_the_kernels_against_python_integers():
     rnd = random.Random(11)
     mods = [2, 3, 4, 6, 2 ** 31, 2 ** 32, 2 ** 32 - 1, 2 ** 32 + 1, 2 ** 64, 2 ** 64 - 2, 101, 2 ** 255 - 19, 2 ** 521 - 1, 2 ** 96,
-            2 ** 128, 2 ** 4095, 2 ** 4096 - 1]
+            2 ** 128, 2 ** 4095, 2 ** 4096 - 1,
+            # powers of two: the rings Z / 2^B take the low B bits instead of a Barrett reduction (generic_kernels.hpp g_low_bits)
+            8, 2 ** 33, 2 ** 63, 2 ** 65, 2 ** 100, 2 ** 127, 2 ** 256, 2 ** 1000]
     for bits in (2, 3, 17, 31, 32, 33, 63, 64, 65, 95, 96, 97, 128, 255, 256, 511, 512, 513, 600, 1024, 2047, 2048, 4096):
         mods += [rnd.getrandbits(bits) | (1 << (bits - 1)) | 1, (rnd.getrandbits(bits) | (1 << (bits - 1))) & ~1]
     for p in mods:

@@ -90,11 +90,18 @@ def test_any_modulus_kernels_private_memory():
     small classes, scratch memory bounded by the class for the large ones"""
     res = kernel_resources.resources('kernels_generic.hip')
     caps = {}
+    small = {}
     for name, k in res.items():
-        m = re.search(r'replay_generic_kernel<(\d+)>', name)
-        if m:
+        m = re.search(r'replay_generic_kernel<(\d+), (\d+)>', name)
+        if m and int(m.group(2)) == 0:
             caps[int(m.group(1))] = k
+        elif m:
+            small[int(m.group(2))] = k
     assert sorted(caps) == [16, 32, 64, 128]
+    # characteristics of up to eight words: word counts at compile time, everything in registers (SmallParams)
+    assert sorted(small) == [1, 2, 3, 4, 5, 6, 7, 8]
+    for kc, k in small.items():
+        assert k['scratch'] == 0 and k['agprs'] == 0 and k['occupancy'] >= 3, (kc, k)
     for cap, k in caps.items():
         assert k['vgprs'] + k['agprs'] <= 512 and k['occupancy'] >= 1, (cap, k)
         assert k['scratch'] <= 40 * cap, (cap, k)     # 3.6 KB per lane at 4096 bits

@@ -40,6 +40,7 @@ struct GenericParams {
   u32 nwords;                       // words per wire value: 2 * ceil(bits / 64), k or k + 1
   u32 p[kGenericMaxWords];
   u32 mu[kGenericMaxWords + 2];     // floor(2^(64 k) / p): k + 2 words (the last is 0 unless p is a power of 2^32)
+  u32 pow2_bits;                    // B where p = 2^B (arithmetic of a ring Z / 2^B: x mod p is the low B bits, no Barrett), else 0
 };
 
 enum OpKind : u32 {
@@ -251,7 +252,7 @@ ZKGPU_DECLARE_WIDTH(16)
 #undef ZKGPU_DECLARE_WIDTH
 
 // any-modulus path (kernels_generic.hip)
-void launch_replay_generic(dim3 grid, hipStream_t st, const ReplayArgs& a, const GenericParams* gp_device, u32 nwords);
+void launch_replay_generic(dim3 grid, hipStream_t st, const ReplayArgs& a, const GenericParams* gp_device, u32 nwords, u32 k_words);
 void launch_dump_generic(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump, u32 batch,
                          u32* out, u32 nwords);
 // the arithmetic of that path run on the HOST (the same functions): op 0 add, 1 mul, 2 reduce(a), 3 and, 4 xor; a, b, out

@@ -20,7 +20,8 @@ namespace zkgpu {
 #define ZKGPU_HD __host__ __device__ __forceinline__
 
 // 1 if a >= p, a: len >= k words, p: k words
-ZKGPU_HD bool g_geq_p(const u32* a, u32 len, const GenericParams* gp) {
+template <class P>
+ZKGPU_HD bool g_geq_p(const u32* a, u32 len, const P* gp) {
   const u32 k = gp->k;
   for (u32 i = len; i-- > k;)
     if (a[i]) return true;
@@ -28,7 +29,8 @@ ZKGPU_HD bool g_geq_p(const u32* a, u32 len, const GenericParams* gp) {
     if (a[i] != gp->p[i]) return a[i] > gp->p[i];
   return true;
 }
-ZKGPU_HD void g_sub_p(u32* a, u32 len, const GenericParams* gp) {
+template <class P>
+ZKGPU_HD void g_sub_p(u32* a, u32 len, const P* gp) {
   const u32 k = gp->k;
   u32 borrow = 0;
   for (u32 i = 0; i < len; ++i) {
@@ -62,9 +64,21 @@ struct GAcc {
 
 // out = x mod p for x < 2^(64 k), x: 2 k words (HAC 14.42: q3 = floor(floor(x / b^(k-1)) * mu / b^(k+1)),
 // r = (x - q3 * p) mod b^(k+1), then at most two subtractions of p).  out: n = nwords >= k words.
-template <int CAP>
-ZKGPU_HD void g_barrett(const u32* x, u32* out, const GenericParams* gp) {
+// p = 2^B (a ring Z / 2^B, e.g. 2^32 or 2^64): x mod p is the low B bits of x -- out[0 .. n) from the low words of x
+template <class P>
+ZKGPU_HD void g_low_bits(const u32* x, u32 x_words, u32* out, const P* gp) {
+  const u32 B = gp->pow2_bits, n = gp->nwords, full = B / 32, rest = B % 32;
+  for (u32 i = 0; i < n; ++i) out[i] = i < full && i < x_words ? x[i] : 0u;
+  if (rest && full < n && full < x_words) out[full] = x[full] & ((1u << rest) - 1u);
+}
+
+template <int CAP, class P>
+ZKGPU_HD void g_barrett(const u32* x, u32* out, const P* gp) {
   const u32 k = gp->k, n = gp->nwords;
+  if (gp->pow2_bits) {
+    g_low_bits(x, 2 * k, out, gp);
+    return;
+  }
   // q3: columns k + 1 .. 2 k + 2 of q1 * mu, q1 = x[k - 1 .. 2 k - 1] (k + 1 words), mu k + 2 words
   u32 q3[CAP + 2];
   GAcc acc{0, 0};
@@ -92,11 +106,20 @@ ZKGPU_HD void g_barrett(const u32* x, u32* out, const GenericParams* gp) {
 }
 
 // out = a * b mod p (a, b canonical, n words each)
-template <int CAP>
-ZKGPU_HD void g_mul(const u32* a, const u32* b, u32* out, const GenericParams* gp) {
+template <int CAP, class P>
+ZKGPU_HD void g_mul(const u32* a, const u32* b, u32* out, const P* gp) {
   const u32 k = gp->k;
   u32 x[2 * CAP];
   GAcc acc{0, 0};
+  if (gp->pow2_bits) {   // only the columns below 2^B count: half a product, no reduction
+    const u32 kw = (gp->pow2_bits + 31) / 32;
+    for (u32 col = 0; col < kw; ++col) {
+      for (u32 i = 0; i <= col; ++i) acc.mac(a[i], b[col - i]);
+      x[col] = acc.shift();
+    }
+    g_low_bits(x, kw, out, gp);
+    return;
+  }
   for (u32 col = 0; col < 2 * k; ++col) {
     const u32 i_lo = col >= k ? col - (k - 1) : 0, i_hi = col < k ? col : k - 1;
     for (u32 i = i_lo; i <= i_hi; ++i) acc.mac(a[i], b[col - i]);
@@ -106,11 +129,21 @@ ZKGPU_HD void g_mul(const u32* a, const u32* b, u32* out, const GenericParams* g
 }
 
 // out = a + b mod p
-template <int CAP>
-ZKGPU_HD void g_add(const u32* a, const u32* b, u32* out, const GenericParams* gp) {
+template <int CAP, class P>
+ZKGPU_HD void g_add(const u32* a, const u32* b, u32* out, const P* gp) {
   const u32 k = gp->k, n = gp->nwords;
   u32 r[CAP + 1];
   u64 c = 0;
+  if (gp->pow2_bits) {   // the sum wraps
+    const u32 kw = (gp->pow2_bits + 31) / 32;
+    for (u32 i = 0; i < kw; ++i) {
+      c += (u64)a[i] + b[i];
+      r[i] = (u32)c;
+      c >>= 32;
+    }
+    g_low_bits(r, kw, out, gp);
+    return;
+  }
   for (u32 i = 0; i < k; ++i) {
     c += (u64)a[i] + b[i];
     r[i] = (u32)c;
@@ -122,8 +155,8 @@ ZKGPU_HD void g_add(const u32* a, const u32* b, u32* out, const GenericParams* g
 }
 
 // out = raw mod p for a raw value of n words (n <= k + 1 <= 2 k)
-template <int CAP>
-ZKGPU_HD void g_reduce(const u32* raw, u32* out, const GenericParams* gp) {
+template <int CAP, class P>
+ZKGPU_HD void g_reduce(const u32* raw, u32* out, const P* gp) {
   const u32 k = gp->k, n = gp->nwords;
   u32 x[2 * CAP];
   for (u32 i = 0; i < 2 * k; ++i) x[i] = i < n ? raw[i] : 0u;
@@ -132,15 +165,18 @@ ZKGPU_HD void g_reduce(const u32* raw, u32* out, const GenericParams* gp) {
 
 // (a & b) % p and (a ^ b) % p on canonical values (evaluator.rs:924-933): the conjunction is below both operands, the
 // exclusive or below 2^bits(p) <= 2 p
-ZKGPU_HD void g_and(const u32* a, const u32* b, u32* out, const GenericParams* gp) {
+template <class P>
+ZKGPU_HD void g_and(const u32* a, const u32* b, u32* out, const P* gp) {
   for (u32 i = 0; i < gp->nwords; ++i) out[i] = a[i] & b[i];
 }
-ZKGPU_HD void g_xor(const u32* a, const u32* b, u32* out, const GenericParams* gp) {
+template <class P>
+ZKGPU_HD void g_xor(const u32* a, const u32* b, u32* out, const P* gp) {
   const u32 n = gp->nwords;
   for (u32 i = 0; i < n; ++i) out[i] = a[i] ^ b[i];
   if (g_geq_p(out, n, gp)) g_sub_p(out, n, gp);
 }
-ZKGPU_HD void g_indicator(bool one, u32* out, const GenericParams* gp) {
+template <class P>
+ZKGPU_HD void g_indicator(bool one, u32* out, const P* gp) {
   for (u32 i = 0; i < gp->nwords; ++i) out[i] = 0;
   out[0] = one ? 1u : 0u;
 }
@@ -198,9 +234,9 @@ __device__ __forceinline__ bool g_stream_load(u32 stream, u32 position, const Re
   return hi != 0;
 }
 
-template <int CAP>
+template <int CAP, class P>
 __device__ __forceinline__ bool g_unreduced_source_is_nonzero(u32 code, const ReplayArgs& args, u32 lane_g, bool lane_valid,
-                                                              const GenericParams* gp) {
+                                                              const P* gp) {
   if (code < 2) return code == 1;
   const u32 q = code - 2;
   u32 raw[CAP];
@@ -208,10 +244,22 @@ __device__ __forceinline__ bool g_unreduced_source_is_nonzero(u32 code, const Re
   return lane_valid && (too_wide || g_geq_p(raw, gp->nwords, gp));
 }
 
+// The parameters of a SMALL characteristic (up to eight words: the rings Z / 2^32 .. Z / 2^128, even moduli up to 256 bits) with the
+// word counts known at compile time and the words themselves in registers: every loop of the arithmetic above has a
+// constant trip count then, its private arrays become registers, and p and mu are not fetched word by word from memory --
+// the C2 relation over Z / 2^64 ran in 103 ms on the general kernel (profiles/r04_tuning_sweeps.txt section 5).
+template <int KC>
+struct SmallParams {
+  static constexpr u32 k = KC, nwords = 2 * ((KC + 1) / 2);
+  u32 p[KC];
+  u32 mu[KC + 2];
+  u32 pow2_bits;
+};
+
 // One wave = 64 witnesses x `ops_per_wave` consecutive entries of the unfused program (the TapeOp entries of
 // replay_kernel; the scheduler makes no fused or pair entries for these fields).
-template <int CAP>
-__global__ __launch_bounds__(256) void replay_generic_kernel(const ReplayArgs args, const GenericParams* __restrict__ gp) {
+template <int CAP, class P>
+__device__ __forceinline__ void replay_generic_body(const ReplayArgs& args, const P* __restrict__ gp) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   const u32 chunk = args.xcd_chunks ? (blockIdx.x >> 3) % args.xcd_chunks : blockIdx.x;
@@ -320,6 +368,24 @@ __global__ __launch_bounds__(256) void replay_generic_kernel(const ReplayArgs ar
       default: has_out = false; break;
     }
     if (has_out) g_wire_store(T + (size_t)op.dst * rec, n, r);
+  }
+}
+
+// KC = 0: any characteristic up to 32 CAP bits, the parameters read from memory; KC > 0: one of KC words (SmallParams)
+template <int CAP, int KC>
+__global__ __launch_bounds__(256) void replay_generic_kernel(const ReplayArgs args, const GenericParams* __restrict__ gp) {
+  if constexpr (KC == 0) {
+    replay_generic_body<CAP>(args, gp);
+  } else {
+    typedef const GenericParams __attribute__((address_space(4))) GpS;   // (wave-uniform: scalar loads)
+    GpS* g = (GpS*)(unsigned long long)gp;
+    SmallParams<KC> sp;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) sp.p[i] = g->p[i];
+#pragma unroll
+    for (int i = 0; i < KC + 2; ++i) sp.mu[i] = g->mu[i];
+    sp.pow2_bits = g->pow2_bits;
+    replay_generic_body<CAP>(args, &sp);
   }
 }
 

@@ -37,6 +37,12 @@ static zkgpu::GenericParams generic_params(const FieldHost& f) {
   gp.nwords = f.nwords;
   memcpy(gp.p, f.p, sizeof gp.p);
   memcpy(gp.mu, f.mu, sizeof gp.mu);
+  // a power of two?  (one bit set in the k words)
+  uint32_t bits_set = 0, at = 0;
+  for (uint32_t i = 0; i < gp.k && i < (uint32_t)zkgpu::kGenericMaxWords; ++i)
+    for (uint32_t b = 0; b < 32; ++b)
+      if (gp.p[i] >> b & 1) { ++bits_set; at = 32 * i + b; }
+  gp.pow2_bits = bits_set == 1 && at >= 2 ? at : 0;   // (2 itself is GF(2), never here)
   return gp;
 }
 
@@ -401,6 +407,7 @@ void Engine::load_program(const Schedule& s, const FieldHost& f, uint32_t n_inst
     zkgpu::GenericParams gp = generic_params(f);
     if (!d_generic_params_) HIP_OK(hipMalloc(&d_generic_params_, sizeof gp));
     HIP_OK(hipMemcpy(d_generic_params_, &gp, sizeof gp, hipMemcpyHostToDevice));
+    generic_k_words_ = gp.k;
   } else if (!s.boolean_path && f.nwords > (uint32_t)zkgpu::kMaxWords) {
     throw std::runtime_error("Engine: the field characteristic is wider than the Montgomery kernels");
   }
@@ -737,7 +744,7 @@ void Engine::launch_one(size_t li, uint32_t lb0, uint32_t lbs, void* stream) {
   a.lane_flags = (zkgpu::u32*)verdict_flags();
   a.aux = (const zkgpu::InputAux*)d_input_aux_;
   a.xcd_chunks = xcd_chunks;
-  if (generic_) zkgpu::launch_replay_generic(grid, st, a, (const zkgpu::GenericParams*)d_generic_params_, nwords_);
+  if (generic_) zkgpu::launch_replay_generic(grid, st, a, (const zkgpu::GenericParams*)d_generic_params_, nwords_, generic_k_words_);
   else launch_plain(nwords_, sched_.has_bitops, grid, st, a, fp);
 }
 

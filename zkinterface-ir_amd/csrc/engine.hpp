@@ -127,6 +127,7 @@ class Engine {
   bool boolean_ = false;
   bool generic_ = false;           // canonical residues, the any-modulus kernels (FieldHost::generic)
   void* d_generic_params_ = nullptr;   // zkgpu::GenericParams
+  uint32_t generic_k_words_ = 0;       // words of the characteristic (which instantiation of the any-modulus kernel runs)
   uint32_t nwords_ = 0, elem_bytes_ = 0;
   uint32_t n_inst_ = 0, n_wit_ = 0;
   uint32_t batch_ = 0, lane_blocks_ = 0, lanes_per_block_ = 64, lane_group_ = 0;

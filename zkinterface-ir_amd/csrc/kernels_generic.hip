@@ -4,11 +4,24 @@
 
 namespace zkgpu {
 
-void launch_replay_generic(dim3 grid, hipStream_t st, const ReplayArgs& a, const GenericParams* gp, u32 nwords) {
-  if (nwords <= 16) replay_generic_kernel<16><<<grid, 256, 0, st>>>(a, gp);
-  else if (nwords <= 32) replay_generic_kernel<32><<<grid, 256, 0, st>>>(a, gp);
-  else if (nwords <= 64) replay_generic_kernel<64><<<grid, 256, 0, st>>>(a, gp);
-  else replay_generic_kernel<kGenericMaxWords><<<grid, 256, 0, st>>>(a, gp);
+// k_words: the words of the characteristic (GenericParams::k): up to eight of them run the instantiation with the word counts
+// at compile time (generic_kernels.hpp SmallParams)
+void launch_replay_generic(dim3 grid, hipStream_t st, const ReplayArgs& a, const GenericParams* gp, u32 nwords, u32 k_words) {
+  switch (k_words <= 8 ? k_words : 0) {
+    case 1: replay_generic_kernel<8, 1><<<grid, 256, 0, st>>>(a, gp); return;
+    case 2: replay_generic_kernel<8, 2><<<grid, 256, 0, st>>>(a, gp); return;
+    case 3: replay_generic_kernel<8, 3><<<grid, 256, 0, st>>>(a, gp); return;
+    case 4: replay_generic_kernel<8, 4><<<grid, 256, 0, st>>>(a, gp); return;
+    case 5: replay_generic_kernel<8, 5><<<grid, 256, 0, st>>>(a, gp); return;
+    case 6: replay_generic_kernel<8, 6><<<grid, 256, 0, st>>>(a, gp); return;
+    case 7: replay_generic_kernel<8, 7><<<grid, 256, 0, st>>>(a, gp); return;
+    case 8: replay_generic_kernel<8, 8><<<grid, 256, 0, st>>>(a, gp); return;
+    default: break;
+  }
+  if (nwords <= 16) replay_generic_kernel<16, 0><<<grid, 256, 0, st>>>(a, gp);
+  else if (nwords <= 32) replay_generic_kernel<32, 0><<<grid, 256, 0, st>>>(a, gp);
+  else if (nwords <= 64) replay_generic_kernel<64, 0><<<grid, 256, 0, st>>>(a, gp);
+  else replay_generic_kernel<kGenericMaxWords, 0><<<grid, 256, 0, st>>>(a, gp);
 }
 
 void launch_dump_generic(dim3 grid, hipStream_t st, const uint4* table, u32 n_slots, const u32* slots, u32 n_dump, u32 batch,
