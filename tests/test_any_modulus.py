@@ -269,7 +269,9 @@ def test_session_between_gf2_and_another_field_on_gpu(order):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('p', [2 ** 89 - 2, 2 ** 607 - 1])
+# (three words on the compile-time instantiation, 19 on the general kernel; the rings Z / 2^64 and Z / 2^128 and an even
+# characteristic of eight words: replay_generic_kernel<8, 2 | 3 | 4 | 5 | 8>)
+@pytest.mark.parametrize('p', [2 ** 89 - 2, 2 ** 607 - 1, 2 ** 64, 2 ** 128, 2 ** 256 - 2, 2 ** 33])
 def test_wide_levels_and_a_full_batch_on_gpu(p):
     """1024 lanes (16 lane blocks: the XCD-aware grid, two streams) over levels of 48 gates, the verdict of every lane against
     Python integers; the product of the last layer is pinned by an instance value per lane"""
